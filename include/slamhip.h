@@ -1,0 +1,146 @@
+/* slamhip.h -- C ABI of libslamhip.so: the MI355X (gfx950) EKF-SLAM / FastSLAM
+ * filter core that replaces the hot path of andrewadare/SLAM.jl.
+ *
+ * The reference has no FFI/plugin interface: its hot path is four plain Julia
+ * functions.  Each entry point below cites the reference
+ * function (path:line relative to the SLAM.jl tree) whose work it takes over;
+ * the Julia-side binding a maintainer would add is shown in INTEGRATION.md and
+ * shipped as slam.jl_amd/SLAMHip.jl.
+ *
+ * Conventions
+ *  - every function returns an int status (SLAM_OK = 0, negative = error) and
+ *    never throws; slam_last_error() gives a thread-local message;
+ *  - on error the filter state is unchanged;
+ *  - the state (x, P) lives on the device for the life of the handle
+ *    (P at N = 10k is 1.6 GB: moving it per call would dwarf the update);
+ *  - host arrays passed in are borrowed for the duration of the call only;
+ *  - matrices are column-major (Julia order).  Small matrices Q, R are
+ *    double[4] = {m11, m21, m12, m22}.  Observations are double pairs
+ *    (range, bearing) = the memory order of Julia's 2 x nz matrix z;
+ *  - landmark indices are 1-based like the reference's idf;
+ *  - dtype selects the storage / bulk-arithmetic type of x and P (and of the
+ *    host buffers of set_state/get_state); the scalar geometry (Jacobians,
+ *    innovations, the k x k factorisation) is always evaluated in double;
+ *  - one HIP stream per handle; calls on one handle must be serialised by the
+ *    caller, distinct handles may be used from distinct threads.
+ */
+#ifndef SLAMHIP_H
+#define SLAMHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAM_OK            0
+#define SLAM_E_BADARG     -1   /* null pointer, negative size, index out of range   */
+#define SLAM_E_CAPACITY   -2   /* augment beyond max_landmarks (Julia: would grow)   */
+#define SLAM_E_NOTPD      -3   /* innovation covariance not positive definite
+                                  (Julia: chol throws PosDefException, ekf.jl:70)    */
+#define SLAM_E_HIP        -4   /* HIP runtime error / no usable device               */
+#define SLAM_E_NOMEM      -5   /* device or host allocation failed                   */
+
+#define SLAM_F32 0
+#define SLAM_F64 1
+
+#define SLAM_FORM_CHOLESKY 0   /* P -= W1*W1'  (reference form, src/ekf.jl:67-75)    */
+#define SLAM_FORM_JOSEPH   1   /* P -= K*T' + T*K', T = P*H' - K*S/2 (not in the
+                                  reference; BASELINE.json config 5)                 */
+
+/* kernel ids for slam_ekf_timing_read */
+#define SLAM_K_GATE      0     /* gating sweep                                      */
+#define SLAM_K_GATE_FIN  1     /* per-observation decision                          */
+#define SLAM_K_PREDICT   2
+#define SLAM_K_AUGMENT   3
+#define SLAM_K_PHT       4     /* P*H' panel                                        */
+#define SLAM_K_FACTOR    5     /* S, factorisation, C = inv(chol(S))                */
+#define SLAM_K_W1        6     /* W1 = PHt*C, x += W*v                              */
+#define SLAM_K_SYRK      7     /* P -= W1*W1' (or Joseph rank-2k)                   */
+#define SLAM_K_COUNT     8
+
+typedef struct slam_ekf* slam_ekf_t;
+
+const char* slam_last_error(void);
+/* Number of usable HIP devices (0 if none); never fails. */
+int slam_device_count(void);
+
+/* ---- EKFSlamState (src/common.jl:22-28): construction, I/O ------------------ */
+
+/* Replaces `EKFSlamState(x, cov)` (src/common.jl:25-28; built at
+ * sim/ekfslam-sim.jl:42).  State starts as x = 0 (3), P = 0 (3x3), 0 landmarks;
+ * capacity for max_landmarks is allocated once (the reference re-allocates P per
+ * new feature, src/ekf.jl:108-109). */
+int slam_ekf_create(slam_ekf_t* h, int dtype, int max_landmarks, int device);
+int slam_ekf_destroy(slam_ekf_t h);
+
+/* Upload x (n) and P (n x n, leading dimension ldP >= n, column-major) from host
+ * buffers of the handle's dtype; n = 3 + 2*N.  Replaces assigning state.x /
+ * state.cov (sim/ekfslam-sim.jl:100,117,120; sim/browser/wsserver.jl:161-174). */
+int slam_ekf_set_state(slam_ekf_t h, const void* x, const void* P, int n, int ldP);
+/* Same, from DEVICE buffers on the handle's device (stream-ordered D2D copy). */
+int slam_ekf_set_state_device(slam_ekf_t h, const void* d_x, const void* d_P, int n, int ldP);
+/* Download; either pointer may be NULL.  Reads of state.x / state.cov. */
+int slam_ekf_get_state(slam_ekf_t h, void* x, void* P, int n, int ldP);
+int slam_ekf_get_pose(slam_ekf_t h, double pose[3]);       /* state.x[1:3]          */
+int slam_ekf_num_landmarks(slam_ekf_t h, int* N);          /* (length(x)-3)/2       */
+int slam_ekf_dtype(slam_ekf_t h, int* dtype);
+/* Raw device views (for zero-copy interop, e.g. a torch tensor over P):
+ * d_x has 3+2*max_landmarks elements, d_P is column-major with leading dim ld. */
+int slam_ekf_device_ptrs(slam_ekf_t h, void** d_x, void** d_P, int* ld, void** stream);
+
+/* ---- the hot path ----------------------------------------------------------- */
+
+/* predict(state, vehicle, Q, dt)  src/ekf.jl:8-43.
+ * (v, g, wheelbase) = vehicle.measured_speed, .measured_gamma, .wheelbase (:14-16).
+ * In place, enqueued on the handle's stream (no host sync). */
+int slam_ekf_predict(slam_ekf_t h, double v, double g, double wheelbase,
+                     const double Q[4], double dt);
+
+/* associate(state, z, R, gate1, gate2)  src/data-association.jl:1-51.
+ * z: nz (range, bearing) pairs.  assoc[i] = j >= 1: observation i matched landmark
+ * j (goes to zf/idf); 0: dropped; -1: new feature (goes to zn).  The reference's
+ * (zf, idf, zn) are rebuilt from assoc in observation order by the host wrapper.
+ * Synchronises (host output). */
+int slam_ekf_associate(slam_ekf_t h, const double* z, int nz, const double R[4],
+                       double gate1, double gate2, int32_t* assoc);
+
+/* compute_association(x, P, z, R, idf)  src/data-association.jl:53-63.
+ * out = {nis, nd}.  Synchronises. */
+int slam_ekf_nis(slam_ekf_t h, const double z1[2], int j, const double R[4], double out[2]);
+
+/* predict_observation(x, idf)  src/common.jl:139-165.  zp = {range, bearing};
+ * Hv = the 2x3 pose block H[:,1:3], Hf = the 2x2 block H[:,fpos:fpos+1], both
+ * column-major; all other columns of the reference's dense H are zero.
+ * Synchronises. */
+int slam_ekf_predict_observation(slam_ekf_t h, int j, double zp[2], double Hv[6], double Hf[4]);
+
+/* update(state, z, R, idf)  src/ekf.jl:46-77.  zf: m (range, bearing) pairs, idf: m
+ * 1-based landmark indices (duplicates allowed, rows are stacked like the
+ * reference).  m = 0 is a no-op.  In place on the device.  Returns SLAM_E_NOTPD
+ * (state unchanged) if S is not positive definite; to report that, the call
+ * synchronises unless slam_ekf_set_async(h, 1) was set, in which case the status
+ * is deferred to slam_ekf_sync(). */
+int slam_ekf_update(slam_ekf_t h, const double* zf, const int32_t* idf, int m,
+                    const double R[4], int form);
+
+/* add_features(state, z, R)  src/ekf.jl:84-122.  zn: nn (range, bearing) pairs.
+ * Returns SLAM_E_CAPACITY (state unchanged) if N + nn > max_landmarks.  Enqueued. */
+int slam_ekf_augment(slam_ekf_t h, const double* zn, int nn, const double R[4]);
+
+/* ---- stream / timing -------------------------------------------------------- */
+
+int slam_ekf_set_async(slam_ekf_t h, int async_updates);
+/* Wait for the handle's stream; returns the first deferred error (and clears it). */
+int slam_ekf_sync(slam_ekf_t h);
+/* When enabled every kernel launch is bracketed by HIP events on the handle's
+ * stream.  timing_read synchronises, folds the pending events into per-kernel
+ * totals and returns total milliseconds and launch count for kernel id `kid`. */
+int slam_ekf_timing(slam_ekf_t h, int enable);
+int slam_ekf_timing_read(slam_ekf_t h, int kid, double* total_ms, int64_t* launches);
+int slam_ekf_timing_reset(slam_ekf_t h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAMHIP_H */

@@ -1,0 +1,120 @@
+// common.h -- internal declarations shared by the HIP sources of libslamhip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/slamhip.h"
+
+#define SLAM_PI 3.14159265358979323846
+
+// ---- error plumbing ---------------------------------------------------------
+void slam_set_error(const char* fmt, ...);
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess) {                                                        \
+            slam_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),     \
+                           __FILE__, __LINE__);                                        \
+            return (_e == hipErrorOutOfMemory) ? SLAM_E_NOMEM : SLAM_E_HIP;            \
+        }                                                                              \
+    } while (0)
+
+#define ARG_CHECK(cond, msg)                                                           \
+    do {                                                                               \
+        if (!(cond)) {                                                                 \
+            slam_set_error("bad argument: %s", msg);                                   \
+            return SLAM_E_BADARG;                                                      \
+        }                                                                              \
+    } while (0)
+
+// ---- geometry of the buffers -------------------------------------------------
+// Covariance tile edge of the rank-k down-date; the panel buffers (PHt, W1, ...)
+// are padded to whole tiles with zero rows so the down-date needs no row guards.
+#define SLAM_TILE 128
+// k = 2m is padded to a multiple of SLAM_KPAD with zero columns.
+#define SLAM_KPAD 32
+
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+struct TimingPair {
+    hipEvent_t a, b;
+    int kid;
+};
+
+struct slam_ekf {
+    int dtype;        // SLAM_F32 / SLAM_F64
+    int device;
+    int maxN;         // landmark capacity
+    int N;            // landmarks in the map
+    int ncap;         // 3 + 2*maxN
+    int ld;           // leading dimension of P (elements), multiple of 64
+    int npad;         // rows of the panel buffers, multiple of SLAM_TILE
+    size_t esz;       // element size
+    void* x;          // [ncap]
+    void* P;          // [ld * ncap] column-major
+    hipStream_t stream;
+    hipEvent_t stage_ev;   // marks the last H2D copy out of the pinned staging buffers
+    int stage_pending;
+
+    // update workspace, (re)allocated when k grows
+    int kcap;         // padded k capacity (multiple of SLAM_KPAD)
+    void* PHt;        // [npad][kcap]   row-major, dtype
+    void* W1;         // [npad][2*kcap] row-major, dtype (Joseph uses both halves: [K|T])
+    void* W2;         // [npad][2*kcap] row-major, dtype (Joseph: [T|K])
+    void* Cmat;       // [kcap][kcap]   row-major, dtype  (C = inv(chol(S)), upper)
+    double* Smat;     // [kcap][kcap]   double (Joseph: S);  also global scratch for big k
+    double* Mwork;    // [kcap][kcap+1] double, factor scratch when it does not fit LDS
+    double* gvec;     // [kcap]  g = C*C'*v  (x += PHt*g)
+    double* obsbuf;   // [ocap][2]  observations on device
+    int32_t* idfbuf;  // [ocap]
+    int ocap;
+    double* h_obs;    // pinned staging
+    int32_t* h_idf;   // pinned staging
+    int32_t* h_assoc; // pinned staging [ocap]
+    int32_t* d_assoc; // [ocap]
+
+    // gating partials
+    double* gate_part;   // [gate_blocks][ocap][3]
+    int gate_blocks_cap;
+
+    // small device scratch + pinned mirror for scalar outputs
+    double* d_small;     // 64 doubles
+    double* h_small;     // pinned, 64 doubles
+    int32_t* d_status;   // [4]  [0] = not-PD flag of the last update
+    int32_t* h_status;   // pinned
+
+    int async_updates;
+    int deferred;        // first deferred error
+    int pending_status;  // an update's status word has not been read back yet
+
+    // timing
+    int timing;
+    std::vector<TimingPair> pairs;
+    std::vector<TimingPair> free_pairs;
+    double t_ms[SLAM_K_COUNT];
+    int64_t t_n[SLAM_K_COUNT];
+};
+
+// RAII-less helper: bracket a launch with events when timing is on.
+struct KTimer {
+    slam_ekf* h;
+    TimingPair p;
+    bool on;
+    KTimer(slam_ekf* h_, int kid);
+    ~KTimer();
+};
+
+// ---- kernel launchers (one per .hip file) -----------------------------------
+int launch_predict(slam_ekf* h, double v, double g, double w, const double Q[4], double dt);
+int launch_augment(slam_ekf* h, int nn, const double R[4]);   // observations already in obsbuf
+int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gate2);
+int launch_nis(slam_ekf* h, const double z1[2], int j, const double R[4]);
+int launch_obs_model(slam_ekf* h, int j);
+int launch_update(slam_ekf* h, int m, const double R[4], int form);
+int ensure_update_workspace(slam_ekf* h, int m);
+int ensure_obs_capacity(slam_ekf* h, int nobs);

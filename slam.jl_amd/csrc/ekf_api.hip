@@ -1,0 +1,473 @@
+// ekf_api.hip -- the extern "C" surface of libslamhip.so for the EKF path
+// (declared in include/slamhip.h).  Host-side bookkeeping only; every numeric
+// operation on the state is a HIP kernel in the other translation units.  There
+// is deliberately no CPU fallback: without a usable device create() fails.
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include "common.h"
+
+int update_kernels_init();   // ekf_update.hip
+
+// ---- errors ------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void slam_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* slam_last_error(void) { return g_err; }
+
+extern "C" int slam_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+// ---- timing ------------------------------------------------------------------
+KTimer::KTimer(slam_ekf* h_, int kid) : h(h_), on(h_->timing != 0) {
+    if (!on) return;
+    if (!h->free_pairs.empty()) {
+        p = h->free_pairs.back();
+        h->free_pairs.pop_back();
+    } else {
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) {
+            on = false;
+            return;
+        }
+    }
+    p.kid = kid;
+    (void)hipEventRecord(p.a, h->stream);
+}
+
+KTimer::~KTimer() {
+    if (!on) return;
+    (void)hipEventRecord(p.b, h->stream);
+    h->pairs.push_back(p);
+}
+
+static int fold_timing(slam_ekf* h) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (auto& p : h->pairs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            h->t_ms[p.kid] += ms;
+            h->t_n[p.kid] += 1;
+        }
+        h->free_pairs.push_back(p);
+    }
+    h->pairs.clear();
+    return SLAM_OK;
+}
+
+// ---- allocation helpers --------------------------------------------------------
+template <typename P>
+static int dev_alloc_zero(P** p, size_t bytes, hipStream_t s) {
+    *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    HIP_TRY(hipMalloc((void**)p, bytes));
+    HIP_TRY(hipMemsetAsync(*p, 0, bytes, s));
+    return SLAM_OK;
+}
+
+static void dev_free(void* p) {
+    if (p) (void)hipFree(p);
+}
+
+int ensure_obs_capacity(slam_ekf* h, int nobs) {
+    if (nobs <= h->ocap) return SLAM_OK;
+    int cap = h->ocap ? h->ocap : 256;
+    while (cap < nobs) cap *= 2;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    dev_free(h->obsbuf); dev_free(h->idfbuf); dev_free(h->d_assoc); dev_free(h->gate_part);
+    if (h->h_obs) (void)hipHostFree(h->h_obs);
+    if (h->h_idf) (void)hipHostFree(h->h_idf);
+    if (h->h_assoc) (void)hipHostFree(h->h_assoc);
+    h->obsbuf = nullptr; h->idfbuf = nullptr; h->d_assoc = nullptr; h->gate_part = nullptr;
+    h->h_obs = nullptr; h->h_idf = nullptr; h->h_assoc = nullptr;
+    h->ocap = 0;
+    int rc;
+    if ((rc = dev_alloc_zero(&h->obsbuf, sizeof(double) * 2 * cap, h->stream))) return rc;
+    if ((rc = dev_alloc_zero(&h->idfbuf, sizeof(int32_t) * cap, h->stream))) return rc;
+    if ((rc = dev_alloc_zero(&h->d_assoc, sizeof(int32_t) * cap, h->stream))) return rc;
+    // gating partials: [blocks][<=256 observations per sweep][3]
+    h->gate_blocks_cap = (h->maxN + 255) / 256 + 1;
+    if ((rc = dev_alloc_zero(&h->gate_part, sizeof(double) * 3 * 256 * (size_t)h->gate_blocks_cap, h->stream))) return rc;
+    HIP_TRY(hipHostMalloc((void**)&h->h_obs, sizeof(double) * 2 * cap, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&h->h_idf, sizeof(int32_t) * cap, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&h->h_assoc, sizeof(int32_t) * cap, hipHostMallocDefault));
+    h->ocap = cap;
+    return SLAM_OK;
+}
+
+static void free_update_workspace(slam_ekf* h) {
+    dev_free(h->PHt); dev_free(h->W1); dev_free(h->W2); dev_free(h->Cmat);
+    dev_free(h->Smat); dev_free(h->Mwork); dev_free(h->gvec);
+    h->PHt = h->W1 = h->W2 = h->Cmat = nullptr;
+    h->Smat = h->Mwork = h->gvec = nullptr;
+    h->kcap = 0;
+}
+
+static int zero_panels(slam_ekf* h) {
+    if (!h->kcap) return SLAM_OK;
+    HIP_TRY(hipMemsetAsync(h->PHt, 0, h->esz * (size_t)h->npad * h->kcap, h->stream));
+    HIP_TRY(hipMemsetAsync(h->W1, 0, h->esz * (size_t)h->npad * 2 * h->kcap, h->stream));
+    HIP_TRY(hipMemsetAsync(h->W2, 0, h->esz * (size_t)h->npad * 2 * h->kcap, h->stream));
+    return SLAM_OK;
+}
+
+int ensure_update_workspace(slam_ekf* h, int m) {
+    const int kp = round_up(2 * m, SLAM_KPAD);
+    if (kp <= h->kcap) return SLAM_OK;
+    int cap = h->kcap ? h->kcap : 32;
+    while (cap < kp) cap *= 2;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    free_update_workspace(h);
+    int rc;
+    if ((rc = dev_alloc_zero(&h->PHt, h->esz * (size_t)h->npad * cap, h->stream))) return rc;
+    if ((rc = dev_alloc_zero(&h->W1, h->esz * (size_t)h->npad * 2 * cap, h->stream))) return rc;
+    if ((rc = dev_alloc_zero(&h->W2, h->esz * (size_t)h->npad * 2 * cap, h->stream))) return rc;
+    if ((rc = dev_alloc_zero(&h->Cmat, h->esz * (size_t)cap * cap, h->stream))) return rc;
+    if ((rc = dev_alloc_zero(&h->Smat, sizeof(double) * (size_t)cap * cap, h->stream))) return rc;
+    if ((rc = dev_alloc_zero(&h->Mwork, sizeof(double) * (size_t)cap * (cap + 1), h->stream))) return rc;
+    if ((rc = dev_alloc_zero(&h->gvec, sizeof(double) * (size_t)cap, h->stream))) return rc;
+    h->kcap = cap;
+    return SLAM_OK;
+}
+
+// ---- create / destroy -----------------------------------------------------------
+extern "C" int slam_ekf_destroy(slam_ekf_t h) {
+    if (!h) return SLAM_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& p : h->pairs) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto& p : h->free_pairs) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    free_update_workspace(h);
+    dev_free(h->x); dev_free(h->P);
+    dev_free(h->obsbuf); dev_free(h->idfbuf); dev_free(h->d_assoc); dev_free(h->gate_part);
+    dev_free(h->d_small); dev_free(h->d_status);
+    if (h->h_obs) (void)hipHostFree(h->h_obs);
+    if (h->h_idf) (void)hipHostFree(h->h_idf);
+    if (h->h_assoc) (void)hipHostFree(h->h_assoc);
+    if (h->h_small) (void)hipHostFree(h->h_small);
+    if (h->h_status) (void)hipHostFree(h->h_status);
+    if (h->stage_ev) (void)hipEventDestroy(h->stage_ev);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return SLAM_OK;
+}
+
+static int create_impl(slam_ekf* h) {
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&h->stage_ev, hipEventDisableTiming));
+    int rc;
+    if ((rc = update_kernels_init())) return rc;
+    if ((rc = dev_alloc_zero(&h->x, h->esz * (size_t)h->ncap, h->stream))) return rc;
+    if ((rc = dev_alloc_zero(&h->P, h->esz * (size_t)h->ld * h->ncap, h->stream))) return rc;
+    if ((rc = dev_alloc_zero(&h->d_small, sizeof(double) * 64, h->stream))) return rc;
+    if ((rc = dev_alloc_zero(&h->d_status, sizeof(int32_t) * 4, h->stream))) return rc;
+    HIP_TRY(hipHostMalloc((void**)&h->h_small, sizeof(double) * 64, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&h->h_status, sizeof(int32_t) * 4, hipHostMallocDefault));
+    if ((rc = ensure_obs_capacity(h, 256))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SLAM_OK;
+}
+
+extern "C" int slam_ekf_create(slam_ekf_t* out, int dtype, int max_landmarks, int device) {
+    ARG_CHECK(out != nullptr, "handle pointer is null");
+    *out = nullptr;
+    ARG_CHECK(dtype == SLAM_F32 || dtype == SLAM_F64, "dtype must be SLAM_F32 or SLAM_F64");
+    ARG_CHECK(max_landmarks >= 0 && max_landmarks <= 500000, "max_landmarks out of range");
+    const int ndev = slam_device_count();
+    if (ndev <= 0) {
+        slam_set_error("no HIP device available: libslamhip has no CPU fallback");
+        return SLAM_E_HIP;
+    }
+    ARG_CHECK(device >= 0 && device < ndev, "device index out of range");
+    slam_ekf* h = new slam_ekf();
+    h->dtype = dtype;
+    h->device = device;
+    h->maxN = max_landmarks;
+    h->N = 0;
+    h->ncap = 3 + 2 * max_landmarks;
+    h->ld = round_up(h->ncap, 64);
+    h->npad = round_up(h->ncap, SLAM_TILE);
+    h->esz = dtype == SLAM_F32 ? 4 : 8;
+    h->x = h->P = nullptr;
+    h->stream = nullptr;
+    h->stage_ev = nullptr; h->stage_pending = 0;
+    h->kcap = 0;
+    h->PHt = h->W1 = h->W2 = h->Cmat = nullptr;
+    h->Smat = h->Mwork = h->gvec = nullptr;
+    h->obsbuf = nullptr; h->idfbuf = nullptr; h->ocap = 0;
+    h->h_obs = nullptr; h->h_idf = nullptr; h->h_assoc = nullptr; h->d_assoc = nullptr;
+    h->gate_part = nullptr; h->gate_blocks_cap = 0;
+    h->d_small = h->h_small = nullptr;
+    h->d_status = h->h_status = nullptr;
+    h->async_updates = 0; h->deferred = 0; h->pending_status = 0;
+    h->timing = 0;
+    for (int i = 0; i < SLAM_K_COUNT; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
+    const int rc = create_impl(h);
+    if (rc != SLAM_OK) {
+        slam_ekf_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return SLAM_OK;
+}
+
+// ---- state I/O -------------------------------------------------------------------
+static int set_state_impl(slam_ekf* h, const void* x, const void* P, int n, int ldP, hipMemcpyKind kind) {
+    ARG_CHECK(h != nullptr, "null handle");
+    ARG_CHECK(x != nullptr && P != nullptr, "x / P is null");
+    ARG_CHECK(n >= 3 && ((n - 3) % 2) == 0, "n must be 3 + 2*N");
+    ARG_CHECK(ldP >= n, "ldP < n");
+    const int N = (n - 3) / 2;
+    if (N > h->maxN) {
+        slam_set_error("state has %d landmarks, capacity is %d", N, h->maxN);
+        return SLAM_E_CAPACITY;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    if (N < h->N) {                 // panel rows >= n must be zero for the down-date
+        const int rc = zero_panels(h);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(h->x, x, h->esz * (size_t)n, kind, h->stream));
+    HIP_TRY(hipMemcpy2DAsync(h->P, h->esz * (size_t)h->ld, P, h->esz * (size_t)ldP, h->esz * (size_t)n, (size_t)n, kind,
+                             h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->N = N;
+    return SLAM_OK;
+}
+
+extern "C" int slam_ekf_set_state(slam_ekf_t h, const void* x, const void* P, int n, int ldP) {
+    return set_state_impl(h, x, P, n, ldP, hipMemcpyHostToDevice);
+}
+
+extern "C" int slam_ekf_set_state_device(slam_ekf_t h, const void* d_x, const void* d_P, int n, int ldP) {
+    return set_state_impl(h, d_x, d_P, n, ldP, hipMemcpyDeviceToDevice);
+}
+
+extern "C" int slam_ekf_get_state(slam_ekf_t h, void* x, void* P, int n, int ldP) {
+    ARG_CHECK(h != nullptr, "null handle");
+    ARG_CHECK(n == 3 + 2 * h->N, "n does not match the state (3 + 2*N)");
+    ARG_CHECK(P == nullptr || ldP >= n, "ldP < n");
+    HIP_TRY(hipSetDevice(h->device));
+    if (x) HIP_TRY(hipMemcpyAsync(x, h->x, h->esz * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    if (P)
+        HIP_TRY(hipMemcpy2DAsync(P, h->esz * (size_t)ldP, h->P, h->esz * (size_t)h->ld, h->esz * (size_t)n, (size_t)n,
+                                 hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SLAM_OK;
+}
+
+extern "C" int slam_ekf_get_pose(slam_ekf_t h, double pose[3]) {
+    ARG_CHECK(h != nullptr && pose != nullptr, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(h->h_small, h->x, h->esz * 3, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 3; ++i)
+        pose[i] = h->dtype == SLAM_F32 ? (double)((float*)h->h_small)[i] : h->h_small[i];
+    return SLAM_OK;
+}
+
+extern "C" int slam_ekf_num_landmarks(slam_ekf_t h, int* N) {
+    ARG_CHECK(h != nullptr && N != nullptr, "null argument");
+    *N = h->N;
+    return SLAM_OK;
+}
+
+extern "C" int slam_ekf_dtype(slam_ekf_t h, int* dtype) {
+    ARG_CHECK(h != nullptr && dtype != nullptr, "null argument");
+    *dtype = h->dtype;
+    return SLAM_OK;
+}
+
+extern "C" int slam_ekf_device_ptrs(slam_ekf_t h, void** d_x, void** d_P, int* ld, void** stream) {
+    ARG_CHECK(h != nullptr, "null handle");
+    if (d_x) *d_x = h->x;
+    if (d_P) *d_P = h->P;
+    if (ld) *ld = h->ld;
+    if (stream) *stream = (void*)h->stream;
+    return SLAM_OK;
+}
+
+// ---- hot path ----------------------------------------------------------------------
+static int check_R(const double* R) {
+    ARG_CHECK(R != nullptr, "R is null");
+    return SLAM_OK;
+}
+
+// stage nobs observation pairs (+ optional idf) on the device, stream-ordered
+static int stage_obs(slam_ekf* h, const double* z, const int32_t* idf, int nobs) {
+    int rc = ensure_obs_capacity(h, nobs);
+    if (rc) return rc;
+    // the pinned staging buffers may still be the source of an earlier async copy
+    if (h->stage_pending) {
+        HIP_TRY(hipEventSynchronize(h->stage_ev));
+        h->stage_pending = 0;
+    }
+    memcpy(h->h_obs, z, sizeof(double) * 2 * (size_t)nobs);
+    HIP_TRY(hipMemcpyAsync(h->obsbuf, h->h_obs, sizeof(double) * 2 * (size_t)nobs, hipMemcpyHostToDevice, h->stream));
+    if (idf) {
+        memcpy(h->h_idf, idf, sizeof(int32_t) * (size_t)nobs);
+        HIP_TRY(hipMemcpyAsync(h->idfbuf, h->h_idf, sizeof(int32_t) * (size_t)nobs, hipMemcpyHostToDevice, h->stream));
+    }
+    HIP_TRY(hipEventRecord(h->stage_ev, h->stream));
+    h->stage_pending = 1;
+    return SLAM_OK;
+}
+
+extern "C" int slam_ekf_predict(slam_ekf_t h, double v, double g, double wheelbase, const double Q[4], double dt) {
+    ARG_CHECK(h != nullptr && Q != nullptr, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    return launch_predict(h, v, g, wheelbase, Q, dt);
+}
+
+extern "C" int slam_ekf_associate(slam_ekf_t h, const double* z, int nz, const double R[4], double gate1, double gate2,
+                                  int32_t* assoc) {
+    ARG_CHECK(h != nullptr, "null handle");
+    ARG_CHECK(nz >= 0, "nz < 0");
+    if (nz == 0) return SLAM_OK;
+    ARG_CHECK(z != nullptr && assoc != nullptr, "z / assoc is null");
+    int rc = check_R(R);
+    if (rc) return rc;
+    if (h->N == 0) {                       // outer stays Inf > gate2: every observation is a new feature
+        for (int i = 0; i < nz; ++i) assoc[i] = -1;
+        return SLAM_OK;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    if ((rc = stage_obs(h, z, nullptr, nz))) return rc;
+    if ((rc = launch_gate(h, nz, R, gate1, gate2))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->h_assoc, h->d_assoc, sizeof(int32_t) * (size_t)nz, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    memcpy(assoc, h->h_assoc, sizeof(int32_t) * (size_t)nz);
+    return SLAM_OK;
+}
+
+extern "C" int slam_ekf_nis(slam_ekf_t h, const double z1[2], int j, const double R[4], double out[2]) {
+    ARG_CHECK(h != nullptr && z1 != nullptr && out != nullptr, "null argument");
+    int rc = check_R(R);
+    if (rc) return rc;
+    ARG_CHECK(j >= 1 && j <= h->N, "landmark index out of range");
+    HIP_TRY(hipSetDevice(h->device));
+    if ((rc = launch_nis(h, z1, j, R))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->h_small, h->d_small, sizeof(double) * 2, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    out[0] = h->h_small[0];
+    out[1] = h->h_small[1];
+    return SLAM_OK;
+}
+
+extern "C" int slam_ekf_predict_observation(slam_ekf_t h, int j, double zp[2], double Hv[6], double Hf[4]) {
+    ARG_CHECK(h != nullptr && zp != nullptr && Hv != nullptr && Hf != nullptr, "null argument");
+    ARG_CHECK(j >= 1 && j <= h->N, "landmark index out of range");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc;
+    if ((rc = launch_obs_model(h, j))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->h_small, h->d_small, sizeof(double) * 12, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    zp[0] = h->h_small[0]; zp[1] = h->h_small[1];
+    for (int i = 0; i < 6; ++i) Hv[i] = h->h_small[2 + i];
+    for (int i = 0; i < 4; ++i) Hf[i] = h->h_small[8 + i];
+    return SLAM_OK;
+}
+
+static int read_status(slam_ekf* h, int sticky) {
+    HIP_TRY(hipMemcpyAsync(h->h_status, h->d_status, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int bad = sticky ? h->h_status[1] : h->h_status[0];
+    if (h->h_status[1]) HIP_TRY(hipMemsetAsync(h->d_status + 1, 0, sizeof(int32_t), h->stream));
+    h->pending_status = 0;
+    if (bad) {
+        slam_set_error("innovation covariance S is not positive definite (state left unchanged)");
+        return SLAM_E_NOTPD;
+    }
+    return SLAM_OK;
+}
+
+extern "C" int slam_ekf_update(slam_ekf_t h, const double* zf, const int32_t* idf, int m, const double R[4], int form) {
+    ARG_CHECK(h != nullptr, "null handle");
+    ARG_CHECK(m >= 0, "m < 0");
+    ARG_CHECK(form == SLAM_FORM_CHOLESKY || form == SLAM_FORM_JOSEPH, "unknown update form");
+    if (m == 0) return SLAM_OK;            // H is 0 x n: the reference's update is the identity
+    ARG_CHECK(zf != nullptr && idf != nullptr, "zf / idf is null");
+    int rc = check_R(R);
+    if (rc) return rc;
+    for (int i = 0; i < m; ++i) ARG_CHECK(idf[i] >= 1 && idf[i] <= h->N, "idf entry out of range (Julia: BoundsError)");
+    HIP_TRY(hipSetDevice(h->device));
+    if ((rc = ensure_update_workspace(h, m))) return rc;
+    if ((rc = stage_obs(h, zf, idf, m))) return rc;
+    if ((rc = launch_update(h, m, R, form))) return rc;
+    if (h->async_updates) {
+        h->pending_status = 1;
+        return SLAM_OK;
+    }
+    return read_status(h, 0);
+}
+
+extern "C" int slam_ekf_augment(slam_ekf_t h, const double* zn, int nn, const double R[4]) {
+    ARG_CHECK(h != nullptr, "null handle");
+    ARG_CHECK(nn >= 0, "nn < 0");
+    if (nn == 0) return SLAM_OK;
+    ARG_CHECK(zn != nullptr, "zn is null");
+    int rc = check_R(R);
+    if (rc) return rc;
+    if (h->N + nn > h->maxN) {
+        slam_set_error("augment: %d + %d landmarks exceed capacity %d", h->N, nn, h->maxN);
+        return SLAM_E_CAPACITY;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    if ((rc = stage_obs(h, zn, nullptr, nn))) return rc;
+    if ((rc = launch_augment(h, nn, R))) return rc;
+    h->N += nn;
+    return SLAM_OK;
+}
+
+// ---- stream / timing -----------------------------------------------------------------
+extern "C" int slam_ekf_set_async(slam_ekf_t h, int async_updates) {
+    ARG_CHECK(h != nullptr, "null handle");
+    h->async_updates = async_updates ? 1 : 0;
+    return SLAM_OK;
+}
+
+extern "C" int slam_ekf_sync(slam_ekf_t h) {
+    ARG_CHECK(h != nullptr, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->pending_status) return read_status(h, 1);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SLAM_OK;
+}
+
+extern "C" int slam_ekf_timing(slam_ekf_t h, int enable) {
+    ARG_CHECK(h != nullptr, "null handle");
+    h->timing = enable ? 1 : 0;
+    return SLAM_OK;
+}
+
+extern "C" int slam_ekf_timing_read(slam_ekf_t h, int kid, double* total_ms, int64_t* launches) {
+    ARG_CHECK(h != nullptr, "null handle");
+    ARG_CHECK(kid >= 0 && kid < SLAM_K_COUNT, "kernel id out of range");
+    HIP_TRY(hipSetDevice(h->device));
+    const int rc = fold_timing(h);
+    if (rc) return rc;
+    if (total_ms) *total_ms = h->t_ms[kid];
+    if (launches) *launches = h->t_n[kid];
+    return SLAM_OK;
+}
+
+extern "C" int slam_ekf_timing_reset(slam_ekf_t h) {
+    ARG_CHECK(h != nullptr, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    const int rc = fold_timing(h);
+    if (rc) return rc;
+    for (int i = 0; i < SLAM_K_COUNT; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
+    return SLAM_OK;
+}

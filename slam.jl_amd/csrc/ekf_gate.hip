@@ -1,0 +1,266 @@
+// ekf_gate.hip -- K1: Mahalanobis gating sweep over all map landmarks.
+//
+// Takes over associate()/compute_association() (src/data-association.jl:1-63)
+// and predict_observation() (src/common.jl:139-165).
+//
+// One thread owns one landmark j.  Everything that does not depend on the
+// observation -- predicted observation zp, the 5 non-zero Jacobian columns,
+// S = H P H' + R, det S -- is evaluated ONCE per landmark from 12 state values
+// (x_f 2, P_fv 6 read from the contiguous column strip P[3:,0:3], P_ff 4) plus
+// the wave-uniform pose / P_vv.  The loop over the nz observations then costs a
+// 2-vector innovation and a 2x2 quadratic form per pair.  The reference instead
+// forms a dense 2 x n H and a dense H*P*H' per pair (:59).
+//
+// Per-observation decision, order-independent form of the scan at :21-50
+// (SURVEY.md 3.2):  jbest = argmin_{j : nis_j < gate1, nd_j < Inf} nd_j, lowest j
+// on ties; if none: new feature iff no j has nis_j <= gate2 (outer > gate2).
+// Only waves that contain an in-gate landmark pay for a shuffle reduction; the
+// rest contribute two ballots per observation.
+#include "common.h"
+#include "device_math.h"
+
+namespace {
+
+constexpr int GATE_BLOCK = 256;
+constexpr int GATE_WAVES = GATE_BLOCK / 64;
+
+struct PairConst {        // per-landmark, observation-independent
+    double zp0, zp1;
+    double s00, s01, s10, s11;
+    double det, logdet;
+};
+
+// S = Hv Pvv Hv' + Hv Pvf Hf' + Hf Pfv Hv' + Hf Pff Hf' + R  (2x2), from the
+// 5x5 sub-block of P.  pvv is row-major 3x3; pfv[a][c] = P[f+a][c]; pff row-major.
+__device__ inline PairConst pair_const(const ObsModel& om, const double* pvv, const double pfv[2][3],
+                                       const double pff[4], const double R[4]) {
+    PairConst pc;
+    pc.zp0 = om.zp[0];
+    pc.zp1 = om.zp[1];
+    double A[2][3];   // Hv * Pvv
+    double B[2][2];   // Hv * Pvf,  Pvf[c][a] = pfv[a][c]
+    double Cc[2][3];  // Hf * Pfv
+    double D[2][2];   // Hf * Pff
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            A[r][c] = om.Hv[r * 3 + 0] * pvv[0 * 3 + c] + om.Hv[r * 3 + 1] * pvv[1 * 3 + c] +
+                      om.Hv[r * 3 + 2] * pvv[2 * 3 + c];
+            Cc[r][c] = om.Hf[r * 2 + 0] * pfv[0][c] + om.Hf[r * 2 + 1] * pfv[1][c];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            B[r][a] = om.Hv[r * 3 + 0] * pfv[a][0] + om.Hv[r * 3 + 1] * pfv[a][1] + om.Hv[r * 3 + 2] * pfv[a][2];
+            D[r][a] = om.Hf[r * 2 + 0] * pff[0 * 2 + a] + om.Hf[r * 2 + 1] * pff[1 * 2 + a];
+        }
+    }
+    double S[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            double s = A[r][0] * om.Hv[q * 3 + 0] + A[r][1] * om.Hv[q * 3 + 1] + A[r][2] * om.Hv[q * 3 + 2];
+            s += B[r][0] * om.Hf[q * 2 + 0] + B[r][1] * om.Hf[q * 2 + 1];
+            s += Cc[r][0] * om.Hv[q * 3 + 0] + Cc[r][1] * om.Hv[q * 3 + 1] + Cc[r][2] * om.Hv[q * 3 + 2];
+            s += D[r][0] * om.Hf[q * 2 + 0] + D[r][1] * om.Hf[q * 2 + 1];
+            S[r][q] = s + R[q * 2 + r];       // R column-major: R[r][q] = R[q*2+r]
+        }
+    pc.s00 = S[0][0]; pc.s01 = S[0][1]; pc.s10 = S[1][0]; pc.s11 = S[1][1];
+    pc.det = pc.s00 * pc.s11 - pc.s01 * pc.s10;
+    pc.logdet = log(pc.det);
+    return pc;
+}
+
+// nis = v' inv(S) v  (src/data-association.jl:60), nd = nis + log det S (:61)
+__device__ inline void pair_eval(const PairConst& pc, double z0, double z1, double& nis, double& nd) {
+    const double v0 = z0 - pc.zp0;
+    const double v1 = mpi_to_pi_d(z1 - pc.zp1);        // :57
+    nis = (v0 * (pc.s11 * v0 - pc.s01 * v1) + v1 * (pc.s00 * v1 - pc.s10 * v0)) / pc.det;
+    nd = nis + pc.logdet;
+}
+
+template <typename T>
+__device__ inline PairConst landmark_const(const T* __restrict__ x, const T* __restrict__ P, int ld, int j0,
+                                           const double pose[3], const double* pvv, const double R[4]) {
+    const int f = 3 + 2 * j0;
+    const double lx = (double)x[f], ly = (double)x[f + 1];
+    const ObsModel om = obs_model(pose[0], pose[1], pose[2], lx, ly);
+    double pfv[2][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        pfv[0][c] = (double)P[(size_t)c * ld + f];
+        pfv[1][c] = (double)P[(size_t)c * ld + f + 1];
+    }
+    double pff[4];
+    pff[0] = (double)P[(size_t)f * ld + f];           // P[f][f]
+    pff[1] = (double)P[(size_t)(f + 1) * ld + f];     // P[f][f+1]
+    pff[2] = (double)P[(size_t)f * ld + f + 1];       // P[f+1][f]
+    pff[3] = (double)P[(size_t)(f + 1) * ld + f + 1]; // P[f+1][f+1]
+    return pair_const(om, pvv, pfv, pff, R);
+}
+
+template <typename T>
+__global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(const T* __restrict__ x, const T* __restrict__ P, int ld,
+                                                           int N, const double* __restrict__ z, int nz, double R0,
+                                                           double R1, double R2, double R3, double gate1, double gate2,
+                                                           double* __restrict__ part) {
+    extern __shared__ double smem[];
+    double* zs = smem;                 // [nz][2]
+    double* red = smem + 2 * nz;       // [nz][GATE_WAVES][3]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    for (int i = tid; i < 2 * nz; i += GATE_BLOCK) zs[i] = z[i];
+
+    const double R[4] = {R0, R1, R2, R3};
+    double pose[3] = {(double)x[0], (double)x[1], (double)x[2]};
+    double pvv[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pvv[r * 3 + c] = (double)P[(size_t)c * ld + r];
+
+    const int j0 = blockIdx.x * GATE_BLOCK + tid;
+    const bool valid = j0 < N;
+    PairConst pc;
+    if (valid) pc = landmark_const(x, P, ld, j0, pose, pvv, R);
+    __syncthreads();
+
+    const double INF = __builtin_inf();
+    for (int i = 0; i < nz; ++i) {
+        double nis = INF, nd = INF;
+        if (valid) pair_eval(pc, zs[2 * i], zs[2 * i + 1], nis, nd);
+        const bool cand = valid && (nis < gate1) && (nd < INF);
+        const bool near = valid && (nis <= gate2);
+        const unsigned long long cand_mask = __ballot(cand);
+        const unsigned long long near_mask = __ballot(near);
+        double nd_c = INF;
+        int j_c = 0x7fffffff;
+        if (cand_mask != 0ull) {                 // wave-uniform
+            if (cand) { nd_c = nd; j_c = j0 + 1; }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double o_nd = __shfl_xor(nd_c, off);
+                const int o_j = __shfl_xor(j_c, off);
+                if (o_nd < nd_c || (o_nd == nd_c && o_j < j_c)) { nd_c = o_nd; j_c = o_j; }
+            }
+        }
+        if (lane == 0) {
+            double* r = red + ((size_t)i * GATE_WAVES + wave) * 3;
+            r[0] = nd_c;
+            r[1] = (double)j_c;
+            r[2] = near_mask != 0ull ? 1.0 : 0.0;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < nz; i += GATE_BLOCK) {
+        double nd_c = INF, j_c = (double)0x7fffffff, near = 0.0;
+        for (int w = 0; w < GATE_WAVES; ++w) {
+            const double* r = red + ((size_t)i * GATE_WAVES + w) * 3;
+            if (r[0] < nd_c || (r[0] == nd_c && r[1] < j_c)) { nd_c = r[0]; j_c = r[1]; }
+            if (r[2] != 0.0) near = 1.0;
+        }
+        double* o = part + ((size_t)blockIdx.x * nz + i) * 3;
+        o[0] = nd_c; o[1] = j_c; o[2] = near;
+    }
+}
+
+// One thread per observation folds the per-block partials into assoc[i].
+__global__ void gate_final_kernel(const double* __restrict__ part, int nblocks, int nz, int32_t* __restrict__ assoc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nz) return;
+    const double INF = __builtin_inf();
+    double nd_c = INF, j_c = (double)0x7fffffff, near = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+        const double* r = part + ((size_t)b * nz + i) * 3;
+        if (r[0] < nd_c || (r[0] == nd_c && r[1] < j_c)) { nd_c = r[0]; j_c = r[1]; }
+        if (r[2] != 0.0) near = 1.0;
+    }
+    int32_t a;
+    if (nd_c < INF) a = (int32_t)j_c;            // jbest != 0          (:43)
+    else if (near == 0.0) a = -1;                // outer > gate2       (:46)
+    else a = 0;                                  // dropped
+    assoc[i] = a;
+}
+
+// compute_association for ONE pair and predict_observation for ONE landmark.
+template <typename T>
+__global__ void single_pair_kernel(const T* __restrict__ x, const T* __restrict__ P, int ld, int j0, double z0, double z1,
+                                   double R0, double R1, double R2, double R3, int mode, double* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double R[4] = {R0, R1, R2, R3};
+    double pose[3] = {(double)x[0], (double)x[1], (double)x[2]};
+    if (mode == 1) {   // predict_observation: zp[2], Hv (col-major 2x3), Hf (col-major 2x2)
+        const int f = 3 + 2 * j0;
+        const ObsModel om = obs_model(pose[0], pose[1], pose[2], (double)x[f], (double)x[f + 1]);
+        out[0] = om.zp[0]; out[1] = om.zp[1];
+        for (int c = 0; c < 3; ++c) { out[2 + 2 * c] = om.Hv[c]; out[2 + 2 * c + 1] = om.Hv[3 + c]; }
+        for (int c = 0; c < 2; ++c) { out[8 + 2 * c] = om.Hf[c]; out[8 + 2 * c + 1] = om.Hf[2 + c]; }
+        return;
+    }
+    double pvv[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) pvv[r * 3 + c] = (double)P[(size_t)c * ld + r];
+    const PairConst pc = landmark_const(x, P, ld, j0, pose, pvv, R);
+    double nis, nd;
+    pair_eval(pc, z0, z1, nis, nd);
+    out[0] = nis;
+    out[1] = nd;
+}
+
+}  // namespace
+
+int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gate2) {
+    const int nblocks = (h->N + GATE_BLOCK - 1) / GATE_BLOCK;
+    if (nblocks > h->gate_blocks_cap) {
+        slam_set_error("internal: gate partial buffer too small");
+        return SLAM_E_HIP;
+    }
+    // observations are swept in chunks so the LDS footprint stays bounded for any nz
+    constexpr int CHUNK = 256;
+    for (int o = 0; o < nz; o += CHUNK) {
+        const int cz = nz - o < CHUNK ? nz - o : CHUNK;
+        const size_t shmem = (size_t)(2 * cz + 3 * GATE_WAVES * cz) * sizeof(double);
+        const double* zc = h->obsbuf + 2 * (size_t)o;
+        {
+            KTimer t(h, SLAM_K_GATE);
+            if (h->dtype == SLAM_F32)
+                hipLaunchKernelGGL(gate_kernel<float>, dim3(nblocks), dim3(GATE_BLOCK), shmem, h->stream,
+                                   (const float*)h->x, (const float*)h->P, h->ld, h->N, zc, cz, R[0], R[1], R[2], R[3],
+                                   gate1, gate2, h->gate_part);
+            else
+                hipLaunchKernelGGL(gate_kernel<double>, dim3(nblocks), dim3(GATE_BLOCK), shmem, h->stream,
+                                   (const double*)h->x, (const double*)h->P, h->ld, h->N, zc, cz, R[0], R[1], R[2], R[3],
+                                   gate1, gate2, h->gate_part);
+        }
+        HIP_TRY(hipGetLastError());
+        {
+            KTimer t(h, SLAM_K_GATE_FIN);
+            hipLaunchKernelGGL(gate_final_kernel, dim3((cz + 63) / 64), dim3(64), 0, h->stream, h->gate_part, nblocks,
+                               cz, h->d_assoc + o);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    return SLAM_OK;
+}
+
+static int launch_single(slam_ekf* h, int j0, double z0, double z1, const double R[4], int mode) {
+    if (h->dtype == SLAM_F32)
+        hipLaunchKernelGGL(single_pair_kernel<float>, dim3(1), dim3(64), 0, h->stream, (const float*)h->x,
+                           (const float*)h->P, h->ld, j0, z0, z1, R[0], R[1], R[2], R[3], mode, h->d_small);
+    else
+        hipLaunchKernelGGL(single_pair_kernel<double>, dim3(1), dim3(64), 0, h->stream, (const double*)h->x,
+                           (const double*)h->P, h->ld, j0, z0, z1, R[0], R[1], R[2], R[3], mode, h->d_small);
+    HIP_TRY(hipGetLastError());
+    return SLAM_OK;
+}
+
+int launch_nis(slam_ekf* h, const double z1[2], int j, const double R[4]) {
+    return launch_single(h, j - 1, z1[0], z1[1], R, 0);
+}
+
+int launch_obs_model(slam_ekf* h, int j) {
+    const double R[4] = {0, 0, 0, 0};
+    return launch_single(h, j - 1, 0.0, 0.0, R, 1);
+}

@@ -1,0 +1,199 @@
+// ekf_strip.hip -- K7 predict and K8 add_features: O(n) strip kernels.
+//
+// predict()       src/ekf.jl:8-43
+// add_features()  src/ekf.jl:84-122
+//
+// Both only touch the three pose rows/columns of P (plus the new rows/columns
+// for add_features).  In column-major storage the COLUMN strip P[:, 0:3] is
+// three contiguous runs, so it is the one that is read (coalesced); the row
+// strip P[0:3, :] is its mirror (P is symmetric) and is only written.  The
+// reference reads the row strip (:34) and re-allocates all of P per new feature
+// (:108-109); here the capacity was allocated once at create.
+#include "common.h"
+#include "device_math.h"
+
+namespace {
+
+struct PredictParams {   // written by the pose kernel, read by the strip kernel
+    double vts, vtc;
+};
+
+// One thread: new pose and P_vv (ekf.jl:24-32, 39-41), and the two scalars the
+// strip needs.  Runs BEFORE the strip kernel on the same stream, so the strip
+// never races with the write of x[2].
+template <typename T>
+__global__ void predict_pose_kernel(T* __restrict__ x, T* __restrict__ P, int ld, double v, double g, double w,
+                                    double Q0, double Q1, double Q2, double Q3, double dt, double* __restrict__ params) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double phi = (double)x[2];
+    const double s = sin(g + phi), c = cos(g + phi);
+    const double vts = v * dt * s, vtc = v * dt * c;
+    const double Gv[3][3] = {{1.0, 0.0, -vts}, {0.0, 1.0, vtc}, {0.0, 0.0, 1.0}};
+    const double Gu[3][2] = {{dt * c, -vts}, {dt * s, vtc}, {dt * sin(g) / w, v * dt * cos(g) / w}};
+    const double Q[2][2] = {{Q0, Q2}, {Q1, Q3}};   // column-major input
+    double Pvv[3][3], GP[3][3], GQ[3][2], out[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 3; ++cc) Pvv[r][cc] = (double)P[(size_t)cc * ld + r];
+    for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 3; ++cc)
+            GP[r][cc] = Gv[r][0] * Pvv[0][cc] + Gv[r][1] * Pvv[1][cc] + Gv[r][2] * Pvv[2][cc];
+    for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 2; ++cc) GQ[r][cc] = Gu[r][0] * Q[0][cc] + Gu[r][1] * Q[1][cc];
+    for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 3; ++cc)
+            out[r][cc] = (GP[r][0] * Gv[cc][0] + GP[r][1] * Gv[cc][1] + GP[r][2] * Gv[cc][2]) +
+                         (GQ[r][0] * Gu[cc][0] + GQ[r][1] * Gu[cc][1]);
+    for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 3; ++cc) P[(size_t)cc * ld + r] = (T)out[r][cc];
+    const double x0 = (double)x[0], x1 = (double)x[1];
+    x[0] = (T)(x0 + vtc);
+    x[1] = (T)(x1 + vts);
+    x[2] = (T)mpi_to_pi_d(phi + v * dt * sin(g) / w);
+    params[0] = vts;
+    params[1] = vtc;
+}
+
+// P_vm <- Gv * P_vm and its mirror (ekf.jl:33-36).  Thread t owns map row f = 3+t.
+template <typename T>
+__global__ __launch_bounds__(256) void predict_strip_kernel(T* __restrict__ P, int ld, int n,
+                                                             const double* __restrict__ params) {
+    const int f = 3 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    const double vts = params[0], vtc = params[1];
+    const double p0 = (double)P[(size_t)0 * ld + f];
+    const double p1 = (double)P[(size_t)1 * ld + f];
+    const double p2 = (double)P[(size_t)2 * ld + f];
+    const T n0 = (T)(p0 - vts * p2);     // Gv = [1 0 -vts; 0 1 vtc; 0 0 1]
+    const T n1 = (T)(p1 + vtc * p2);
+    const T n2 = (T)p2;
+    P[(size_t)0 * ld + f] = n0;          // column strip  P[f, 0:3]
+    P[(size_t)1 * ld + f] = n1;
+    P[(size_t)2 * ld + f] = n2;
+    T* row = P + (size_t)f * ld;         // row strip     P[0:3, f]
+    row[0] = n0;
+    row[1] = n1;
+    row[2] = n2;
+}
+
+// add_features: thread t owns old state index c = t (0 .. n0-1) and writes, for
+// every new feature a, the 2 x 1 cross block P[fa:fa+1, c] = Gv_a * P[0:3, c] and its
+// mirror.  P[0:3, c] is read as P[c, 0:3] (symmetric).  Block 0 additionally writes
+// the new-new blocks and the new entries of x.
+template <typename T>
+__global__ __launch_bounds__(256) void augment_kernel(T* __restrict__ x, T* __restrict__ P, int ld, int n0,
+                                                       const double* __restrict__ zn, int nn, double R0, double R1,
+                                                       double R2, double R3) {
+    const double xv = (double)x[0], yv = (double)x[1], phi = (double)x[2];   // ekf.jl:88 (phi fixed for the call)
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n0) {
+        const double p0 = (double)P[(size_t)0 * ld + c];
+        const double p1 = (double)P[(size_t)1 * ld + c];
+        const double p2 = (double)P[(size_t)2 * ld + c];
+        for (int a = 0; a < nn; ++a) {
+            const double r = zn[2 * a], b = zn[2 * a + 1];
+            const double s = sin(phi + b), co = cos(phi + b);
+            // Gv = [1 0 -r*s; 0 1 r*c]                               (:102)
+            const T v0 = (T)(p0 - r * s * p2);
+            const T v1 = (T)(p1 + r * co * p2);
+            const int fa = n0 + 2 * a;
+            P[(size_t)fa * ld + c] = v0;            // P[c, fa]      column of the new feature (:114,:118)
+            P[(size_t)(fa + 1) * ld + c] = v1;
+            P[(size_t)c * ld + fa] = v0;            // P[fa, c]      row of the new feature    (:113,:117)
+            P[(size_t)c * ld + fa + 1] = v1;
+        }
+    }
+    if (blockIdx.x != 0) return;
+    double Pvv[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 3; ++cc) Pvv[r][cc] = (double)P[(size_t)cc * ld + r];
+    const double R[2][2] = {{R0, R2}, {R1, R3}};
+    // pairs (a, b) with b <= a
+    const int npairs = nn * (nn + 1) / 2;
+    for (int pidx = threadIdx.x; pidx < npairs; pidx += blockDim.x) {
+        int a = 0;
+        while ((a + 1) * (a + 2) / 2 <= pidx) ++a;
+        const int b = pidx - a * (a + 1) / 2;
+        const double ra = zn[2 * a], ba = zn[2 * a + 1];
+        const double sa = sin(phi + ba), ca = cos(phi + ba);
+        const double Ga[2][3] = {{1.0, 0.0, -ra * sa}, {0.0, 1.0, ra * ca}};
+        const int fa = n0 + 2 * a;
+        if (a == b) {
+            // P[rng,rng] = Gv*Pvv*Gv' + Gz*R*Gz'                      (:112)
+            const double Gz[2][2] = {{ca, -ra * sa}, {sa, ra * ca}};
+            double GP[2][3], GR[2][2];
+            for (int r = 0; r < 2; ++r)
+                for (int cc = 0; cc < 3; ++cc)
+                    GP[r][cc] = Ga[r][0] * Pvv[0][cc] + Ga[r][1] * Pvv[1][cc] + Ga[r][2] * Pvv[2][cc];
+            for (int r = 0; r < 2; ++r)
+                for (int cc = 0; cc < 2; ++cc) GR[r][cc] = Gz[r][0] * R[0][cc] + Gz[r][1] * R[1][cc];
+            for (int r = 0; r < 2; ++r)
+                for (int cc = 0; cc < 2; ++cc) {
+                    const double val = (GP[r][0] * Ga[cc][0] + GP[r][1] * Ga[cc][1] + GP[r][2] * Ga[cc][2]) +
+                                       (GR[r][0] * Gz[cc][0] + GR[r][1] * Gz[cc][1]);
+                    P[(size_t)(fa + cc) * ld + fa + r] = (T)val;
+                }
+            x[fa] = (T)(xv + ra * ca);                                  // (:99)
+            x[fa + 1] = (T)(yv + ra * sa);
+        } else {
+            // P[rng_a, rng_b] = Gv_a * P[0:3, rng_b],  P[0:3, rng_b] = (Gv_b*Pvv)'   (:114,:117 with rnm grown)
+            const double rb = zn[2 * b], bb = zn[2 * b + 1];
+            const double sb = sin(phi + bb), cb = cos(phi + bb);
+            const double Gb[2][3] = {{1.0, 0.0, -rb * sb}, {0.0, 1.0, rb * cb}};
+            const int fb = n0 + 2 * b;
+            double GbP[2][3];   // Gv_b * Pvv
+            for (int r = 0; r < 2; ++r)
+                for (int cc = 0; cc < 3; ++cc)
+                    GbP[r][cc] = Gb[r][0] * Pvv[0][cc] + Gb[r][1] * Pvv[1][cc] + Gb[r][2] * Pvv[2][cc];
+            for (int r = 0; r < 2; ++r)
+                for (int cc = 0; cc < 2; ++cc) {
+                    // (Gv_a * (Gv_b Pvv)')[r][cc] = sum_t Ga[r][t] * GbP[cc][t]
+                    const T val = (T)(Ga[r][0] * GbP[cc][0] + Ga[r][1] * GbP[cc][1] + Ga[r][2] * GbP[cc][2]);
+                    P[(size_t)(fb + cc) * ld + fa + r] = val;           // P[fa+r, fb+cc]
+                    P[(size_t)(fa + r) * ld + fb + cc] = val;           // mirror (:118)
+                }
+        }
+    }
+}
+
+}  // namespace
+
+int launch_predict(slam_ekf* h, double v, double g, double w, const double Q[4], double dt) {
+    const int n = 3 + 2 * h->N;
+    double* params = h->d_small + 32;
+    {
+        KTimer t(h, SLAM_K_PREDICT);
+        if (h->dtype == SLAM_F32)
+            hipLaunchKernelGGL(predict_pose_kernel<float>, dim3(1), dim3(64), 0, h->stream, (float*)h->x, (float*)h->P,
+                               h->ld, v, g, w, Q[0], Q[1], Q[2], Q[3], dt, params);
+        else
+            hipLaunchKernelGGL(predict_pose_kernel<double>, dim3(1), dim3(64), 0, h->stream, (double*)h->x,
+                               (double*)h->P, h->ld, v, g, w, Q[0], Q[1], Q[2], Q[3], dt, params);
+        if (h->N > 0) {
+            const int blocks = (2 * h->N + 255) / 256;
+            if (h->dtype == SLAM_F32)
+                hipLaunchKernelGGL(predict_strip_kernel<float>, dim3(blocks), dim3(256), 0, h->stream, (float*)h->P,
+                                   h->ld, n, params);
+            else
+                hipLaunchKernelGGL(predict_strip_kernel<double>, dim3(blocks), dim3(256), 0, h->stream, (double*)h->P,
+                                   h->ld, n, params);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return SLAM_OK;
+}
+
+int launch_augment(slam_ekf* h, int nn, const double R[4]) {
+    const int n0 = 3 + 2 * h->N;
+    const int blocks = (n0 + 255) / 256;
+    {
+        KTimer t(h, SLAM_K_AUGMENT);
+        if (h->dtype == SLAM_F32)
+            hipLaunchKernelGGL(augment_kernel<float>, dim3(blocks), dim3(256), 0, h->stream, (float*)h->x, (float*)h->P,
+                               h->ld, n0, h->obsbuf, nn, R[0], R[1], R[2], R[3]);
+        else
+            hipLaunchKernelGGL(augment_kernel<double>, dim3(blocks), dim3(256), 0, h->stream, (double*)h->x,
+                               (double*)h->P, h->ld, n0, h->obsbuf, nn, R[0], R[1], R[2], R[3]);
+    }
+    HIP_TRY(hipGetLastError());
+    return SLAM_OK;
+}
