@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- EKF-SLAM hot path on MI355X: associate + update steps at N = 10k landmarks.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the configuration the metric "EKF updates/sec @ 10k
+landmarks" is quoted on): N = 10 000 landmarks at config-1 density, fp32 state
+resident in HBM, nz = 64 range-bearing observations per step (the 64 nearest landmarks in the
+forward half-plane, fresh noise every step), gates 4.0 / 25.0.  One step = one pass of the hot
+path: associate (gating sweep over all landmarks, host gets the decisions like the
+reference's caller) + update (P*H', S, C = inv(chol(S)), W1, P -= W1*W1') through the C ABI.
+
+Unit: an "EKF update" is ONE observation assimilated; a step with m matched observations
+counts m.  steps/s is reported beside it.
+
+The EKF path does not shard (one dense coupled covariance): with --gpus N > 1 every rank runs
+an independent replica on its own GPU ("replicas only", weak scaling, no data-path collective).
+
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+R = np.array([[0.1 ** 2, 0.0], [0.0, (math.pi / 180) ** 2]])
+GATE1, GATE2 = 4.0, 25.0
+SEED = 20240601
+MFMA_F32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md, Peak FP32 (matrix)
+HBM_PEAK_GBPS = 8000.0                # MI355X_MICROARCH.md, HBM3E peak (6290 measured copy rate)
+
+
+def make_workload(N, nz, nsteps, seed):
+    """Synthetic map, state and per-step observations."""
+    rng = np.random.default_rng(seed)
+    n = 3 + 2 * N
+    L = 100.0 * math.sqrt(N / 35.0)
+    lm = rng.uniform(0, L, (2, N))
+    pose = np.array([L / 2, L / 2, 0.3])
+    x = np.concatenate([pose, (lm + rng.normal(0, 0.1, lm.shape)).T.reshape(-1)]).astype(np.float32)
+    A = rng.normal(0, 0.05, (n, 16)).astype(np.float32)
+    P = A @ A.T
+    P[np.diag_indices(n)] += np.float32(0.01)
+    P = np.maximum(P, P.T)
+    dx, dy = lm[0] - pose[0], lm[1] - pose[1]
+    fwd = np.flatnonzero(dx * math.cos(pose[2]) + dy * math.sin(pose[2]) > 0)
+    ids = fwd[np.argsort(dx[fwd] ** 2 + dy[fwd] ** 2)[:nz]]
+    ztrue = np.vstack([np.hypot(dx[ids], dy[ids]), np.arctan2(dy[ids], dx[ids]) - pose[2]])
+    zs = [ztrue + rng.normal(0, 1, ztrue.shape) * np.array([[0.1], [math.pi / 180]]) for _ in range(nsteps)]
+    return x, P, zs
+
+
+def gpu_step(st, z):
+    """associate -> (host splits the decisions, as sim! does) -> update.  Returns matched count."""
+    a = st.associate_vector(z, R, GATE1, GATE2)
+    sel = a > 0
+    m = int(sel.sum())
+    if m:
+        st.update(z[:, sel], R, a[sel])
+    return m
+
+
+def cpu_baseline(x, P, zs, budget_s=20.0):
+    """The oracle's sparse restatement (vectorised NumPy / BLAS, fp64) on the host cores, same
+    workload, bounded sample: whole steps until ~budget_s of CPU time is spent."""
+    from oracle import ekf_ref as O
+    xo = x.astype(np.float64)
+    Po = P.astype(np.float64)
+    done = matched = 0
+    t0 = time.perf_counter()
+    for z in zs:
+        zf, idf, _zn = O.associate_sparse(xo, Po, z, R, GATE1, GATE2)
+        xo, Po = O.update_sparse(xo, Po, zf, R, idf, inplace=True)
+        matched += idf.shape[1]
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": matched / dt, "unit": "obs-updates/s", "cores": os.cpu_count(), "kind": "port",
+            "steps_per_s": done / dt,
+            "sample": f"{done} full associate+update steps of the same N={len(x) // 2 - 1} nz={zs[0].shape[1]} "
+                      f"workload in fp64 (oracle sparse restatement: vectorised 5x5 gating + BLAS rank-k "
+                      f"down-date, {os.cpu_count()} BLAS threads), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--landmarks", type=int, default=10000)
+    ap.add_argument("--obs", type=int, default=64)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--form", default="cholesky", choices=["cholesky", "joseph"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    from __graft_entry__ import load_package
+    pkg = load_package()
+
+    N, nz = args.landmarks, args.obs
+    n = 3 + 2 * N
+    total_steps = args.warmup + args.steps
+    x, P, zs = make_workload(N, nz, total_steps, SEED + rank)      # every replica gets its own noise
+    st = pkg.EKFSlamState(x, P, dtype=args.dtype, max_landmarks=N, device=local_rank)
+
+    def step(z):
+        a = st.associate_vector(z, R, GATE1, GATE2)
+        sel = a > 0
+        m = int(sel.sum())
+        if m:
+            st.update(z[:, sel], R, a[sel], form=args.form)
+        return m
+
+    st.set_async(True)                     # the update's status is collected at the final sync
+    for i in range(args.warmup):
+        step(zs[i])
+    st.sync()
+    st.timing(True)
+    st.timing_reset()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    matched = 0
+    for i in range(args.warmup, total_steps):
+        matched += step(zs[i])
+    st.sync()
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    tim = st.timing_read()
+    st.timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        mt = torch.tensor([matched], dtype=torch.float64, device="cuda")
+        dist.all_reduce(mt, op=dist.ReduceOp.SUM)
+        matched_all = float(mt.item())
+    else:
+        matched_all = float(matched)
+
+    if rank == 0:
+        esz = 4 if args.dtype == "f32" else 8
+        syrk_ms, syrk_n = tim["syrk"]
+        syrk_avg_s = (syrk_ms / max(syrk_n, 1)) * 1e-3
+        k_avg = 2.0 * matched / max(syrk_n, 1)                       # actual k = 2m per launch
+        if args.form == "joseph":
+            k_avg *= 2.0
+        alg_flops = 2.0 * n * n * k_avg                               # full matrix (both triangles computed)
+        alg_bytes = 2.0 * n * n * esz                                 # P read once + written once
+        tflops = alg_flops / syrk_avg_s / 1e12 if syrk_avg_s > 0 else 0.0
+        gbps = alg_bytes / syrk_avg_s / 1e9 if syrk_avg_s > 0 else 0.0
+        if args.dtype == "f32":
+            roof = {"kernel": "downdate (P -= W1*W1')", "bound": "mfma", "achieved": tflops,
+                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_F32_PEAK_TFLOPS,
+                    "traffic": None, "avg_launch_ms": syrk_avg_s * 1e3, "launches": syrk_n,
+                    "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
+                    "hbm_achieved_GBps": gbps, "hbm_frac_of_8TBps": gbps / HBM_PEAK_GBPS}
+        else:
+            roof = {"kernel": "downdate (P -= X*Y')", "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, "traffic": None,
+                    "avg_launch_ms": syrk_avg_s * 1e3, "launches": syrk_n,
+                    "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes}
+        out = {
+            "metric": "EKF updates/sec @ 10k landmarks" if N == 10000 else f"EKF updates/sec @ {N} landmarks",
+            "value": matched_all / elapsed,
+            "unit": "obs-updates/s (one observation assimilated = one update)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "steps_per_s": world * args.steps / elapsed,
+            "matched_per_step": matched / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"EKF-SLAM associate+update, N={N} landmarks (n={n}), nz={nz} obs/step, "
+                                   f"gates {GATE1}/{GATE2}, {args.form} form, state resident in HBM",
+                       "landmarks": N, "obs_per_step": nz, "form": args.form,
+                       "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (EKF does not shard)"},
+            "roofline": roof,
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in tim.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(x, P, zs, args.cpu_budget)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    st.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,103 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol
+that include/slamhip.h declares, carries no torch / oracle dependency, and fails loudly
+(never falls back to a CPU path) when no device is present."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "slamhip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(slam_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_hot_path():
+    syms = declared_symbols()
+    for need in ("slam_ekf_create", "slam_ekf_destroy", "slam_ekf_predict", "slam_ekf_associate",
+                 "slam_ekf_update", "slam_ekf_augment", "slam_ekf_nis", "slam_ekf_predict_observation",
+                 "slam_ekf_set_state", "slam_ekf_get_state", "slam_last_error"):
+        assert need in syms
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = ctypes.CDLL(pkg._lib.LIB_PATH)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, missing
+    # and the Python binding covers exactly the declared surface
+    assert sorted(pkg._lib.SIGNATURES) == declared_symbols()
+
+
+def test_library_has_no_torch_or_python_dependency(pkg):
+    out = subprocess.run(["ldd", pkg._lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "libamdhip64" in out
+    assert "torch" not in out and "python" not in out
+
+
+def test_product_package_never_imports_the_oracle():
+    pkgdir = os.path.join(ROOT, "slam.jl_amd")
+    for dirpath, _dirs, files in os.walk(pkgdir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".jl")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "ekf_ref" not in src, f
+
+
+def test_no_device_means_loud_failure_not_fallback(pkg):
+    if pkg.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(pkg.SlamHipError) as ei:
+        pkg.EKFSlamState(np.zeros(3), np.zeros((3, 3)))
+    assert ei.value.code == pkg._lib.SLAM_E_HIP
+    assert "no CPU fallback" in str(ei.value)
+
+
+def test_bad_arguments_are_status_codes_not_crashes(pkg):
+    lib = pkg._lib.lib
+    assert lib.slam_ekf_create(None, 0, 10, 0) == pkg._lib.SLAM_E_BADARG
+    h = ctypes.c_void_p()
+    assert lib.slam_ekf_create(ctypes.byref(h), 7, 10, 0) == pkg._lib.SLAM_E_BADARG
+    assert "dtype" in pkg._lib.last_error()
+    assert lib.slam_ekf_destroy(None) == 0
+    assert lib.slam_ekf_predict(None, 1.0, 0.0, 4.0, None, 0.025) == pkg._lib.SLAM_E_BADARG
+
+
+def test_host_helpers(pkg):
+    import math
+    assert pkg.mpi_to_pi(3.5 * math.pi) == pytest.approx(1.5 * math.pi)
+    assert pkg.mpi_to_pi(-3.5 * math.pi) == pytest.approx(-1.5 * math.pi)
+    assert pkg.mpi_to_pi(0.25) == 0.25
+    from slam_jl_amd import ekf
+    assert ekf._small(np.array([[1.0, 2.0], [3.0, 4.0]])).tolist() == [1.0, 3.0, 2.0, 4.0]     # column-major
+    z = np.array([[10.0, 20.0, 30.0], [0.1, 0.2, 0.3]])
+    assert ekf._obs(z).tolist() == [[10.0, 0.1], [20.0, 0.2], [30.0, 0.3]]
+    assert ekf._obs(np.zeros((2, 0))).shape == (0, 2)
+
+
+def test_sim_driver_pieces(pkg, golden_dir):
+    import math
+    S = pkg.sim
+    wp = S.get_waypoints(os.path.join(golden_dir, "course1.txt"))
+    assert wp.shape == (2, 19) and wp[0, 0] == pytest.approx(49.954)
+    pose = S.initial_pose(wp)
+    assert pose[2] == pytest.approx(math.atan2(14.904 - 14.665, 41.931 - 49.954))
+    lm = S.make_landmarks(500, [0.0, 100.0, 0.0, 100.0], 0.05, np.random.default_rng(0))
+    assert lm.min() == 5 and lm.max() == 95 and np.all(lm == np.round(lm))
+    veh = S.Vehicle(pose=pose.copy())
+    S.steer(veh, wp, S.D_MIN, S.DT)
+    assert veh.waypoint_id == 2 and abs(veh.target_gamma) <= veh.steer_rate * S.DT + 1e-15
+    S.step_vehicle(veh, S.DT)
+    assert np.hypot(*(veh.pose[:2] - pose[:2])) == pytest.approx(8 * 0.025)
+    # sensor model: forward half-plane and 30 m range (sim/sim-utils.jl:20-22)
+    veh.pose = np.array([50.0, 50.0, 0.0])
+    lms = np.array([[60.0, 40.0, 50.0, 79.9, 80.1], [50.0, 50.0, 70.0, 50.0, 50.0]])
+    z, tags = S.get_observations(veh, lms, np.zeros((2, 2)), np.random.default_rng(1))
+    assert tags.tolist() == [1, 4] and z[0].tolist() == pytest.approx([10.0, 29.9])
