@@ -1,0 +1,206 @@
+# SLAMHip.jl -- Julia 1.x binding of libslamhip.so (include/slamhip.h).
+#
+# Keeps the public surface of SLAM.jl's filter core (src/SLAM.jl:5-30: SlamState,
+# EKFSlamState, predict, update, add_features, associate, compute_association,
+# predict_observation, mpi_to_pi) and adds the in-place names ekf_predict!,
+# ekf_update!, augment!.  Every numeric operation is a `ccall` into the HIP
+# library; the state lives on the GPU for the life of the handle.
+#
+# NOTE: there is no `julia` binary in the build image, so this file is written to
+# be thin and mechanical and is NOT executed by the test-suite; the same C ABI is
+# exercised through the ctypes mirror in ekf.py.  The reference itself is Julia
+# 0.5/0.6 syntax (`type`, `atan2`, `chol`) and does not parse on Julia >= 1.0.
+module SLAMHip
+
+export SlamState, EKFSlamState, set_state!, predict, update, add_features, associate,
+       compute_association, predict_observation, mpi_to_pi,
+       ekf_predict!, ekf_update!, augment!
+
+const libslamhip = get(ENV, "SLAMHIP_LIB", joinpath(@__DIR__, "libslamhip.so"))
+
+const SLAM_OK = Cint(0)
+const SLAM_E_NOTPD = Cint(-3)
+const SLAM_F32 = Cint(0)
+const SLAM_F64 = Cint(1)
+const FORM_CHOLESKY = Cint(0)
+const FORM_JOSEPH = Cint(1)
+
+last_error() = unsafe_string(ccall((:slam_last_error, libslamhip), Cstring, ()))
+
+function check(rc::Cint)
+    rc == SLAM_OK && return nothing
+    # the reference raises PosDefException from chol (src/ekf.jl:70) / BoundsError
+    error("libslamhip status $(rc): $(last_error())")
+end
+
+abstract type SlamState end                       # src/common.jl:22
+
+"""
+    EKFSlamState(x, cov; max_landmarks, device=0)
+
+Device-resident counterpart of `EKFSlamState{T}` (src/common.jl:25-28).  `T` is
+`Float32` or `Float64`.  `state.x` / `state.cov` download on access; assigning them
+uploads.  Capacity is fixed at construction (the reference re-allocates `P` per
+new feature, src/ekf.jl:108-109).
+"""
+mutable struct EKFSlamState{T<:Union{Float32,Float64}} <: SlamState
+    handle::Ptr{Cvoid}
+    function EKFSlamState{T}(x::AbstractVector, cov::AbstractMatrix;
+                             max_landmarks::Integer = max(64, length(x) - 3), device::Integer = 0) where {T}
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:slam_ekf_create, libslamhip), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint, Cint),
+                    h, T === Float32 ? SLAM_F32 : SLAM_F64, max_landmarks, device))
+        s = new{T}(h[])
+        finalizer(s) do st
+            ccall((:slam_ekf_destroy, libslamhip), Cint, (Ptr{Cvoid},), getfield(st, :handle))
+        end
+        set_state!(s, x, cov)
+        return s
+    end
+end
+EKFSlamState(x::AbstractVector{T}, cov::AbstractMatrix; kw...) where {T<:Union{Float32,Float64}} =
+    EKFSlamState{T}(x, cov; kw...)
+
+handle(s::EKFSlamState) = getfield(s, :handle)
+
+function nlandmarks(s::EKFSlamState)
+    n = Ref{Cint}(0)
+    check(ccall((:slam_ekf_num_landmarks, libslamhip), Cint, (Ptr{Cvoid}, Ref{Cint}), handle(s), n))
+    Int(n[])
+end
+Base.length(s::EKFSlamState) = 3 + 2 * nlandmarks(s)
+
+function set_state!(s::EKFSlamState{T}, x::AbstractVector, cov::AbstractMatrix) where {T}
+    xv = Vector{T}(x); P = Matrix{T}(cov)                     # column-major, like the C ABI
+    n = length(xv)
+    size(P) == (n, n) || throw(DimensionMismatch("cov must be n x n"))
+    check(ccall((:slam_ekf_set_state, libslamhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint),
+                handle(s), xv, P, n, n))
+    s
+end
+
+function download(s::EKFSlamState{T}, which::Symbol) where {T}
+    n = length(s)
+    x = which === :cov ? C_NULL : Vector{T}(undef, n)
+    P = which === :x ? C_NULL : Matrix{T}(undef, n, n)
+    check(ccall((:slam_ekf_get_state, libslamhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint),
+                handle(s), x, P, n, n))
+    which === :x ? x : which === :cov ? P : (x, P)
+end
+
+function Base.getproperty(s::EKFSlamState, f::Symbol)
+    f === :x && return download(s, :x)
+    f === :cov && return download(s, :cov)
+    getfield(s, f)
+end
+
+function Base.setproperty!(s::EKFSlamState, f::Symbol, v)
+    # `state.x, state.cov = predict(state, ...)` (sim/ekfslam-sim.jl:100) hands back `nothing`
+    # placeholders from the in-place kernels: nothing to upload.
+    v === nothing && return v
+    if f === :x
+        length(v) == length(s) || error("x and cov change size together: use set_state!(state, x, cov)")
+        set_state!(s, v, download(s, :cov))
+        return v
+    elseif f === :cov
+        size(v, 1) == length(s) || error("x and cov change size together: use set_state!(state, x, cov)")
+        set_state!(s, download(s, :x), v)
+        return v
+    end
+    setfield!(s, f, v)
+end
+
+colmajor4(M::AbstractMatrix) = Float64[M[1, 1], M[2, 1], M[1, 2], M[2, 2]]
+pairs64(z::AbstractMatrix) = Matrix{Float64}(z)              # 2 x nz column-major == (range, bearing) pairs
+
+"Single conditional wrap, src/common.jl:102-110."
+function mpi_to_pi(phi::AbstractFloat)
+    phi > pi && return phi - 2pi
+    phi < -pi && return phi + 2pi
+    phi
+end
+
+# ---- in-place operations ---------------------------------------------------------------
+"predict (src/ekf.jl:8-43) in place on the device."
+function ekf_predict!(s::EKFSlamState, v::Real, g::Real, wheelbase::Real, Q::AbstractMatrix, dt::Real)
+    check(ccall((:slam_ekf_predict, libslamhip), Cint, (Ptr{Cvoid}, Cdouble, Cdouble, Cdouble, Ptr{Cdouble}, Cdouble),
+                handle(s), v, g, wheelbase, colmajor4(Q), dt))
+    s
+end
+
+"update (src/ekf.jl:46-77) in place on the device; `form = :joseph` selects the rank-2k Joseph form."
+function ekf_update!(s::EKFSlamState, z::AbstractMatrix, R::AbstractMatrix, idf; form::Symbol = :cholesky)
+    m = size(z, 2)
+    m == 0 && return s
+    ids = Vector{Int32}(vec(collect(idf)))
+    check(ccall((:slam_ekf_update, libslamhip), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Int32}, Cint, Ptr{Cdouble}, Cint),
+                handle(s), pairs64(z), ids, m, colmajor4(R), form === :joseph ? FORM_JOSEPH : FORM_CHOLESKY))
+    s
+end
+
+"add_features (src/ekf.jl:84-122) in place on the device."
+function augment!(s::EKFSlamState, z::AbstractMatrix, R::AbstractMatrix)
+    nn = size(z, 2)
+    nn == 0 && return s
+    check(ccall((:slam_ekf_augment, libslamhip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Cdouble}),
+                handle(s), pairs64(z), nn, colmajor4(R)))
+    s
+end
+
+# ---- the reference's function surface ------------------------------------------------------
+# The reference returns (x, P) and its only caller assigns them back to the state
+# (sim/ekfslam-sim.jl:100,117,120).  Here the state was already updated in place, so the
+# returned pair is (nothing, nothing) and `setproperty!` ignores it -- no 1.6 GB round trip.
+
+"predict(state, vehicle, Q, dt): `vehicle` needs measured_speed, measured_gamma, wheelbase (src/ekf.jl:14-16)."
+function predict(s::EKFSlamState, vehicle, Q::AbstractMatrix, dt::AbstractFloat)
+    ekf_predict!(s, vehicle.measured_speed, vehicle.measured_gamma, vehicle.wheelbase, Q, dt)
+    nothing, nothing
+end
+
+function update(s::EKFSlamState, z, R, idf)
+    ekf_update!(s, z, R, idf)
+    nothing, nothing
+end
+
+function add_features(s::EKFSlamState, z, R)
+    augment!(s, z, R)
+    nothing, nothing
+end
+
+"associate(state, z, R, gate1, gate2) -> (zf 2 x nf, idf 1 x nf Int, zn 2 x nn)  (src/data-association.jl:1-51)."
+function associate(s::EKFSlamState, z::AbstractMatrix, R::AbstractMatrix, gate1::Real, gate2::Real)
+    nz = size(z, 2)
+    assoc = zeros(Int32, nz)
+    if nz > 0
+        check(ccall((:slam_ekf_associate, libslamhip), Cint,
+                    (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cdouble, Cdouble, Ptr{Int32}),
+                    handle(s), pairs64(z), nz, colmajor4(R), gate1, gate2, assoc))
+    end
+    hit = findall(>(0), assoc)
+    new = findall(<(0), assoc)
+    z[:, hit], reshape(Int.(assoc[hit]), 1, :), z[:, new]
+end
+
+"compute_association(state, z, R, idf) -> (nis, nd)  (src/data-association.jl:53-63; x, P are the state's)."
+function compute_association(s::EKFSlamState, z::AbstractVector, R::AbstractMatrix, idf::Integer)
+    out = zeros(Float64, 2)
+    check(ccall((:slam_ekf_nis, libslamhip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}),
+                handle(s), Float64[z[1], z[2]], idf, colmajor4(R), out))
+    out[1], out[2]
+end
+
+"predict_observation(state, idf) -> (z, H) with H dense 2 x n (src/common.jl:139-165)."
+function predict_observation(s::EKFSlamState, idf::Integer)
+    zp = zeros(2); Hv = zeros(2, 3); Hf = zeros(2, 2)
+    check(ccall((:slam_ekf_predict_observation, libslamhip), Cint,
+                (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}), handle(s), idf, zp, Hv, Hf))
+    H = zeros(2, length(s))
+    H[:, 1:3] = Hv
+    fpos = 3 + 2 * idf - 1
+    H[:, fpos:fpos+1] = Hf
+    zp, H
+end
+
+end # module

@@ -63,10 +63,11 @@ struct slam_ekf {
 
     // update workspace, (re)allocated when k grows
     int kcap;         // padded k capacity (multiple of SLAM_KPAD)
-    void* PHt;        // [npad][kcap]   row-major, dtype
+    double* PHt;      // [npad][kcap]   row-major, double
+    double* Kd;       // [npad][kcap]   row-major, double (Joseph: K = PHt*inv(S))
     void* W1;         // [npad][2*kcap] row-major, dtype (Joseph uses both halves: [K|T])
     void* W2;         // [npad][2*kcap] row-major, dtype (Joseph: [T|K])
-    void* Cmat;       // [kcap][kcap]   row-major, dtype  (C = inv(chol(S)), upper)
+    double* Cmat;     // [kcap][kcap]   row-major, double (C = inv(chol(S)) upper, or inv(S) for Joseph)
     double* Smat;     // [kcap][kcap]   double (Joseph: S);  also global scratch for big k
     double* Mwork;    // [kcap][kcap+1] double, factor scratch when it does not fit LDS
     double* gvec;     // [kcap]  g = C*C'*v  (x += PHt*g)
@@ -77,6 +78,10 @@ struct slam_ekf {
     int32_t* h_idf;   // pinned staging
     int32_t* h_assoc; // pinned staging [ocap]
     int32_t* d_assoc; // [ocap]
+
+    // down-date tile order (ekf_syrk.hip): workgroup b computes tile tiles[b]
+    int2* tiles;
+    int tiles_T, tiles_len, tiles_cap;
 
     // gating partials
     double* gate_part;   // [gate_blocks][ocap][3]

@@ -97,7 +97,7 @@ int ensure_obs_capacity(slam_ekf* h, int nobs) {
     if ((rc = dev_alloc_zero(&h->idfbuf, sizeof(int32_t) * cap, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->d_assoc, sizeof(int32_t) * cap, h->stream))) return rc;
     // gating partials: [blocks][<=256 observations per sweep][3]
-    h->gate_blocks_cap = (h->maxN + 255) / 256 + 1;
+    h->gate_blocks_cap = (h->maxN + 63) / 64 + 1;
     if ((rc = dev_alloc_zero(&h->gate_part, sizeof(double) * 3 * 256 * (size_t)h->gate_blocks_cap, h->stream))) return rc;
     HIP_TRY(hipHostMalloc((void**)&h->h_obs, sizeof(double) * 2 * cap, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&h->h_idf, sizeof(int32_t) * cap, hipHostMallocDefault));
@@ -107,16 +107,17 @@ int ensure_obs_capacity(slam_ekf* h, int nobs) {
 }
 
 static void free_update_workspace(slam_ekf* h) {
-    dev_free(h->PHt); dev_free(h->W1); dev_free(h->W2); dev_free(h->Cmat);
+    dev_free(h->PHt); dev_free(h->Kd); dev_free(h->W1); dev_free(h->W2); dev_free(h->Cmat);
     dev_free(h->Smat); dev_free(h->Mwork); dev_free(h->gvec);
-    h->PHt = h->W1 = h->W2 = h->Cmat = nullptr;
-    h->Smat = h->Mwork = h->gvec = nullptr;
+    h->W1 = h->W2 = nullptr;
+    h->PHt = h->Kd = h->Cmat = h->Smat = h->Mwork = h->gvec = nullptr;
     h->kcap = 0;
 }
 
 static int zero_panels(slam_ekf* h) {
     if (!h->kcap) return SLAM_OK;
-    HIP_TRY(hipMemsetAsync(h->PHt, 0, h->esz * (size_t)h->npad * h->kcap, h->stream));
+    HIP_TRY(hipMemsetAsync(h->PHt, 0, sizeof(double) * (size_t)h->npad * h->kcap, h->stream));
+    HIP_TRY(hipMemsetAsync(h->Kd, 0, sizeof(double) * (size_t)h->npad * h->kcap, h->stream));
     HIP_TRY(hipMemsetAsync(h->W1, 0, h->esz * (size_t)h->npad * 2 * h->kcap, h->stream));
     HIP_TRY(hipMemsetAsync(h->W2, 0, h->esz * (size_t)h->npad * 2 * h->kcap, h->stream));
     return SLAM_OK;
@@ -130,10 +131,11 @@ int ensure_update_workspace(slam_ekf* h, int m) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     free_update_workspace(h);
     int rc;
-    if ((rc = dev_alloc_zero(&h->PHt, h->esz * (size_t)h->npad * cap, h->stream))) return rc;
+    if ((rc = dev_alloc_zero(&h->PHt, sizeof(double) * (size_t)h->npad * cap, h->stream))) return rc;
+    if ((rc = dev_alloc_zero(&h->Kd, sizeof(double) * (size_t)h->npad * cap, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->W1, h->esz * (size_t)h->npad * 2 * cap, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->W2, h->esz * (size_t)h->npad * 2 * cap, h->stream))) return rc;
-    if ((rc = dev_alloc_zero(&h->Cmat, h->esz * (size_t)cap * cap, h->stream))) return rc;
+    if ((rc = dev_alloc_zero(&h->Cmat, sizeof(double) * (size_t)cap * cap, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->Smat, sizeof(double) * (size_t)cap * cap, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->Mwork, sizeof(double) * (size_t)cap * (cap + 1), h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->gvec, sizeof(double) * (size_t)cap, h->stream))) return rc;
@@ -149,7 +151,7 @@ extern "C" int slam_ekf_destroy(slam_ekf_t h) {
     for (auto& p : h->pairs) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto& p : h->free_pairs) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     free_update_workspace(h);
-    dev_free(h->x); dev_free(h->P);
+    dev_free(h->x); dev_free(h->P); dev_free(h->tiles);
     dev_free(h->obsbuf); dev_free(h->idfbuf); dev_free(h->d_assoc); dev_free(h->gate_part);
     dev_free(h->d_small); dev_free(h->d_status);
     if (h->h_obs) (void)hipHostFree(h->h_obs);
@@ -204,8 +206,9 @@ extern "C" int slam_ekf_create(slam_ekf_t* out, int dtype, int max_landmarks, in
     h->stream = nullptr;
     h->stage_ev = nullptr; h->stage_pending = 0;
     h->kcap = 0;
-    h->PHt = h->W1 = h->W2 = h->Cmat = nullptr;
-    h->Smat = h->Mwork = h->gvec = nullptr;
+    h->W1 = h->W2 = nullptr;
+    h->PHt = h->Kd = h->Cmat = h->Smat = h->Mwork = h->gvec = nullptr;
+    h->tiles = nullptr; h->tiles_T = h->tiles_len = h->tiles_cap = 0;
     h->obsbuf = nullptr; h->idfbuf = nullptr; h->ocap = 0;
     h->h_obs = nullptr; h->h_idf = nullptr; h->h_assoc = nullptr; h->d_assoc = nullptr;
     h->gate_part = nullptr; h->gate_blocks_cap = 0;

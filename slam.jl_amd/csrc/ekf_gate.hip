@@ -21,13 +21,14 @@
 
 namespace {
 
-constexpr int GATE_BLOCK = 256;
+constexpr int GATE_BLOCK = 64;      // one wave per workgroup: N/64 workgroups spread the sweep over the CUs
 constexpr int GATE_WAVES = GATE_BLOCK / 64;
 
 struct PairConst {        // per-landmark, observation-independent
     double zp0, zp1;
     double s00, s01, s10, s11;
     double det, logdet;
+    double qa, qb, qc;    // nis = qa*v0^2 + qb*v0*v1 + qc*v1^2  (inv(S) folded in once per landmark)
 };
 
 // S = Hv Pvv Hv' + Hv Pvf Hf' + Hf Pfv Hv' + Hf Pff Hf' + R  (2x2), from the
@@ -69,6 +70,10 @@ __device__ inline PairConst pair_const(const ObsModel& om, const double* pvv, co
     pc.s00 = S[0][0]; pc.s01 = S[0][1]; pc.s10 = S[1][0]; pc.s11 = S[1][1];
     pc.det = pc.s00 * pc.s11 - pc.s01 * pc.s10;
     pc.logdet = log(pc.det);
+    const double rdet = 1.0 / pc.det;
+    pc.qa = pc.s11 * rdet;
+    pc.qb = -(pc.s01 + pc.s10) * rdet;
+    pc.qc = pc.s00 * rdet;
     return pc;
 }
 
@@ -76,7 +81,7 @@ __device__ inline PairConst pair_const(const ObsModel& om, const double* pvv, co
 __device__ inline void pair_eval(const PairConst& pc, double z0, double z1, double& nis, double& nd) {
     const double v0 = z0 - pc.zp0;
     const double v1 = mpi_to_pi_d(z1 - pc.zp1);        // :57
-    nis = (v0 * (pc.s11 * v0 - pc.s01 * v1) + v1 * (pc.s00 * v1 - pc.s10 * v0)) / pc.det;
+    nis = pc.qa * v0 * v0 + pc.qb * v0 * v1 + pc.qc * v1 * v1;
     nd = nis + pc.logdet;
 }
 
@@ -166,22 +171,34 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(const T* __restrict__ 
     }
 }
 
-// One thread per observation folds the per-block partials into assoc[i].
-__global__ void gate_final_kernel(const double* __restrict__ part, int nblocks, int nz, int32_t* __restrict__ assoc) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nz) return;
+// One wave per observation folds the per-workgroup partials into assoc[i].
+__global__ __launch_bounds__(64) void gate_final_kernel(const double* __restrict__ part, int nblocks, int nz,
+                                                        int32_t* __restrict__ assoc) {
+    const int i = blockIdx.x;
+    const int lane = threadIdx.x;
     const double INF = __builtin_inf();
-    double nd_c = INF, j_c = (double)0x7fffffff, near = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
+    double nd_c = INF, j_c = (double)0x7fffffff;
+    bool near = false;
+    for (int b = lane; b < nblocks; b += 64) {
         const double* r = part + ((size_t)b * nz + i) * 3;
-        if (r[0] < nd_c || (r[0] == nd_c && r[1] < j_c)) { nd_c = r[0]; j_c = r[1]; }
-        if (r[2] != 0.0) near = 1.0;
+        const double r0 = r[0], r1 = r[1], r2 = r[2];
+        if (r0 < nd_c || (r0 == nd_c && r1 < j_c)) { nd_c = r0; j_c = r1; }
+        near = near || (r2 != 0.0);
     }
-    int32_t a;
-    if (nd_c < INF) a = (int32_t)j_c;            // jbest != 0          (:43)
-    else if (near == 0.0) a = -1;                // outer > gate2       (:46)
-    else a = 0;                                  // dropped
-    assoc[i] = a;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double o_nd = __shfl_xor(nd_c, off);
+        const double o_j = __shfl_xor(j_c, off);
+        if (o_nd < nd_c || (o_nd == nd_c && o_j < j_c)) { nd_c = o_nd; j_c = o_j; }
+    }
+    const bool any_near = __ballot(near) != 0ull;
+    if (lane == 0) {
+        int32_t a;
+        if (nd_c < INF) a = (int32_t)j_c;            // jbest != 0          (:43)
+        else if (!any_near) a = -1;                  // outer > gate2       (:46)
+        else a = 0;                                  // dropped
+        assoc[i] = a;
+    }
 }
 
 // compute_association for ONE pair and predict_observation for ONE landmark.
@@ -237,8 +254,8 @@ int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gat
         HIP_TRY(hipGetLastError());
         {
             KTimer t(h, SLAM_K_GATE_FIN);
-            hipLaunchKernelGGL(gate_final_kernel, dim3((cz + 63) / 64), dim3(64), 0, h->stream, h->gate_part, nblocks,
-                               cz, h->d_assoc + o);
+            hipLaunchKernelGGL(gate_final_kernel, dim3(cz), dim3(64), 0, h->stream, h->gate_part, nblocks, cz,
+                               h->d_assoc + o);
         }
         HIP_TRY(hipGetLastError());
     }

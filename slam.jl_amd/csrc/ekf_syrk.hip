@@ -5,26 +5,44 @@
 //
 // P is n x n column-major with leading dimension ld; X, Y are row-major
 // [npad][pitch] panels, zero in rows >= n and in padding columns.  This kernel
-// is where >= 95 % of an update's time goes: algorithmic traffic is one read and
-// one write of P (2*n^2*sizeof(T)), algorithmic work 2*n^2*k flops.
+// is where >= 90 % of an update's time goes.
+//
+// Symmetry.  X*Y' is symmetric in both forms and P is kept EXACTLY symmetric,
+// so only the tiles on and below the diagonal are computed: tile (I,J), I >= J,
+// reads P(I,J) once, forms P(I,J) - X_I*Y_J', and stores it to (I,J) and,
+// transposed through LDS so that both stores are full 128-byte lines, to (J,I).
+// Algorithmic traffic per update: n^2/2 elements read + n^2 written; algorithmic
+// work n^2*k flops (half of the full product).  Diagonal tiles store their lower
+// triangle directly and their upper triangle from the mirror, which keeps P
+// bit-for-bit symmetric also in the Joseph form.
 //
 // fp32: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).  A 256-thread
-// workgroup owns a 128 x 128 tile of P; its four waves own 64 x 64 quadrants as
-// 2 x 2 MFMA blocks (64 accumulator VGPRs).  The panels are staged through LDS in
-// k-chunks of 32 with 16-byte loads; each lane then pulls FOUR consecutive k of
-// its row with one ds_read_b128 and feeds four MFMAs -- the k index inside an
-// MFMA is only a label, so lane half h takes k = kc+4h..kc+4h+3 for both operands.
-// The product is accumulated from zero and subtracted from P once (the
-// reference's order: form W1*W1', then subtract), so P's magnitude never enters
-// the accumulation error.
+// workgroup owns a 128 x 128 tile; its four waves own 64 x 64 quadrants as 2 x 2
+// MFMA blocks (64 accumulator registers).  The product is accumulated from zero
+// and subtracted from P once (the reference's order: form W1*W1', then subtract).
+// The k-loop is software pipelined: panels travel global -> registers -> LDS in
+// chunks of 32 columns with two LDS buffers and ONE barrier per chunk; the loads
+// of chunk c+1 and of the P tile itself are in flight while chunk c feeds the
+// MFMAs.  Each lane pulls FOUR consecutive k of its row with one ds_read_b128 and
+// feeds four MFMAs -- the k index inside an MFMA is only a label, so lane half h
+// takes k = kc+4h..kc+4h+3 for both operands.
 //
 // MFMA orientation: D[i][j] = sum_k A[i][k] B[k][j], j on lanes, i in registers.
 // P is column-major, so rows of P go on the LANES (j) and columns in the
-// registers (i): each accumulator register then covers 32 consecutive rows of
-// one column = one full 128-byte line per half-wave for the P load and store.
+// registers (i): each accumulator register then covers 32 consecutive rows of one
+// column = one full 128-byte line per half-wave for the P load and store.
 //
-// fp64: LDS-tiled VALU kernel (64 x 64 tile, 4 x 4 per thread); at the k used by
-// BASELINE.json's fp64 configuration the down-date is HBM-bound.
+// Tile order.  Workgroups are dispatched round-robin over the 8 XCDs (observed,
+// not contractual: only speed depends on it), each with a private 4 MiB L2.  The
+// host builds a tile list in which XCD x walks "super-rows" of four tile rows,
+// column by column, so the four row panels stay L2-resident and every column
+// panel fetched is used four times.
+//
+// fp64: the same triangular / mirrored scheme with an LDS-tiled VALU kernel
+// (64 x 64 tile, 4 x 4 per thread); at the k of BASELINE.json's fp64
+// configuration the down-date is HBM-bound.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -33,15 +51,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TILE = SLAM_TILE;      // 128
-constexpr int KC = 32;               // k-chunk staged per barrier pair
+constexpr int KC = 32;               // k-chunk per barrier
 constexpr int LDSP = KC + 4;         // LDS row pitch in floats (144 B: 16-B aligned, conflict-free b128)
+constexpr int TP = 33;               // pitch of the per-wave 32 x 32 transpose scratch
 
-__global__ __launch_bounds__(256) void downdate_f32_mfma(float* __restrict__ P, int ld, int n, const float* __restrict__ X,
-                                                         const float* __restrict__ Y, int pitch, int kp,
-                                                         const int32_t* __restrict__ status) {
+__global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ P, int ld, int n,
+                                                            const float* __restrict__ X, const float* __restrict__ Y,
+                                                            int pitch, int kp, const int2* __restrict__ tiles,
+                                                            const int32_t* __restrict__ status) {
     if (status[0] != 0) return;
-    __shared__ __attribute__((aligned(16))) float sX[TILE][LDSP];   // rows of P  (lanes,  "B" operand)
-    __shared__ __attribute__((aligned(16))) float sY[TILE][LDSP];   // cols of P  (regs,   "A" operand)
+    const int2 tile = tiles[blockIdx.x];
+    if (tile.x < 0) return;                                   // padding entry of the tile list
+    __shared__ __attribute__((aligned(16))) float smem[2][2][TILE][LDSP];   // [buffer][X|Y][row][k]  73,728 B
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -49,8 +70,24 @@ __global__ __launch_bounds__(256) void downdate_f32_mfma(float* __restrict__ P, 
     const int wc = wave >> 1;         // column half
     const int l31 = lane & 31;
     const int lh = lane >> 5;
-    const int R0 = blockIdx.x * TILE;
-    const int C0 = blockIdx.y * TILE;
+    const int R0 = tile.x * TILE;     // rows  (I)
+    const int C0 = tile.y * TILE;     // cols  (J <= I)
+    const bool diag = tile.x == tile.y;
+
+    // P tile -> registers, in flight during the whole k-loop
+    float pold[2][2][16];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const int row = R0 + 64 * wr + 32 * rb + l31;
+            const int colb = C0 + 64 * wc + 32 * cb + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = colb + (r & 3) + 8 * (r >> 2);
+                pold[cb][rb][r] = (row < n && col < n) ? P[(size_t)col * ld + row] : 0.0f;
+            }
+        }
 
     f32x16 acc[2][2];                 // [cb][rb]
 #pragma unroll
@@ -60,28 +97,43 @@ __global__ __launch_bounds__(256) void downdate_f32_mfma(float* __restrict__ P, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[cb][rb][r] = 0.0f;
 
-    for (int kc = 0; kc < kp; kc += KC) {
-        // stage 128 x 32 floats of each panel: 1024 float4 per panel, 4 per thread
+    // staging registers: 128 x 32 floats per panel = 1024 float4, 4 per thread per panel
+    f32x4 gx[4], gy[4];
+    const int srow = tid >> 3;        // + 32*s
+    const int sc4 = tid & 7;
+    const float* xsrc = X + (size_t)(R0 + srow) * pitch + 4 * sc4;
+    const float* ysrc = Y + (size_t)(C0 + srow) * pitch + 4 * sc4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        gx[s] = *reinterpret_cast<const f32x4*>(xsrc + (size_t)(32 * s) * pitch);
+        gy[s] = *reinterpret_cast<const f32x4*>(ysrc + (size_t)(32 * s) * pitch);
+    }
+
+    const int nchunks = kp / KC;
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int idx = tid + 256 * s;
-            const int row = idx >> 3;
-            const int c4 = idx & 7;
-            const f32x4 vx = *reinterpret_cast<const f32x4*>(X + (size_t)(R0 + row) * pitch + kc + 4 * c4);
-            const f32x4 vy = *reinterpret_cast<const f32x4*>(Y + (size_t)(C0 + row) * pitch + kc + 4 * c4);
-            *reinterpret_cast<f32x4*>(&sX[row][4 * c4]) = vx;
-            *reinterpret_cast<f32x4*>(&sY[row][4 * c4]) = vy;
+            *reinterpret_cast<f32x4*>(&smem[buf][0][srow + 32 * s][4 * sc4]) = gx[s];
+            *reinterpret_cast<f32x4*>(&smem[buf][1][srow + 32 * s][4 * sc4]) = gy[s];
         }
         __syncthreads();
+        if (c + 1 < nchunks) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                gx[s] = *reinterpret_cast<const f32x4*>(xsrc + (size_t)(32 * s) * pitch + (c + 1) * KC);
+                gy[s] = *reinterpret_cast<const f32x4*>(ysrc + (size_t)(32 * s) * pitch + (c + 1) * KC);
+            }
+        }
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 8) {
             f32x4 a[2], b[2];
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
-                a[cb] = *reinterpret_cast<const f32x4*>(&sY[64 * wc + 32 * cb + l31][kk + 4 * lh]);
+                a[cb] = *reinterpret_cast<const f32x4*>(&smem[buf][1][64 * wc + 32 * cb + l31][kk + 4 * lh]);
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
-                b[rb] = *reinterpret_cast<const f32x4*>(&sX[64 * wr + 32 * rb + l31][kk + 4 * lh]);
+                b[rb] = *reinterpret_cast<const f32x4*>(&smem[buf][0][64 * wr + 32 * rb + l31][kk + 4 * lh]);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -90,45 +142,60 @@ __global__ __launch_bounds__(256) void downdate_f32_mfma(float* __restrict__ P, 
                     for (int rb = 0; rb < 2; ++rb)
                         acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cb][t], b[rb][t], acc[cb][rb], 0, 0, 0);
         }
-        __syncthreads();
     }
+    __syncthreads();                  // every wave is done with the panels: reuse LDS as transpose scratch
+    float* sT = &smem[0][0][0][0] + wave * (32 * TP);
 
-    // P[row, col] -= acc ;  row on the lane, col = register-mapped
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
-            const int row = R0 + 64 * wr + 32 * rb + l31;
-            const int colb = C0 + 64 * wc + 32 * cb + 4 * lh;
-            if (row < n) {
+            const int rowb = R0 + 64 * wr + 32 * rb;
+            const int colb = C0 + 64 * wc + 32 * cb;
+            const int row = rowb + l31;
+            // direct store: rows on the lanes, 32 consecutive rows of one column per half-wave
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int col = colb + (r & 3) + 8 * (r >> 2);
-                    if (col < n) {
-                        float* p = P + (size_t)col * ld + row;
-                        *p = *p - acc[cb][rb][r];
-                    }
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int ci = 4 * lh + (r & 3) + 8 * (r >> 2);
+                const int col = colb + ci;
+                const float val = pold[cb][rb][r] - acc[cb][rb][r];
+                if (row < n && col < n && (!diag || row >= col)) P[(size_t)col * ld + row] = val;
+                sT[l31 * TP + ci] = val;
             }
+            __syncthreads();
+            // mirrored store: element (row rr, col c) goes to P[c, rr]; c on the lanes
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int rr = 2 * s + lh;
+                const float val = sT[rr * TP + l31];
+                const int rowI = rowb + rr;
+                const int colJ = colb + l31;
+                if (rowI < n && colJ < n && (!diag || rowI > colJ)) P[(size_t)rowI * ld + colJ] = val;
+            }
+            __syncthreads();
         }
 }
 
-// ---- fp64 (and generic) VALU down-date ---------------------------------------
+// ---- fp64 VALU down-date -----------------------------------------------------
 constexpr int DT = 64;     // tile edge
 constexpr int DK = 16;     // k-chunk
 
 template <typename T>
 __global__ __launch_bounds__(256) void downdate_valu(T* __restrict__ P, int ld, int n, const T* __restrict__ X,
                                                      const T* __restrict__ Y, int pitch, int kp,
-                                                     const int32_t* __restrict__ status) {
+                                                     const int2* __restrict__ tiles, const int32_t* __restrict__ status) {
     if (status[0] != 0) return;
+    const int2 tile = tiles[blockIdx.x];
+    if (tile.x < 0) return;
     __shared__ T sX[DT][DK + 1];
     __shared__ T sY[DT][DK + 1];
+    __shared__ T sT[DT][DT + 1];
     const int tid = threadIdx.x;
     const int tx = tid & 15;          // rows  tx + 16u
     const int ty = tid >> 4;          // cols  ty + 16v
-    const int R0 = blockIdx.x * DT;
-    const int C0 = blockIdx.y * DT;
+    const int R0 = tile.x * DT;
+    const int C0 = tile.y * DT;
+    const bool diag = tile.x == tile.y;
     T acc[4][4];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -161,33 +228,100 @@ __global__ __launch_bounds__(256) void downdate_valu(T* __restrict__ P, int ld, 
     }
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        const int col = C0 + ty + 16 * v;
-        if (col >= n) continue;
+        const int cl = ty + 16 * v;
+        const int col = C0 + cl;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int row = R0 + tx + 16 * u;
-            if (row < n) {
+            const int rl = tx + 16 * u;
+            const int row = R0 + rl;
+            T val = (T)0;
+            if (row < n && col < n) {
                 T* p = P + (size_t)col * ld + row;
-                *p = *p - acc[u][v];
+                val = *p - acc[u][v];
+                if (!diag || row >= col) *p = val;
             }
+            sT[rl][cl] = val;
         }
     }
+    __syncthreads();
+    // mirror: thread (tx, ty) stores element (row = ty+16v, col = tx+16u) to P[col, row]; col on tx
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int rl = ty + 16 * v;
+        const int rowI = R0 + rl;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cl = tx + 16 * u;
+            const int colJ = C0 + cl;
+            if (rowI < n && colJ < n && (!diag || rowI > colJ)) P[(size_t)rowI * ld + colJ] = sT[rl][cl];
+        }
+    }
+}
+
+// Tile list: entry b is the tile of workgroup b; XCD x (= b % 8 under round-robin
+// dispatch) walks super-rows of SR tile rows, largest first, column by column.
+void build_tile_order(int T, std::vector<int2>& out) {
+    constexpr int NX = 8, SR = 4;
+    const int nsr = (T + SR - 1) / SR;
+    std::vector<long> load(NX, 0);
+    std::vector<std::vector<int>> mine(NX);
+    for (int s = nsr - 1; s >= 0; --s) {
+        const int I0 = s * SR, I1 = std::min(T, I0 + SR);
+        long cnt = 0;
+        for (int I = I0; I < I1; ++I) cnt += I + 1;
+        int best = 0;
+        for (int xcd = 1; xcd < NX; ++xcd)
+            if (load[xcd] < load[best]) best = xcd;
+        load[best] += cnt;
+        mine[best].push_back(s);
+    }
+    std::vector<std::vector<int2>> lists(NX);
+    size_t L = 0;
+    for (int xcd = 0; xcd < NX; ++xcd) {
+        for (int s : mine[xcd]) {
+            const int I0 = s * SR, I1 = std::min(T, I0 + SR);
+            for (int J = 0; J < I1; ++J)
+                for (int I = std::max(I0, J); I < I1; ++I) lists[xcd].push_back(make_int2(I, J));
+        }
+        L = std::max(L, lists[xcd].size());
+    }
+    out.assign(L * NX, make_int2(-1, -1));
+    for (int xcd = 0; xcd < NX; ++xcd)
+        for (size_t slot = 0; slot < lists[xcd].size(); ++slot) out[slot * NX + xcd] = lists[xcd][slot];
+}
+
+int ensure_tile_order(slam_ekf* h, int T) {
+    if (h->tiles && h->tiles_T == T) return SLAM_OK;
+    std::vector<int2> order;
+    build_tile_order(T, order);
+    HIP_TRY(hipStreamSynchronize(h->stream));          // earlier down-dates may still read the old list
+    if ((int)order.size() > h->tiles_cap) {
+        if (h->tiles) (void)hipFree(h->tiles);
+        h->tiles = nullptr;
+        h->tiles_cap = 0;
+        HIP_TRY(hipMalloc((void**)&h->tiles, sizeof(int2) * order.size()));
+        h->tiles_cap = (int)order.size();
+    }
+    HIP_TRY(hipMemcpy(h->tiles, order.data(), sizeof(int2) * order.size(), hipMemcpyHostToDevice));
+    h->tiles_T = T;
+    h->tiles_len = (int)order.size();
+    return SLAM_OK;
 }
 
 }  // namespace
 
 int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int pitch) {
     const int n = 3 + 2 * h->N;
+    const int edge = h->dtype == SLAM_F32 ? TILE : DT;
+    const int rc = ensure_tile_order(h, (n + edge - 1) / edge);
+    if (rc) return rc;
     KTimer t(h, SLAM_K_SYRK);
-    if (h->dtype == SLAM_F32) {
-        const int tiles = (n + TILE - 1) / TILE;
-        hipLaunchKernelGGL(downdate_f32_mfma, dim3(tiles, tiles), dim3(256), 0, h->stream, (float*)h->P, h->ld, n,
-                           (const float*)X, (const float*)Y, pitch, kp_total, h->d_status);
-    } else {
-        const int tiles = (n + DT - 1) / DT;
-        hipLaunchKernelGGL(downdate_valu<double>, dim3(tiles, tiles), dim3(256), 0, h->stream, (double*)h->P, h->ld, n,
-                           (const double*)X, (const double*)Y, pitch, kp_total, h->d_status);
-    }
+    if (h->dtype == SLAM_F32)
+        hipLaunchKernelGGL(downdate_f32_mfma, dim3(h->tiles_len), dim3(256), 0, h->stream, (float*)h->P, h->ld, n,
+                           (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->d_status);
+    else
+        hipLaunchKernelGGL(downdate_valu<double>, dim3(h->tiles_len), dim3(256), 0, h->stream, (double*)h->P, h->ld, n,
+                           (const double*)X, (const double*)Y, pitch, kp_total, (const int2*)h->tiles, h->d_status);
     HIP_TRY(hipGetLastError());
     return SLAM_OK;
 }

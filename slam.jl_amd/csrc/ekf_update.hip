@@ -3,58 +3,73 @@
 //   K2/K3  pht_kernel      PHt = P*H'  from the 5 non-zero columns of each H row pair
 //                          (the reference multiplies by a dense 2m x n H, :67)
 //   K4     factor_kernel   S = H*PHt + RR, S = (S+S')/2, C = inv(chol(S))   (:68-70)
-//                          one workgroup, double precision, LDS resident
-//   K5     panel_gemm      W1 = PHt*C (:71);   x += W*v = PHt*(C*C'*v)   (:72,:74)
+//                          one workgroup, double precision, register/LDS resident
+//   K5     panel_gemm      W1 = PHt*C (:71);   x_update: x += W*v = PHt*(C*C'*v)   (:72,:74)
 //
 // The covariance down-date P -= W1*W1' (:75) is in ekf_syrk.hip.
 //
-// Panel buffers are ROW-major [npad][pitch] in the state dtype, zero in rows >= n
-// (never written) and in columns k..kp-1 (written as zeros here), so the
-// down-date needs no guards on its operand loads.
+// Precision: everything in this file is evaluated in DOUBLE whatever the state
+// dtype.  S inherits the low-rank structure of P, so C has large entries of mixed
+// sign and PHt*C cancels by one to two orders of magnitude; doing that product in
+// fp32 costs ~1e-3 relative error on the updated covariance blocks.  W1 is rounded
+// to the state dtype once, at the end.
+//
+// Panel buffers are ROW-major [npad][pitch], zero in rows >= n (never written)
+// and in columns k..kp-1 (written as zeros here), so the down-date needs no
+// guards on its operand loads.
 #include "common.h"
 #include "device_math.h"
 
 int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int pitch);   // ekf_syrk.hip
-int joseph_T_pass(slam_ekf* h, int kp);
 
 namespace {
 
 // ---------------------------------------------------------------------------
 // K2/K3: PHt[r, 2i:2i+2] = P[r,0:3]*Hv_i' + P[r,f_i:f_i+2]*Hf_i'
+// grid.x: 256-row blocks, grid.y: chunks of PHT_OBS observations
 // ---------------------------------------------------------------------------
+constexpr int PHT_OBS = 16;
+
 template <typename T>
 __global__ __launch_bounds__(256) void pht_kernel(const T* __restrict__ x, const T* __restrict__ P, int ld, int n,
                                                    const int32_t* __restrict__ idf, int m, int k, int kp,
-                                                   T* __restrict__ PHt, int pitch) {
-    extern __shared__ double sm[];            // [m][10] Jacobian blocks, then int f[m]
-    int* sf = reinterpret_cast<int*>(sm + (size_t)10 * m);
+                                                   double* __restrict__ PHt, int pitch) {
+    __shared__ double sh[PHT_OBS][10];
+    __shared__ int sf[PHT_OBS];
     const int tid = threadIdx.x;
-    const double xv = (double)x[0], yv = (double)x[1], phi = (double)x[2];
-    for (int i = tid; i < m; i += blockDim.x) {
-        const int f = 3 + 2 * (idf[i] - 1);
+    const int i0 = blockIdx.y * PHT_OBS;
+    const int mc = (m - i0 < PHT_OBS) ? m - i0 : PHT_OBS;       // observations in this chunk (may be <= 0 for pure padding)
+    if (tid < mc) {
+        const double xv = (double)x[0], yv = (double)x[1], phi = (double)x[2];
+        const int f = 3 + 2 * (idf[i0 + tid] - 1);
         const ObsModel om = obs_model(xv, yv, phi, (double)x[f], (double)x[f + 1]);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) sm[10 * i + q] = om.Hv[q];
+        for (int q = 0; q < 6; ++q) sh[tid][q] = om.Hv[q];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) sm[10 * i + 6 + q] = om.Hf[q];
-        sf[i] = f;
+        for (int q = 0; q < 4; ++q) sh[tid][6 + q] = om.Hf[q];
+        sf[tid] = f;
     }
     __syncthreads();
     const int r = blockIdx.x * blockDim.x + tid;
     if (r >= n) return;
-    const double p0 = (double)P[(size_t)0 * ld + r];
-    const double p1 = (double)P[(size_t)1 * ld + r];
-    const double p2 = (double)P[(size_t)2 * ld + r];
-    T* out = PHt + (size_t)r * pitch;
-    for (int i = 0; i < m; ++i) {
-        const double* hb = sm + 10 * i;
-        const int f = sf[i];
-        const double q0 = (double)P[(size_t)f * ld + r];
-        const double q1 = (double)P[(size_t)(f + 1) * ld + r];
-        out[2 * i] = (T)(hb[0] * p0 + hb[1] * p1 + hb[2] * p2 + hb[6] * q0 + hb[7] * q1);
-        out[2 * i + 1] = (T)(hb[3] * p0 + hb[4] * p1 + hb[5] * p2 + hb[8] * q0 + hb[9] * q1);
+    double* out = PHt + (size_t)r * pitch + 2 * i0;
+    if (mc > 0) {
+        const double p0 = (double)P[(size_t)0 * ld + r];
+        const double p1 = (double)P[(size_t)1 * ld + r];
+        const double p2 = (double)P[(size_t)2 * ld + r];
+        for (int i = 0; i < mc; ++i) {
+            const double* hb = sh[i];
+            const int f = sf[i];
+            const double q0 = (double)P[(size_t)f * ld + r];
+            const double q1 = (double)P[(size_t)(f + 1) * ld + r];
+            out[2 * i] = hb[0] * p0 + hb[1] * p1 + hb[2] * p2 + hb[6] * q0 + hb[7] * q1;
+            out[2 * i + 1] = hb[3] * p0 + hb[4] * p1 + hb[5] * p2 + hb[8] * q0 + hb[9] * q1;
+        }
     }
-    for (int c = k; c < kp; ++c) out[c] = (T)0;
+    // zero the padding columns k..kp-1 that fall into this chunk
+    const int c_begin = (2 * i0 > k) ? 2 * i0 : k;
+    const int c_end = (2 * (i0 + PHT_OBS) < kp) ? 2 * (i0 + PHT_OBS) : kp;
+    for (int c = c_begin; c < c_end; ++c) PHt[(size_t)r * pitch + c] = 0.0;
 }
 
 // ---------------------------------------------------------------------------
@@ -65,28 +80,114 @@ __global__ __launch_bounds__(256) void pht_kernel(const T* __restrict__ x, const
 // holds row i of inv(L) (unit lower), the diagonal holds D.  Then
 //   chol(S) = U = sqrt(D) L'   and   C = inv(U) = inv(L)' / sqrt(D)  (upper),
 // which is the reference's inv(chol(S)) (unique: upper, positive diagonal,
-// C*C' = inv(S)).  Two barriers per elimination step.
+// C*C' = inv(S)).
+//
+// For kp <= 128 the matrix lives in REGISTERS during the elimination: the 1024
+// threads form a 32 x 32 grid and thread (ty, tx) owns the elements
+// (ty + 32u, tx + 32v) -- a cyclic distribution, so every thread stays busy as the
+// active rows shrink.  Per step the owners publish row j and column j through a
+// double-buffered LDS line, one barrier, and everyone updates its registers.
+// Larger k falls back to an elimination in global memory (two barriers per step).
 // ---------------------------------------------------------------------------
 constexpr int FACTOR_THREADS = 1024;
 
+template <int NB>
+__device__ inline bool eliminate_in_registers(double* M, int mp, int k, int kp, double* rowbuf, double* colbuf) {
+    const int tid = threadIdx.x;
+    const int tx = tid & 31, ty = tid >> 5;
+    double a[NB][NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+#pragma unroll
+        for (int v = 0; v < NB; ++v) a[u][v] = M[(size_t)(ty + 32 * u) * mp + tx + 32 * v];
+    bool bad = false;
+#pragma unroll
+    for (int ub = 0; ub < NB; ++ub) {
+        for (int jj = 0; jj < 32; ++jj) {
+            const int j = 32 * ub + jj;
+            if (j >= k || bad) break;                     // uniform
+            double* rb = rowbuf + (j & 1) * kp;
+            double* cb = colbuf + (j & 1) * kp;
+            if (ty == jj) {
+#pragma unroll
+                for (int v = 0; v < NB; ++v) rb[tx + 32 * v] = a[ub][v];
+            }
+            if (tx == jj) {
+#pragma unroll
+                for (int u = 0; u < NB; ++u) cb[ty + 32 * u] = a[u][ub];
+            }
+            __syncthreads();
+            const double piv = rb[j];
+            if (!(piv > 0.0) || piv == __builtin_inf()) { bad = true; break; }   // uniform: same LDS word
+            const double rp = 1.0 / piv;
+            double rowv[NB], mm[NB];
+#pragma unroll
+            for (int v = 0; v < NB; ++v) rowv[v] = rb[tx + 32 * v];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) mm[u] = cb[ty + 32 * u] * rp;
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int i = ty + 32 * u;
+                if (i > j && i < k) {
+#pragma unroll
+                    for (int v = 0; v < NB; ++v) {
+                        const int c = tx + 32 * v;
+                        a[u][v] = (c == j) ? -mm[u] : a[u][v] - mm[u] * rowv[v];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+#pragma unroll
+        for (int v = 0; v < NB; ++v) M[(size_t)(ty + 32 * u) * mp + tx + 32 * v] = a[u][v];
+    __syncthreads();
+    return !bad;
+}
+
+__device__ inline bool eliminate_in_memory(double* M, int mp, int k, double* mvec) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int j = 0; j < k; ++j) {
+        const double piv = M[(size_t)j * mp + j];
+        if (!(piv > 0.0) || piv == __builtin_inf()) return false;      // uniform
+        const double rp = 1.0 / piv;
+        for (int i = j + 1 + tid; i < k; i += nt) mvec[i] = M[(size_t)i * mp + j] * rp;
+        __syncthreads();
+        const int rows = k - j - 1;
+        for (int idx = tid; idx < rows * k; idx += nt) {
+            const int ii = idx / k;
+            const int c = idx - ii * k;
+            const int i = j + 1 + ii;
+            const double mi = mvec[i];
+            if (c == j) M[(size_t)i * mp + j] = -mi;
+            else M[(size_t)i * mp + c] -= mi * M[(size_t)j * mp + c];
+        }
+        __syncthreads();
+    }
+    return true;
+}
+
 template <typename T>
 __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
-    const T* __restrict__ x, const T* __restrict__ PHt, int pht_pitch, const double* __restrict__ z,
+    const T* __restrict__ x, const double* __restrict__ PHt, int pht_pitch, const double* __restrict__ z,
     const int32_t* __restrict__ idf, int m, int k, int kp, double R0, double R1, double R2, double R3,
-    T* __restrict__ Cout, int c_pitch, double* __restrict__ gvec, double* __restrict__ Sout, int want_sinv,
+    double* __restrict__ Cout, int c_pitch, double* __restrict__ gvec, double* __restrict__ Sout, int want_sinv,
     double* __restrict__ Mglobal, int32_t* __restrict__ status) {
     extern __shared__ double lds[];
     const int tid = threadIdx.x;
     const int nt = blockDim.x;
-    const int mp = kp + 1;                                   // pitch of M (odd: conflict-free column walks)
+    const int mp = kp + 1;                                   // odd pitch: conflict-free column walks
     double* M = Mglobal ? Mglobal : lds;
     double* aux = Mglobal ? lds : lds + (size_t)kp * mp;
-    double* mvec = aux;                                      // [kp]
-    double* vvec = aux + kp;                                 // [kp] innovation
+    double* mvec = aux;                                      // [kp]  multipliers, later 1/sqrt(D)
+    double* vvec = aux + kp;                                 // [kp]  innovation
     double* yvec = aux + 2 * kp;                             // [kp]
-    double* hb = aux + 3 * kp;                               // [m][10]
+    double* rowbuf = aux + 3 * kp;                           // [2][kp]
+    double* colbuf = aux + 5 * kp;                           // [2][kp]
+    double* hb = aux + 7 * kp;                               // [m][10]
     int* sf = reinterpret_cast<int*>(hb + (size_t)10 * m);   // [m]
-    const double R[2][2] = {{R0, R2}, {R1, R3}};
 
     if (tid == 0) status[0] = 0;
     // innovation and Jacobian blocks (ekf.jl:55-61)
@@ -111,12 +212,10 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
             const int i = a >> 1, ra = a & 1;
             const double* h = hb + 10 * i;
             const int f = sf[i];
-            s = h[3 * ra + 0] * (double)PHt[(size_t)0 * pht_pitch + b] +
-                h[3 * ra + 1] * (double)PHt[(size_t)1 * pht_pitch + b] +
-                h[3 * ra + 2] * (double)PHt[(size_t)2 * pht_pitch + b] +
-                h[6 + 2 * ra + 0] * (double)PHt[(size_t)f * pht_pitch + b] +
-                h[6 + 2 * ra + 1] * (double)PHt[(size_t)(f + 1) * pht_pitch + b];
-            if ((b >> 1) == i) s += R[ra][b & 1];
+            s = h[3 * ra + 0] * PHt[(size_t)0 * pht_pitch + b] + h[3 * ra + 1] * PHt[(size_t)1 * pht_pitch + b] +
+                h[3 * ra + 2] * PHt[(size_t)2 * pht_pitch + b] + h[6 + 2 * ra + 0] * PHt[(size_t)f * pht_pitch + b] +
+                h[6 + 2 * ra + 1] * PHt[(size_t)(f + 1) * pht_pitch + b];
+            if ((b >> 1) == i) s += ra ? ((b & 1) ? R3 : R1) : ((b & 1) ? R2 : R0);     // RR block = R (column-major args)
         } else {
             s = (a == b) ? 1.0 : 0.0;
         }
@@ -136,66 +235,57 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
     if (Sout) {
         for (int idx = tid; idx < kp * kp; idx += nt) {
             const int a = idx / kp, b = idx - a * kp;
-            Sout[(size_t)a * kp + b] = (a < k && b < k) ? M[(size_t)a * mp + b] : 0.0;
+            Sout[(size_t)a * c_pitch + b] = (a < k && b < k) ? M[(size_t)a * mp + b] : 0.0;
         }
     }
+    __syncthreads();
 
-    // elimination (see header comment)
-    bool bad = false;
-    for (int j = 0; j < k; ++j) {
-        const double piv = M[(size_t)j * mp + j];
-        if (!(piv > 0.0) || piv == __builtin_inf()) { bad = true; break; }   // uniform: every thread reads the same word
-        const double rp = 1.0 / piv;
-        for (int i = j + 1 + tid; i < k; i += nt) mvec[i] = M[(size_t)i * mp + j] * rp;
-        __syncthreads();
-        const int rows = k - j - 1;
-        for (int idx = tid; idx < rows * k; idx += nt) {
-            const int ii = idx / k;
-            const int c = idx - ii * k;
-            const int i = j + 1 + ii;
-            const double mi = mvec[i];
-            if (c == j) M[(size_t)i * mp + j] = -mi;
-            else M[(size_t)i * mp + c] -= mi * M[(size_t)j * mp + c];
-        }
-        __syncthreads();
-    }
-    if (bad) {
+    bool ok;
+    if (Mglobal) ok = eliminate_in_memory(M, mp, k, mvec);
+    else if (kp == 32) ok = eliminate_in_registers<1>(M, mp, k, kp, rowbuf, colbuf);
+    else if (kp == 64) ok = eliminate_in_registers<2>(M, mp, k, kp, rowbuf, colbuf);
+    else if (kp == 96) ok = eliminate_in_registers<3>(M, mp, k, kp, rowbuf, colbuf);
+    else ok = eliminate_in_registers<4>(M, mp, k, kp, rowbuf, colbuf);
+    if (!ok) {
         if (tid == 0) { status[0] = 1; status[1] = 1; }    // [1] is sticky until slam_ekf_sync reads it
         return;
     }
     // mvec <- 1/sqrt(D)
     for (int b = tid; b < kp; b += nt) mvec[b] = (b < k) ? 1.0 / sqrt(M[(size_t)b * mp + b]) : 0.0;
     __syncthreads();
-    // y = C'*v :  y[b] = (v[b] + sum_{a<b} Linv[b][a] v[a]) / sqrt(D_b)
-    for (int b = tid; b < kp; b += nt) {
+    // y = C'*v :  y[b] = (v[b] + sum_{a<b} Linv[b][a] v[a]) / sqrt(D_b);  8 lanes per row
+    for (int b0 = 0; b0 < kp; b0 += nt / 8) {
+        const int b = b0 + (tid >> 3), part = tid & 7;
         double s = 0.0;
-        if (b < k) {
-            s = vvec[b];
-            for (int a = 0; a < b; ++a) s += M[(size_t)b * mp + a] * vvec[a];
-            s *= mvec[b];
-        }
-        yvec[b] = s;
+        if (b < k)
+            for (int a = part; a < b; a += 8) s += M[(size_t)b * mp + a] * vvec[a];
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (part == 0 && b < kp) yvec[b] = (b < k) ? (s + vvec[b]) * mvec[b] : 0.0;
     }
     __syncthreads();
     // g = C*y = inv(S)*v  (x += PHt*g  ==  x += W*v, ekf.jl:72,74)
-    for (int a = tid; a < kp; a += nt) {
+    for (int a0 = 0; a0 < kp; a0 += nt / 8) {
+        const int a = a0 + (tid >> 3), part = tid & 7;
         double s = 0.0;
-        if (a < k) {
-            s = yvec[a] * mvec[a];
-            for (int b = a + 1; b < k; ++b) s += M[(size_t)b * mp + a] * mvec[b] * yvec[b];
-        }
-        gvec[a] = s;
+        if (a < k)
+            for (int b = a + 1 + part; b < k; b += 8) s += M[(size_t)b * mp + a] * mvec[b] * yvec[b];
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (part == 0 && a < kp) gvec[a] = (a < k) ? s + yvec[a] * mvec[a] : 0.0;
     }
     if (!want_sinv) {
         // C[a][b] = Linv[b][a]/sqrt(D_b) (a<b), 1/sqrt(D_b) (a==b), 0 below and in the padding
         for (int idx = tid; idx < kp * kp; idx += nt) {
-            const int a = idx / kp, b = idx - a * kp;
+            const int b = idx / kp, a = idx - b * kp;         // consecutive threads walk a row of M
             double c = 0.0;
             if (a < k && b < k) {
                 if (a == b) c = mvec[b];
                 else if (a < b) c = M[(size_t)b * mp + a] * mvec[b];
             }
-            Cout[(size_t)a * c_pitch + b] = (T)c;
+            Cout[(size_t)a * c_pitch + b] = c;
         }
     } else {
         // inv(S) = C*C' :  Sinv[a][b] = sum_{c >= max(a,b)} C[a][c] C[b][c]   (Joseph form needs K = PHt*inv(S))
@@ -210,82 +300,104 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
                     s += ca * cb * mvec[c] * mvec[c];
                 }
             }
-            Cout[(size_t)a * c_pitch + b] = (T)s;
+            Cout[(size_t)a * c_pitch + b] = s;
         }
     }
 }
 
 // ---------------------------------------------------------------------------
-// K5: OUT = beta*ADD + alpha*(IN * MAT)   (n x kp) = (n x kp)(kp x kp)
-// ROWS=64 rows per block, 32 output columns per block (blockIdx.y), inner
-// dimension staged through LDS in chunks of 128.  `upper` skips the part of an
-// upper-triangular MAT that is structurally zero.
+// K5: OUT = beta*ADD + alpha*(IN * MAT)   (n x kp) = (n x kp)(kp x kp), in double.
+// 128 rows x 64 columns per block, 4 x 8 outputs per thread (rows tr + 32u so the
+// LDS column walk is conflict-free), inner dimension staged through LDS in chunks
+// of 32.  `upper` skips the structurally zero part of an upper-triangular MAT.
+// The result is written in the state dtype to OUT1 (and OUT2), optionally also in
+// double to OUTD.
 // ---------------------------------------------------------------------------
-constexpr int PG_ROWS = 64;
-constexpr int PG_COLS = 32;
-template <typename T> struct PgKc { static constexpr int value = 128; };
-template <> struct PgKc<double> { static constexpr int value = 64; };
+constexpr int PG_ROWS = 128;
+constexpr int PG_COLS = 64;
+constexpr int PG_KC = 32;
 
-template <typename T>
-__global__ __launch_bounds__(256) void panel_gemm_kernel(const T* __restrict__ IN, int in_pitch, const T* __restrict__ MAT,
-                                                          int mat_pitch, int kp, int upper, T alpha, const T* __restrict__ ADD,
-                                                          int add_pitch, T beta, T* __restrict__ OUT1, int out1_pitch,
-                                                          int out1_col, T* __restrict__ OUT2, int out2_pitch, int out2_col,
+template <typename TO>
+__global__ __launch_bounds__(256) void panel_gemm_kernel(const double* __restrict__ IN, int in_pitch,
+                                                          const double* __restrict__ MAT, int mat_pitch, int kp, int upper,
+                                                          double alpha, const double* __restrict__ ADD, int add_pitch,
+                                                          double beta, TO* __restrict__ OUT1, int out1_pitch, int out1_col,
+                                                          TO* __restrict__ OUT2, int out2_pitch, int out2_col,
+                                                          double* __restrict__ OUTD, int outd_pitch,
                                                           const int32_t* __restrict__ status) {
     if (status[0] != 0) return;
-    constexpr int PG_KC = PgKc<T>::value;
-    __shared__ T sIn[PG_ROWS][PG_KC + 1];
-    __shared__ __attribute__((aligned(16))) T sMat[PG_KC][PG_COLS];
+    __shared__ double sIn[PG_ROWS][PG_KC + 1];
+    __shared__ __attribute__((aligned(16))) double sMat[PG_KC][PG_COLS];
     const int tid = threadIdx.x;
-    const int r = tid & 63;
-    const int cq = tid >> 6;
+    const int tr = tid & 31;          // rows tr + 32u
+    const int tc = tid >> 5;          // cols tc*8 + q
     const int row0 = blockIdx.x * PG_ROWS;
     const int b0 = blockIdx.y * PG_COLS;
-    T acc[8];
+    const int bw = (kp - b0 < PG_COLS) ? kp - b0 : PG_COLS;            // valid columns of this block (multiple of 32)
+    double acc[4][8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = (T)0;
-    const int a_end = upper ? (b0 + PG_COLS < kp ? b0 + PG_COLS : kp) : kp;
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[u][q] = 0.0;
+    const int a_end = upper ? (b0 + bw) : kp;
     for (int a0 = 0; a0 < a_end; a0 += PG_KC) {
-        const int ac = (a_end - a0 < PG_KC) ? a_end - a0 : PG_KC;     // multiple of 32
-        // IN tile: 64 rows x ac columns, coalesced along the row
-        for (int idx = tid; idx < PG_ROWS * ac; idx += 256) {
-            const int rr = idx / ac, cc = idx - rr * ac;
+        // IN tile 128 x 32 (coalesced along the row), MAT tile 32 x 64
+        for (int idx = tid; idx < PG_ROWS * PG_KC; idx += 256) {
+            const int rr = idx >> 5, cc = idx & 31;
             sIn[rr][cc] = IN[(size_t)(row0 + rr) * in_pitch + a0 + cc];
         }
-        for (int idx = tid; idx < ac * PG_COLS; idx += 256) {
-            const int aa = idx / PG_COLS, bb = idx - aa * PG_COLS;
-            sMat[aa][bb] = MAT[(size_t)(a0 + aa) * mat_pitch + b0 + bb];
+        for (int idx = tid; idx < PG_KC * PG_COLS; idx += 256) {
+            const int aa = idx >> 6, bb = idx & 63;
+            sMat[aa][bb] = (bb < bw) ? MAT[(size_t)(a0 + aa) * mat_pitch + b0 + bb] : 0.0;
         }
         __syncthreads();
-        for (int a = 0; a < ac; ++a) {
-            const T p = sIn[r][a];
+#pragma unroll 4
+        for (int a = 0; a < PG_KC; ++a) {
+            double p[4];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] += p * sMat[a][cq * 8 + q];
+            for (int u = 0; u < 4; ++u) p[u] = sIn[tr + 32 * u][a];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double mv = sMat[a][tc * 8 + q];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u][q] += p[u] * mv;
+            }
         }
         __syncthreads();
     }
-    const size_t row = (size_t)(row0 + r);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int b = b0 + cq * 8 + q;
-        T v = alpha * acc[q];
-        if (ADD) v += beta * ADD[row * add_pitch + b];
-        OUT1[row * out1_pitch + out1_col + b] = v;
-        if (OUT2) OUT2[row * out2_pitch + out2_col + b] = v;
+    for (int u = 0; u < 4; ++u) {
+        const size_t row = (size_t)(row0 + tr + 32 * u);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int b = b0 + tc * 8 + q;
+            if (b >= kp) continue;
+            double v = alpha * acc[u][q];
+            if (ADD) v += beta * ADD[row * add_pitch + b];
+            OUT1[row * out1_pitch + out1_col + b] = (TO)v;
+            if (OUT2) OUT2[row * out2_pitch + out2_col + b] = (TO)v;
+            if (OUTD) OUTD[row * outd_pitch + b] = v;
+        }
     }
 }
 
-// x += PHt * g      (ekf.jl:74 with W*v = PHt*(C*C'*v))
+// x += PHt * g      (ekf.jl:74 with W*v = PHt*(C*C'*v)); 8 lanes per row
 template <typename T>
-__global__ __launch_bounds__(256) void x_update_kernel(T* __restrict__ x, const T* __restrict__ PHt, int pitch, int n, int k,
-                                                        const double* __restrict__ g, const int32_t* __restrict__ status) {
+__global__ __launch_bounds__(256) void x_update_kernel(T* __restrict__ x, const double* __restrict__ PHt, int pitch, int n,
+                                                        int k, const double* __restrict__ g,
+                                                        const int32_t* __restrict__ status) {
     if (status[0] != 0) return;
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const T* row = PHt + (size_t)r * pitch;
+    const int r = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int part = threadIdx.x & 7;
     double s = 0.0;
-    for (int a = 0; a < k; ++a) s += (double)row[a] * g[a];
-    x[r] = (T)((double)x[r] + s);
+    if (r < n) {
+        const double* row = PHt + (size_t)r * pitch;
+        for (int a = part; a < k; a += 8) s += row[a] * g[a];
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    if (part == 0 && r < n) x[r] = (T)((double)x[r] + s);
 }
 
 template <typename T>
@@ -293,94 +405,60 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form) {
     const int n = 3 + 2 * h->N;
     const int k = 2 * m;
     const int kp = round_up(k, SLAM_KPAD);
-    const int pitchA = h->kcap;         // PHt, Cmat
+    const int pitchA = h->kcap;         // PHt, Cmat, Smat, Kd
     const int pitchW = 2 * h->kcap;     // W1, W2
     T* x = (T*)h->x;
     T* P = (T*)h->P;
-    T* PHt = (T*)h->PHt;
     T* W1 = (T*)h->W1;
     T* W2 = (T*)h->W2;
-    T* Cm = (T*)h->Cmat;
+    const bool joseph = form == SLAM_FORM_JOSEPH;
 
     {   // K2/K3
         KTimer t(h, SLAM_K_PHT);
-        const size_t shm = (size_t)m * (10 * sizeof(double) + sizeof(int));
-        hipLaunchKernelGGL(pht_kernel<T>, dim3((n + 255) / 256), dim3(256), shm, h->stream, x, P, h->ld, n, h->idfbuf, m, k,
-                           kp, PHt, pitchA);
+        const dim3 grid((n + 255) / 256, kp / (2 * PHT_OBS));
+        hipLaunchKernelGGL(pht_kernel<T>, grid, dim3(256), 0, h->stream, x, P, h->ld, n, h->idfbuf, m, k, kp, h->PHt, pitchA);
     }
     HIP_TRY(hipGetLastError());
     {   // K4
         KTimer t(h, SLAM_K_FACTOR);
         const bool in_lds = kp <= 128;
-        const size_t aux = (size_t)3 * kp * sizeof(double) + (size_t)m * (10 * sizeof(double) + sizeof(int));
+        const size_t aux = (size_t)7 * kp * sizeof(double) + (size_t)m * (10 * sizeof(double) + sizeof(int));
         const size_t shm = aux + (in_lds ? (size_t)kp * (kp + 1) * sizeof(double) : 0);
-        hipLaunchKernelGGL(factor_kernel<T>, dim3(1), dim3(FACTOR_THREADS), shm, h->stream, x, PHt, pitchA, h->obsbuf,
-                           h->idfbuf, m, k, kp, R[0], R[1], R[2], R[3], Cm, pitchA, h->gvec,
-                           form == SLAM_FORM_JOSEPH ? h->Smat : (double*)nullptr, form == SLAM_FORM_JOSEPH ? 1 : 0,
-                           in_lds ? (double*)nullptr : h->Mwork, h->d_status);
+        hipLaunchKernelGGL(factor_kernel<T>, dim3(1), dim3(FACTOR_THREADS), shm, h->stream, x, h->PHt, pitchA, h->obsbuf,
+                           h->idfbuf, m, k, kp, R[0], R[1], R[2], R[3], h->Cmat, pitchA, h->gvec,
+                           joseph ? h->Smat : (double*)nullptr, joseph ? 1 : 0, in_lds ? (double*)nullptr : h->Mwork,
+                           h->d_status);
     }
     HIP_TRY(hipGetLastError());
-    const dim3 pg_grid(h->npad / PG_ROWS, kp / PG_COLS);
+    const dim3 pg_grid(h->npad / PG_ROWS, (kp + PG_COLS - 1) / PG_COLS);
     int kp_total;
     {   // K5
         KTimer t(h, SLAM_K_W1);
-        if (form == SLAM_FORM_CHOLESKY) {
+        if (!joseph) {
             // W1 = PHt*C
-            hipLaunchKernelGGL(panel_gemm_kernel<T>, pg_grid, dim3(256), 0, h->stream, PHt, pitchA, Cm, pitchA, kp, 1, (T)1,
-                               (const T*)nullptr, 0, (T)0, W1, pitchW, 0, (T*)nullptr, 0, 0, h->d_status);
+            hipLaunchKernelGGL(panel_gemm_kernel<T>, pg_grid, dim3(256), 0, h->stream, h->PHt, pitchA, h->Cmat, pitchA, kp, 1,
+                               1.0, (const double*)nullptr, 0, 0.0, W1, pitchW, 0, (T*)nullptr, 0, 0, (double*)nullptr, 0,
+                               h->d_status);
             kp_total = kp;
         } else {
-            // K = PHt*inv(S)  ->  W1[:, 0:kp] and W2[:, kp:2kp]
-            hipLaunchKernelGGL(panel_gemm_kernel<T>, pg_grid, dim3(256), 0, h->stream, PHt, pitchA, Cm, pitchA, kp, 0, (T)1,
-                               (const T*)nullptr, 0, (T)0, W1, pitchW, 0, W2, pitchW, kp, h->d_status);
-            // S (double) -> dtype copy into Cmat is done by convert below; T = PHt - 0.5*K*S -> W1[:, kp:2kp], W2[:, 0:kp]
+            // K = PHt*inv(S)            -> W1[:, 0:kp], W2[:, kp:2kp], Kd (double)
+            hipLaunchKernelGGL(panel_gemm_kernel<T>, pg_grid, dim3(256), 0, h->stream, h->PHt, pitchA, h->Cmat, pitchA, kp, 0,
+                               1.0, (const double*)nullptr, 0, 0.0, W1, pitchW, 0, W2, pitchW, kp, h->Kd, pitchA,
+                               h->d_status);
+            // T = PHt - 0.5 * K * S     -> W1[:, kp:2kp], W2[:, 0:kp]
+            hipLaunchKernelGGL(panel_gemm_kernel<T>, pg_grid, dim3(256), 0, h->stream, (const double*)h->Kd, pitchA,
+                               (const double*)h->Smat, pitchA, kp, 0, -0.5, (const double*)h->PHt, pitchA, 1.0, W1, pitchW,
+                               kp, W2, pitchW, 0, (double*)nullptr, 0, h->d_status);
             kp_total = 2 * kp;
         }
-        hipLaunchKernelGGL(x_update_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, h->stream, x, PHt, pitchA, n, k,
-                           h->gvec, h->d_status);
+        hipLaunchKernelGGL(x_update_kernel<T>, dim3((n + 31) / 32), dim3(256), 0, h->stream, x, h->PHt, pitchA, n, k, h->gvec,
+                           h->d_status);
     }
     HIP_TRY(hipGetLastError());
-    if (form == SLAM_FORM_JOSEPH) {
-        const int rc = joseph_T_pass(h, kp);
-        if (rc != SLAM_OK) return rc;
-    }
-    return launch_downdate(h, kp_total, W1, form == SLAM_FORM_CHOLESKY ? (const void*)W1 : (const void*)W2, pitchW);
-}
-
-// dtype copy of the k x k double matrix S into Cmat (row-major, pitch kcap)
-template <typename T>
-__global__ void convert_s_kernel(const double* __restrict__ S, int kp, T* __restrict__ out, int pitch,
-                                 const int32_t* __restrict__ status) {
-    if (status[0] != 0) return;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= kp * kp) return;
-    const int a = idx / kp, b = idx - a * kp;
-    out[(size_t)a * pitch + b] = (T)S[idx];
-}
-
-template <typename T>
-int joseph_T_typed(slam_ekf* h, int kp) {
-    const int pitchA = h->kcap, pitchW = 2 * h->kcap;
-    T* PHt = (T*)h->PHt;
-    T* W1 = (T*)h->W1;
-    T* W2 = (T*)h->W2;
-    T* Cm = (T*)h->Cmat;
-    KTimer t(h, SLAM_K_W1);
-    hipLaunchKernelGGL(convert_s_kernel<T>, dim3((kp * kp + 255) / 256), dim3(256), 0, h->stream, h->Smat, kp, Cm, pitchA,
-                       h->d_status);
-    const dim3 pg_grid(h->npad / PG_ROWS, kp / PG_COLS);
-    // T = PHt - 0.5 * K * S ;  K is W1[:, 0:kp]
-    hipLaunchKernelGGL(panel_gemm_kernel<T>, pg_grid, dim3(256), 0, h->stream, (const T*)W1, pitchW, (const T*)Cm, pitchA, kp,
-                       0, (T)-0.5, (const T*)PHt, pitchA, (T)1, W1, pitchW, kp, W2, pitchW, 0, h->d_status);
-    HIP_TRY(hipGetLastError());
-    return SLAM_OK;
+    return launch_downdate(h, kp_total, W1, joseph ? (const void*)W2 : (const void*)W1, pitchW);
 }
 
 }  // namespace
-
-int joseph_T_pass(slam_ekf* h, int kp) {
-    return h->dtype == SLAM_F32 ? joseph_T_typed<float>(h, kp) : joseph_T_typed<double>(h, kp);
-}
 
 int launch_update(slam_ekf* h, int m, const double R[4], int form) {
     return h->dtype == SLAM_F32 ? update_typed<float>(h, m, R, form) : update_typed<double>(h, m, R, form);
