@@ -22,7 +22,7 @@
 namespace {
 
 constexpr int GATE_BLOCK = 64;      // one wave per workgroup: N/64 workgroups spread the sweep over the CUs
-constexpr int GATE_WAVES = GATE_BLOCK / 64;
+constexpr int GATE_WAVES = 1;
 
 struct PairConst {        // per-landmark, observation-independent
     double zp0, zp1;
@@ -112,10 +112,9 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(const T* __restrict__ 
                                                            double* __restrict__ part) {
     extern __shared__ double smem[];
     double* zs = smem;                 // [nz][2]
-    double* red = smem + 2 * nz;       // [nz][GATE_WAVES][3]
+    double* red = smem + 2 * nz;       // [nz][3]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
     for (int i = tid; i < 2 * nz; i += GATE_BLOCK) zs[i] = z[i];
 
     const double R[4] = {R0, R1, R2, R3};
@@ -130,9 +129,17 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(const T* __restrict__ 
     const bool valid = j0 < N;
     PairConst pc;
     if (valid) pc = landmark_const(x, P, ld, j0, pose, pvv, R);
+    const double INF = __builtin_inf();
+    // per-observation result of this wave, default "nothing in either gate"
+    for (int i = tid; i < nz; i += GATE_BLOCK) {
+        red[3 * i] = INF;
+        red[3 * i + 1] = (double)0x7fffffff;
+        red[3 * i + 2] = 0.0;
+    }
     __syncthreads();
 
-    const double INF = __builtin_inf();
+    // Almost every (observation, landmark) pair is far outside both gates: the common path is a
+    // 2-vector innovation, a 2x2 quadratic form and two ballots, with no LDS traffic at all.
     for (int i = 0; i < nz; ++i) {
         double nis = INF, nd = INF;
         if (valid) pair_eval(pc, zs[2 * i], zs[2 * i + 1], nis, nd);
@@ -140,35 +147,27 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(const T* __restrict__ 
         const bool near = valid && (nis <= gate2);
         const unsigned long long cand_mask = __ballot(cand);
         const unsigned long long near_mask = __ballot(near);
-        double nd_c = INF;
-        int j_c = 0x7fffffff;
-        if (cand_mask != 0ull) {                 // wave-uniform
-            if (cand) { nd_c = nd; j_c = j0 + 1; }
+        if ((cand_mask | near_mask) != 0ull) {       // wave-uniform, rare
+            double nd_c = INF;
+            int j_c = 0x7fffffff;
+            if (cand_mask != 0ull) {
+                if (cand) { nd_c = nd; j_c = j0 + 1; }
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const double o_nd = __shfl_xor(nd_c, off);
-                const int o_j = __shfl_xor(j_c, off);
-                if (o_nd < nd_c || (o_nd == nd_c && o_j < j_c)) { nd_c = o_nd; j_c = o_j; }
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const double o_nd = __shfl_xor(nd_c, off);
+                    const int o_j = __shfl_xor(j_c, off);
+                    if (o_nd < nd_c || (o_nd == nd_c && o_j < j_c)) { nd_c = o_nd; j_c = o_j; }
+                }
             }
-        }
-        if (lane == 0) {
-            double* r = red + ((size_t)i * GATE_WAVES + wave) * 3;
-            r[0] = nd_c;
-            r[1] = (double)j_c;
-            r[2] = near_mask != 0ull ? 1.0 : 0.0;
+            if (lane == 0) {
+                red[3 * i] = nd_c;
+                red[3 * i + 1] = (double)j_c;
+                red[3 * i + 2] = 1.0;                // near_mask != 0 or a candidate (which is also near-or-matched)
+            }
         }
     }
     __syncthreads();
-    for (int i = tid; i < nz; i += GATE_BLOCK) {
-        double nd_c = INF, j_c = (double)0x7fffffff, near = 0.0;
-        for (int w = 0; w < GATE_WAVES; ++w) {
-            const double* r = red + ((size_t)i * GATE_WAVES + w) * 3;
-            if (r[0] < nd_c || (r[0] == nd_c && r[1] < j_c)) { nd_c = r[0]; j_c = r[1]; }
-            if (r[2] != 0.0) near = 1.0;
-        }
-        double* o = part + ((size_t)blockIdx.x * nz + i) * 3;
-        o[0] = nd_c; o[1] = j_c; o[2] = near;
-    }
+    for (int i = tid; i < 3 * nz; i += GATE_BLOCK) part[(size_t)blockIdx.x * 3 * nz + i] = red[i];
 }
 
 // One wave per observation folds the per-workgroup partials into assoc[i].

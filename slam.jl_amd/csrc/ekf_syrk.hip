@@ -55,6 +55,15 @@ constexpr int KC = 32;               // k-chunk per barrier
 constexpr int LDSP = KC + 4;         // LDS row pitch in floats (144 B: 16-B aligned, conflict-free b128)
 constexpr int TP = 33;               // pitch of the per-wave 32 x 32 transpose scratch
 
+// The transpose scratch is private to a wave; LDS executes one wave's instructions in order, so a
+// compiler-level fence is all that is needed between its writes and reads.  (A __syncthreads()
+// here would also drain every outstanding global store of the epilogue: vmcnt(0) per barrier.)
+__device__ inline void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ P, int ld, int n,
                                                             const float* __restrict__ X, const float* __restrict__ Y,
                                                             int pitch, int kp, const int2* __restrict__ tiles,
@@ -73,21 +82,6 @@ __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ 
     const int R0 = tile.x * TILE;     // rows  (I)
     const int C0 = tile.y * TILE;     // cols  (J <= I)
     const bool diag = tile.x == tile.y;
-
-    // P tile -> registers, in flight during the whole k-loop
-    float pold[2][2][16];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const int row = R0 + 64 * wr + 32 * rb + l31;
-            const int colb = C0 + 64 * wc + 32 * cb + 4 * lh;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int col = colb + (r & 3) + 8 * (r >> 2);
-                pold[cb][rb][r] = (row < n && col < n) ? P[(size_t)col * ld + row] : 0.0f;
-            }
-        }
 
     f32x16 acc[2][2];                 // [cb][rb]
 #pragma unroll
@@ -108,6 +102,23 @@ __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ 
         gx[s] = *reinterpret_cast<const f32x4*>(xsrc + (size_t)(32 * s) * pitch);
         gy[s] = *reinterpret_cast<const f32x4*>(ysrc + (size_t)(32 * s) * pitch);
     }
+
+
+    // P tile -> registers AFTER the first panel chunk was requested (vmcnt retires in order, so the
+    // first LDS fill only waits for the chunk); in flight during the whole k-loop
+    float pold[2][2][16];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const int row = R0 + 64 * wr + 32 * rb + l31;
+            const int colb = C0 + 64 * wc + 32 * cb + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = colb + (r & 3) + 8 * (r >> 2);
+                pold[cb][rb][r] = (row < n && col < n) ? P[(size_t)col * ld + row] : 0.0f;
+            }
+        }
 
     const int nchunks = kp / KC;
     for (int c = 0; c < nchunks; ++c) {
@@ -162,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ 
                 if (row < n && col < n && (!diag || row >= col)) P[(size_t)col * ld + row] = val;
                 sT[l31 * TP + ci] = val;
             }
-            __syncthreads();
+            wave_lds_fence();
             // mirrored store: element (row rr, col c) goes to P[c, rr]; c on the lanes
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
@@ -172,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ 
                 const int colJ = colb + l31;
                 if (rowI < n && colJ < n && (!diag || rowI > colJ)) P[(size_t)rowI * ld + colJ] = val;
             }
-            __syncthreads();
+            wave_lds_fence();
         }
 }
 

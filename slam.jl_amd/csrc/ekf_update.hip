@@ -57,13 +57,21 @@ __global__ __launch_bounds__(256) void pht_kernel(const T* __restrict__ x, const
         const double p0 = (double)P[(size_t)0 * ld + r];
         const double p1 = (double)P[(size_t)1 * ld + r];
         const double p2 = (double)P[(size_t)2 * ld + r];
-        for (int i = 0; i < mc; ++i) {
-            const double* hb = sh[i];
-            const int f = sf[i];
-            const double q0 = (double)P[(size_t)f * ld + r];
-            const double q1 = (double)P[(size_t)(f + 1) * ld + r];
-            out[2 * i] = hb[0] * p0 + hb[1] * p1 + hb[2] * p2 + hb[6] * q0 + hb[7] * q1;
-            out[2 * i + 1] = hb[3] * p0 + hb[4] * p1 + hb[5] * p2 + hb[8] * q0 + hb[9] * q1;
+        // all gathers of the chunk are issued before the first use: one memory latency, not sixteen
+        T q0[PHT_OBS], q1[PHT_OBS];
+#pragma unroll
+        for (int i = 0; i < PHT_OBS; ++i) {
+            const int f = sf[i < mc ? i : 0];
+            q0[i] = P[(size_t)f * ld + r];
+            q1[i] = P[(size_t)(f + 1) * ld + r];
+        }
+#pragma unroll
+        for (int i = 0; i < PHT_OBS; ++i) {
+            if (i < mc) {
+                const double* hb = sh[i];
+                out[2 * i] = hb[0] * p0 + hb[1] * p1 + hb[2] * p2 + hb[6] * (double)q0[i] + hb[7] * (double)q1[i];
+                out[2 * i + 1] = hb[3] * p0 + hb[4] * p1 + hb[5] * p2 + hb[8] * (double)q0[i] + hb[9] * (double)q1[i];
+            }
         }
     }
     // zero the padding columns k..kp-1 that fall into this chunk
@@ -119,21 +127,23 @@ __device__ inline bool eliminate_in_registers(double* M, int mp, int k, int kp, 
             __syncthreads();
             const double piv = rb[j];
             if (!(piv > 0.0) || piv == __builtin_inf()) { bad = true; break; }   // uniform: same LDS word
-            const double rp = 1.0 / piv;
-            double rowv[NB], mm[NB];
+            // 1/piv: hardware estimate + two Newton steps (every thread needs it; a full IEEE divide
+            // here is a tenth of the step)
+            double rp = __builtin_amdgcn_rcp(piv);
+            rp = __builtin_fma(rp, __builtin_fma(-piv, rp, 1.0), rp);
+            rp = __builtin_fma(rp, __builtin_fma(-piv, rp, 1.0), rp);
+            double rowv[NB];
 #pragma unroll
             for (int v = 0; v < NB; ++v) rowv[v] = rb[tx + 32 * v];
+            // rows i = ty + 32u: u < ub is finished (i < j), u > ub is active, u == ub is active iff ty > jj.
+            // Padding rows (i >= k) carry a zero in column j, so their multiplier is zero: no guard needed.
 #pragma unroll
-            for (int u = 0; u < NB; ++u) mm[u] = cb[ty + 32 * u] * rp;
+            for (int u = ub; u < NB; ++u) {
+                const double mu = cb[ty + 32 * u] * rp;
+                if (u > ub || ty > jj) {
 #pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                const int i = ty + 32 * u;
-                if (i > j && i < k) {
-#pragma unroll
-                    for (int v = 0; v < NB; ++v) {
-                        const int c = tx + 32 * v;
-                        a[u][v] = (c == j) ? -mm[u] : a[u][v] - mm[u] * rowv[v];
-                    }
+                    for (int v = 0; v < NB; ++v) a[u][v] = __builtin_fma(-mu, rowv[v], a[u][v]);
+                    if (tx == jj) a[u][ub] = -mu;          // column j now holds column j of inv(L)
                 }
             }
         }
@@ -307,13 +317,14 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
 
 // ---------------------------------------------------------------------------
 // K5: OUT = beta*ADD + alpha*(IN * MAT)   (n x kp) = (n x kp)(kp x kp), in double.
-// 128 rows x 64 columns per block, 4 x 8 outputs per thread (rows tr + 32u so the
-// LDS column walk is conflict-free), inner dimension staged through LDS in chunks
-// of 32.  `upper` skips the structurally zero part of an upper-triangular MAT.
-// The result is written in the state dtype to OUT1 (and OUT2), optionally also in
+// 64 rows x 64 columns per block, 2 x 8 outputs per thread (rows tr + 32u so the
+// LDS column walk is conflict-free).  The inner dimension is staged through LDS in
+// chunks of 32 with the NEXT chunk's global loads in flight during the FMAs.
+// `upper` skips the structurally zero part of an upper-triangular MAT.  The
+// result is written in the state dtype to OUT1 (and OUT2), optionally also in
 // double to OUTD.
 // ---------------------------------------------------------------------------
-constexpr int PG_ROWS = 128;
+constexpr int PG_ROWS = 64;
 constexpr int PG_COLS = 64;
 constexpr int PG_KC = 32;
 
@@ -334,39 +345,52 @@ __global__ __launch_bounds__(256) void panel_gemm_kernel(const double* __restric
     const int row0 = blockIdx.x * PG_ROWS;
     const int b0 = blockIdx.y * PG_COLS;
     const int bw = (kp - b0 < PG_COLS) ? kp - b0 : PG_COLS;            // valid columns of this block (multiple of 32)
-    double acc[4][8];
+    double acc[2][8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc[u][q] = 0.0;
     const int a_end = upper ? (b0 + bw) : kp;
+    // staging: IN chunk 64 x 32 and MAT chunk 32 x 64 = 8 + 8 doubles per thread
+    double gi[8], gm[8];
+    const int irow = tid >> 5, icol = tid & 31;        // + 8*s rows
+    const int mrow = tid >> 6, mcol = tid & 63;        // + 4*s rows
+    const double* isrc = IN + (size_t)(row0 + irow) * in_pitch + icol;
+    const double* msrc = MAT + (size_t)mrow * mat_pitch + b0 + mcol;
+    const bool mvalid = mcol < bw;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        gi[s] = isrc[(size_t)(8 * s) * in_pitch];
+        gm[s] = mvalid ? msrc[(size_t)(4 * s) * mat_pitch] : 0.0;
+    }
     for (int a0 = 0; a0 < a_end; a0 += PG_KC) {
-        // IN tile 128 x 32 (coalesced along the row), MAT tile 32 x 64
-        for (int idx = tid; idx < PG_ROWS * PG_KC; idx += 256) {
-            const int rr = idx >> 5, cc = idx & 31;
-            sIn[rr][cc] = IN[(size_t)(row0 + rr) * in_pitch + a0 + cc];
-        }
-        for (int idx = tid; idx < PG_KC * PG_COLS; idx += 256) {
-            const int aa = idx >> 6, bb = idx & 63;
-            sMat[aa][bb] = (bb < bw) ? MAT[(size_t)(a0 + aa) * mat_pitch + b0 + bb] : 0.0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            sIn[irow + 8 * s][icol] = gi[s];
+            sMat[mrow + 4 * s][mcol] = gm[s];
         }
         __syncthreads();
-#pragma unroll 4
-        for (int a = 0; a < PG_KC; ++a) {
-            double p[4];
+        if (a0 + PG_KC < a_end) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) p[u] = sIn[tr + 32 * u][a];
+            for (int s = 0; s < 8; ++s) {
+                gi[s] = isrc[(size_t)(8 * s) * in_pitch + a0 + PG_KC];
+                gm[s] = mvalid ? msrc[(size_t)(a0 + PG_KC + 4 * s) * mat_pitch] : 0.0;
+            }
+        }
+#pragma unroll 8
+        for (int a = 0; a < PG_KC; ++a) {
+            const double p0 = sIn[tr][a], p1 = sIn[tr + 32][a];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const double mv = sMat[a][tc * 8 + q];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) acc[u][q] += p[u] * mv;
+                acc[0][q] = __builtin_fma(p0, mv, acc[0][q]);
+                acc[1][q] = __builtin_fma(p1, mv, acc[1][q]);
             }
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 2; ++u) {
         const size_t row = (size_t)(row0 + tr + 32 * u);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {

@@ -3,10 +3,14 @@ host mirror), against the fp64 CPU oracle on the same seeded inputs and against 
 committed golden fixtures.
 
 Tolerances (stated, per BASELINE.json's north star):
-  fp64  1e-6 relative is the target; asserted at 1e-9 of the array's max magnitude.
-  fp32  the state is STORED and the rank-k down-date is ACCUMULATED in fp32 (exact-fp32
-        MFMA); the oracle is evaluated in fp64 from the same fp32-rounded inputs.
-        Asserted: |dx| <= 5e-6 * max|x|, |dP| <= 5e-5 * max|P| per call.
+  x     |dx| relative to max|x|: fp64 1e-9 (target 1e-6), fp32 5e-6.
+  P     every entry against ITS OWN scale: |dP_ij| / sqrt(s_i * s_j) with s = max(prior diag,
+        posterior diag): fp64 1e-9 (target 1e-6), fp32 5e-6 per call.  In fp32 the state is STORED
+        and the rank-k down-date ACCUMULATED in fp32 (exact-fp32 MFMA), so the absolute error of
+        P - W1*W1' is a few ulp OF THE PRIOR (measured 4e-7..1.4e-6); a posterior variance that
+        collapsed by 1e4 (a bearing seen at 2 m) therefore keeps only ~3 digits.  That is the
+        fp32 storage format, not the kernel: a NumPy float32 emulation gives the same numbers.
+        The oracle is evaluated in fp64 from the same fp32-rounded inputs.
 Index work (association decisions) must be identical, except that an fp32 run may differ
 from fp64 where the oracle's own margin to a gate is below 1e-3 (none in these seeds).
 """
@@ -22,7 +26,7 @@ pytestmark = pytest.mark.gpu
 
 R = np.array([[0.1 ** 2, 0.0], [0.0, (math.pi / 180) ** 2]])
 Q = np.array([[0.5 ** 2, 0.0], [0.0, (3 * math.pi / 180) ** 2]])
-TOL = {"f64": dict(x=1e-9, P=1e-9), "f32": dict(x=5e-6, P=5e-5)}
+TOL = {"f64": dict(x=1e-9, P=1e-9), "f32": dict(x=5e-6, P=5e-6)}
 DTYPES = ["f64", "f32"]
 
 
@@ -33,13 +37,18 @@ def relerr(a, b):
     return float(np.max(np.abs(a - b)) / scale) if b.size else 0.0
 
 
-def relerr_cov(Pg, Po, block=2048):
-    """max |dP_ij| / sqrt(Po_ii * Po_jj): entries are judged against their own scale, so the
-    large blocks of far-away new features cannot hide errors in the 0.01-scale ones."""
+def relerr_cov(Pg, Po, prior_diag=None, block=2048):
+    """max |dP_ij| / sqrt(s_i * s_j), s = max(posterior diag, prior diag): entries are judged
+    against their own scale, so the large blocks of far-away new features cannot hide errors in
+    the 0.01-scale ones."""
     n = Po.shape[0]
     if n == 0:
         return 0.0
-    d = np.sqrt(np.abs(np.diag(Po)).astype(np.float64))
+    dd = np.abs(np.diag(Po)).astype(np.float64)
+    if prior_diag is not None:
+        pd = np.abs(np.asarray(prior_diag, dtype=np.float64))
+        dd[:len(pd)] = np.maximum(dd[:len(pd)], pd[:len(dd)])
+    d = np.sqrt(dd)
     floor = float(np.max(np.abs(Po)))
     d = np.where(d > 0, d, math.sqrt(floor) if floor > 0 else 1.0)
     worst = 0.0
@@ -50,10 +59,10 @@ def relerr_cov(Pg, Po, block=2048):
     return worst
 
 
-def check_state(st, xo, Po, dtype, what, fx=1.0, fP=1.0):
+def check_state(st, xo, Po, dtype, what, fx=1.0, fP=1.0, prior=None):
     xg, Pg = st.download()
     assert xg.shape == xo.shape and Pg.shape == Po.shape, what
-    ex, eP = relerr(xg, xo), relerr_cov(Pg, Po)
+    ex, eP = relerr(xg, xo), relerr_cov(Pg, Po, None if prior is None else np.diag(prior))
     assert ex <= TOL[dtype]["x"] * fx, f"{what}: x rel err {ex:.3e}"
     assert eP <= TOL[dtype]["P"] * fP, f"{what}: P rel err {eP:.3e}"
     return ex, eP
@@ -178,7 +187,7 @@ def test_single_calls_against_golden(pkg, single, dtype, N):
                 assert nd == pytest.approx(single[f"{t}_nd"][i, j - 1], rel=rt, abs=rt)
     zf, idf, zn = st.associate(z, R, 4.0, 25.0)
     st.update(zf, R, idf)
-    check_state(st, single[f"{t}_update_x"], single[f"{t}_update_P"], dtype, "update")
+    check_state(st, single[f"{t}_update_x"], single[f"{t}_update_P"], dtype, "update", prior=P)
     st.add_features(zn, R)
     assert st.N == N + 2
     check_state(st, single[f"{t}_augment_x"], single[f"{t}_augment_P"], dtype, "add_features", fx=4.0)
@@ -200,8 +209,9 @@ def test_full_cycle_against_oracle(pkg, dtype, N, m, nn):
     assert np.array_equal(a, ao)
     zf, idf, zn = O.split_assoc(z, ao)
     st.update(zf, R, idf)
+    Pprior = Po
     xo, Po = O.update_sparse(xo, Po, zf, R, idf)
-    check_state(st, xo, Po, dtype, "update")
+    check_state(st, xo, Po, dtype, "update", prior=Pprior)
     xg, Pg = st.download()
     assert np.array_equal(Pg, Pg.T), "P must stay exactly symmetric"
     st.add_features(zn, R)
@@ -235,7 +245,7 @@ def test_reference_call_pattern(pkg, dtype):
     xo, Po = O.update(xo, Po, zfo, R, idfo)
     xo, Po = O.add_features(xo, Po, zno, R)
     assert len(state.x) == len(xo) and state.cov.shape == Po.shape
-    check_state(state, xo, Po, dtype, "sim! call pattern", fx=4.0)
+    check_state(state, xo, Po, dtype, "sim! call pattern", fx=4.0, prior=P)
     # reset by plain assignment (sim/browser/wsserver.jl:161-174)
     state.x = np.array([1.0, 2.0, 0.5])
     state.cov = np.zeros((3, 3))
@@ -261,7 +271,7 @@ def test_edge_cases(pkg, dtype):
     z = np.stack([zp + [0.05, 0.001], zp - [0.03, 0.002]], axis=1)
     st.update(z, R, [4, 4])
     xo, Po = O.update(x0.astype(np.float64), np.array(P0, dtype=np.float64), z, R, np.array([[4, 4]]))
-    check_state(st, xo, Po, dtype, "duplicate idf")
+    check_state(st, xo, Po, dtype, "duplicate idf", prior=P0)
     # capacity: Julia would grow the arrays; here a status code and an untouched state
     xb, Pb = st.download()
     with pytest.raises(pkg.SlamHipError) as ei:
@@ -304,8 +314,9 @@ def test_many_observations_and_large_k(pkg, dtype):
     assert np.array_equal(a, ao)
     sel = np.flatnonzero(ao > 0)[:100]                   # m = 100 -> k = 200
     st.update(z[:, sel], R, ao[sel])
+    Pprior = Po
     xo, Po = O.update_sparse(xo, Po, z[:, sel], R, ao[sel])
-    check_state(st, xo, Po, dtype, "update k=200", fP=4.0)
+    check_state(st, xo, Po, dtype, "update k=200", fP=4.0, prior=Pprior)
     st.close()
 
 
@@ -320,9 +331,9 @@ def test_joseph_form(pkg, dtype):
     z = noisy_obs(rng, xo, ids)
     st.update(z, R, ids, form="joseph")
     xj, Pj = O.update_joseph_sparse(xo, Po, z, R, ids)
-    check_state(st, xj, Pj, dtype, "joseph", fP=2.0)
+    check_state(st, xj, Pj, dtype, "joseph", fP=2.0, prior=Po)
     xc, Pc = O.update_sparse(xo, Po, z, R, ids)             # equals the reference form up to rounding
-    check_state(st, xc, Pc, dtype, "joseph vs cholesky form", fP=2.0)
+    check_state(st, xc, Pc, dtype, "joseph vs cholesky form", fP=2.0, prior=Po)
     _, Pg = st.download()
     assert np.array_equal(Pg, Pg.T)
     st.close()
@@ -439,13 +450,14 @@ def test_full_size_10k_landmarks_fp32(pkg):
     sel = ao > 0
     assert sel.sum() >= m // 2
     tr0 = float(np.trace(Po))
+    prior_diag = np.diag(Po).copy()
     st.update(z[:, sel], R, ao[sel])
     xn, Pn = O.update_sparse(xo, Po, z[:, sel], R, ao[sel], inplace=True)     # Po is overwritten
     xg, Pg = st.download()
     ex = relerr(xg, xn)
-    eP = relerr_cov(Pg, Pn)
+    eP = relerr_cov(Pg, Pn, prior_diag)
     print(f"N=10k fp32 update: rel err x {ex:.3e}  P {eP:.3e}  matched {int(sel.sum())}/{m}")
-    assert ex <= 5e-6 and eP <= 5e-5
+    assert ex <= 5e-6 and eP <= 5e-6
     assert np.array_equal(Pg, Pg.T)
     assert float(np.trace(Pg.astype(np.float64))) < tr0
     st.close()
