@@ -168,6 +168,12 @@ def main():
 
     tim = st.timing_read()
     st.timing(False)
+    # diagnostics (outside the timed region): phase stamps of the factorisation kernel
+    st.debug_stamps(True)
+    step(zs[-1])
+    st.sync()
+    stamps = st.debug_stamps(False)
+    phases = [(b - a) / 100.0 for a, b in zip(stamps[:6], stamps[1:7])]     # 100 MHz ticks -> us
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -217,6 +223,7 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (EKF does not shard)"},
             "roofline": roof,
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in tim.items()},
+            "factor_phases_us": dict(zip(["innovation", "build_S", "symmetrise", "eliminate", "y_g", "emit_C"], phases)),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(x, P, zs, args.cpu_budget)

@@ -139,6 +139,9 @@ int slam_ekf_sync(slam_ekf_t h);
 int slam_ekf_timing(slam_ekf_t h, int enable);
 int slam_ekf_timing_read(slam_ekf_t h, int kid, double* total_ms, int64_t* launches);
 int slam_ekf_timing_reset(slam_ekf_t h);
+/* Diagnostics: when enabled the factorisation kernel records 100 MHz wall-clock stamps at its
+ * phase boundaries; out8 (may be NULL) receives the stamps of the last update. */
+int slam_ekf_debug_stamps(slam_ekf_t h, int enable, uint64_t* out8);
 
 #ifdef __cplusplus
 }

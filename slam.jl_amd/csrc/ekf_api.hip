@@ -214,7 +214,7 @@ extern "C" int slam_ekf_create(slam_ekf_t* out, int dtype, int max_landmarks, in
     h->gate_part = nullptr; h->gate_blocks_cap = 0;
     h->d_small = h->h_small = nullptr;
     h->d_status = h->h_status = nullptr;
-    h->async_updates = 0; h->deferred = 0; h->pending_status = 0;
+    h->async_updates = 0; h->deferred = 0; h->pending_status = 0; h->debug_stamps = 0;
     h->timing = 0;
     for (int i = 0; i < SLAM_K_COUNT; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
     const int rc = create_impl(h);
@@ -446,6 +446,18 @@ extern "C" int slam_ekf_sync(slam_ekf_t h) {
     HIP_TRY(hipSetDevice(h->device));
     if (h->pending_status) return read_status(h, 1);
     HIP_TRY(hipStreamSynchronize(h->stream));
+    return SLAM_OK;
+}
+
+extern "C" int slam_ekf_debug_stamps(slam_ekf_t h, int enable, uint64_t* out8) {
+    ARG_CHECK(h != nullptr, "null handle");
+    h->debug_stamps = enable ? 1 : 0;
+    if (out8) {
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipMemcpyAsync(h->h_small, h->d_small + 40, sizeof(uint64_t) * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        memcpy(out8, h->h_small, sizeof(uint64_t) * 8);
+    }
     return SLAM_OK;
 }
 

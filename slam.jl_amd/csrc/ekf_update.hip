@@ -184,8 +184,13 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
     const T* __restrict__ x, const double* __restrict__ PHt, int pht_pitch, const double* __restrict__ z,
     const int32_t* __restrict__ idf, int m, int k, int kp, double R0, double R1, double R2, double R3,
     double* __restrict__ Cout, int c_pitch, double* __restrict__ gvec, double* __restrict__ Sout, int want_sinv,
-    double* __restrict__ Mglobal, int32_t* __restrict__ status) {
+    double* __restrict__ Mglobal, int32_t* __restrict__ status, unsigned long long* __restrict__ stamps) {
+#define STAMP(i)                                                  \
+    do {                                                          \
+        if (stamps && threadIdx.x == 0) stamps[i] = wall_clock64(); \
+    } while (0)
     extern __shared__ double lds[];
+    STAMP(0);
     const int tid = threadIdx.x;
     const int nt = blockDim.x;
     const int mp = kp + 1;                                   // odd pitch: conflict-free column walks
@@ -213,8 +218,46 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
     }
     for (int a = k + tid; a < kp; a += nt) vvec[a] = 0.0;
     __syncthreads();
+    STAMP(1);
 
     // S = H*PHt + RR (ekf.jl:68); rows/cols >= k are padded with the identity
+    if (!Mglobal) {
+        // kp <= 128: thread (grp, b) owns column b and the observations grp, grp+G, ... (at most 8);
+        // its <= 19 loads of PHt are all issued before the first use.
+        const int G = nt / kp;
+        const int b = tid % kp, grp = tid / kp;
+        for (int idx = tid; idx < kp * kp; idx += nt) {                 // identity padding first
+            const int a = idx / kp, bb = idx - a * kp;
+            if (a >= k || bb >= k) M[(size_t)a * mp + bb] = (a == bb) ? 1.0 : 0.0;
+        }
+        if (grp < G && b < k) {
+            const double p0 = PHt[(size_t)0 * pht_pitch + b];
+            const double p1 = PHt[(size_t)1 * pht_pitch + b];
+            const double p2 = PHt[(size_t)2 * pht_pitch + b];
+            double q0[8], q1[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int i = grp + t * G;
+                const int f = sf[i < m ? i : 0];
+                q0[t] = PHt[(size_t)f * pht_pitch + b];
+                q1[t] = PHt[(size_t)(f + 1) * pht_pitch + b];
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int i = grp + t * G;
+                if (i < m) {
+                    const double* h = hb + 10 * i;
+#pragma unroll
+                    for (int ra = 0; ra < 2; ++ra) {
+                        double sv = h[3 * ra + 0] * p0 + h[3 * ra + 1] * p1 + h[3 * ra + 2] * p2 + h[6 + 2 * ra + 0] * q0[t] +
+                                    h[6 + 2 * ra + 1] * q1[t];
+                        if ((b >> 1) == i) sv += ra ? ((b & 1) ? R3 : R1) : ((b & 1) ? R2 : R0);   // RR block = R
+                        M[(size_t)(2 * i + ra) * mp + b] = sv;
+                    }
+                }
+            }
+        }
+    } else
     for (int idx = tid; idx < kp * kp; idx += nt) {
         const int a = idx / kp, b = idx - a * kp;
         double s;
@@ -232,6 +275,7 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
         M[(size_t)a * mp + b] = s;
     }
     __syncthreads();
+    STAMP(2);
     // S = (S + S')*0.5 (ekf.jl:69)
     for (int idx = tid; idx < k * k; idx += nt) {
         const int a = idx / k, b = idx - a * k;
@@ -250,6 +294,7 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
     }
     __syncthreads();
 
+    STAMP(3);
     bool ok;
     if (Mglobal) ok = eliminate_in_memory(M, mp, k, mvec);
     else if (kp == 32) ok = eliminate_in_registers<1>(M, mp, k, kp, rowbuf, colbuf);
@@ -260,6 +305,7 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
         if (tid == 0) { status[0] = 1; status[1] = 1; }    // [1] is sticky until slam_ekf_sync reads it
         return;
     }
+    STAMP(4);
     // mvec <- 1/sqrt(D)
     for (int b = tid; b < kp; b += nt) mvec[b] = (b < k) ? 1.0 / sqrt(M[(size_t)b * mp + b]) : 0.0;
     __syncthreads();
@@ -286,6 +332,7 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
         s += __shfl_xor(s, 4);
         if (part == 0 && a < kp) gvec[a] = (a < k) ? s + yvec[a] * mvec[a] : 0.0;
     }
+    STAMP(5);
     if (!want_sinv) {
         // C[a][b] = Linv[b][a]/sqrt(D_b) (a<b), 1/sqrt(D_b) (a==b), 0 below and in the padding
         for (int idx = tid; idx < kp * kp; idx += nt) {
@@ -313,6 +360,8 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
             Cout[(size_t)a * c_pitch + b] = s;
         }
     }
+    STAMP(6);
+#undef STAMP
 }
 
 // ---------------------------------------------------------------------------
@@ -451,7 +500,7 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form) {
         hipLaunchKernelGGL(factor_kernel<T>, dim3(1), dim3(FACTOR_THREADS), shm, h->stream, x, h->PHt, pitchA, h->obsbuf,
                            h->idfbuf, m, k, kp, R[0], R[1], R[2], R[3], h->Cmat, pitchA, h->gvec,
                            joseph ? h->Smat : (double*)nullptr, joseph ? 1 : 0, in_lds ? (double*)nullptr : h->Mwork,
-                           h->d_status);
+                           h->d_status, h->debug_stamps ? (unsigned long long*)(h->d_small + 40) : (unsigned long long*)nullptr);
     }
     HIP_TRY(hipGetLastError());
     const dim3 pg_grid(h->npad / PG_ROWS, (kp + PG_COLS - 1) / PG_COLS);

@@ -311,6 +311,12 @@ class EKFSlamState(SlamState):
     def timing(self, enable=True):
         check(lib.slam_ekf_timing(self._h, 1 if enable else 0))
 
+    def debug_stamps(self, enable=True):
+        """Diagnostics: 100 MHz wall-clock stamps of the factorisation kernel's phases (last update)."""
+        out = (C.c_uint64 * 8)()
+        check(lib.slam_ekf_debug_stamps(self._h, 1 if enable else 0, out))
+        return [int(v) for v in out]
+
     def timing_reset(self):
         check(lib.slam_ekf_timing_reset(self._h))
 
