@@ -52,11 +52,11 @@ struct slam_ekf {
     int maxN;         // landmark capacity
     int N;            // landmarks in the map
     int ncap;         // 3 + 2*maxN
-    int ld;           // leading dimension of P (elements), multiple of 64
+    int ld;           // leading dimension of P (elements) = npad
     int npad;         // rows of the panel buffers, multiple of SLAM_TILE
     size_t esz;       // element size
     void* x;          // [ncap]
-    void* P;          // [ld * ncap] column-major
+    void* P;          // [ld * npad] column-major, whole 128 x 128 tiles; rows/cols >= n are zero padding
     hipStream_t stream;
     hipEvent_t stage_ev;   // marks the last H2D copy out of the pinned staging buffers
     int stage_pending;

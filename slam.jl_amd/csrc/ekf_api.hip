@@ -172,7 +172,7 @@ static int create_impl(slam_ekf* h) {
     int rc;
     if ((rc = update_kernels_init())) return rc;
     if ((rc = dev_alloc_zero(&h->x, h->esz * (size_t)h->ncap, h->stream))) return rc;
-    if ((rc = dev_alloc_zero(&h->P, h->esz * (size_t)h->ld * h->ncap, h->stream))) return rc;
+    if ((rc = dev_alloc_zero(&h->P, h->esz * (size_t)h->ld * h->npad, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->d_small, sizeof(double) * 64, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->d_status, sizeof(int32_t) * 4, h->stream))) return rc;
     HIP_TRY(hipHostMalloc((void**)&h->h_small, sizeof(double) * 64, hipHostMallocDefault));
@@ -199,8 +199,8 @@ extern "C" int slam_ekf_create(slam_ekf_t* out, int dtype, int max_landmarks, in
     h->maxN = max_landmarks;
     h->N = 0;
     h->ncap = 3 + 2 * max_landmarks;
-    h->ld = round_up(h->ncap, 64);
     h->npad = round_up(h->ncap, SLAM_TILE);
+    h->ld = h->npad;                  // P is allocated in whole tiles: npad x npad, padding stays zero
     h->esz = dtype == SLAM_F32 ? 4 : 8;
     h->x = h->P = nullptr;
     h->stream = nullptr;

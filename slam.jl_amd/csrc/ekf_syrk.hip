@@ -64,6 +64,111 @@ __device__ inline void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// P tile <-> registers.
+//
+// Off-diagonal tiles need no masks at all (P is allocated in whole 128 x 128 tiles: rows/columns
+// >= n are padding that stays zero because the panels are zero there), and every address is
+// "wave-uniform column offset + per-lane row offset".  They go through buffer loads/stores whose
+// column offset rides in an SGPR (soffset): no per-element 64-bit VALU address arithmetic, no
+// branches.  A buffer descriptor covers one 128-column band of P (128*ld*4 bytes < 4 GiB).
+// Diagonal tiles (1 in 80 at N = 10k) take the masked path: lower triangle stored directly,
+// upper triangle from the mirror.
+typedef __attribute__((__vector_size__(4 * sizeof(int)))) int rsrc_t;
+
+__device__ inline auto band_rsrc(const float* band, int ld) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(band), (short)0, TILE * ld * 4, 0x00020000);
+}
+
+__device__ inline void load_p_tile_fast(const float* __restrict__ P, int ld, int R0, int C0, int wr, int wc, int l31,
+                                        int lh, float (&pold)[2][2][16]) {
+    const auto rs = band_rsrc(P + (size_t)C0 * ld, ld);
+    const int voff = (l31 + lh * 4 * ld) * 4;                 // bytes: row on the lane, upper half-wave 4 columns on
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci0 = (r & 3) + 8 * (r >> 2);
+                const int soff = ((64 * wc + 32 * cb + ci0) * ld + R0 + 64 * wr + 32 * rb) * 4;
+                pold[cb][rb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+            }
+}
+
+__device__ inline void store_p_tile_fast(float* __restrict__ P, int ld, int R0, int C0, int wr, int wc, int l31, int lh,
+                                         const float (&pold)[2][2][16], const f32x16 (&acc)[2][2], float* sT) {
+    const auto rs = band_rsrc(P + (size_t)C0 * ld, ld);       // direct:   columns C0.., rows R0..
+    const auto rsm = band_rsrc(P + (size_t)R0 * ld, ld);      // mirrored: columns R0.., rows C0..
+    const int voff = (l31 + lh * 4 * ld) * 4;
+    const int voff_m = (l31 + lh * ld) * 4;                   // columns on lanes, upper half-wave 1 row on
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci0 = (r & 3) + 8 * (r >> 2);
+                const float val = pold[cb][rb][r] - acc[cb][rb][r];
+                const int soff = ((64 * wc + 32 * cb + ci0) * ld + R0 + 64 * wr + 32 * rb) * 4;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rs, voff, soff, 0);
+                sT[l31 * TP + 4 * lh + ci0] = val;
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float val = sT[(2 * s + lh) * TP + l31];
+                const int soff = ((64 * wr + 32 * rb + 2 * s) * ld + C0 + 64 * wc + 32 * cb) * 4;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rsm, voff_m, soff, 0);
+            }
+            wave_lds_fence();
+        }
+}
+
+__device__ inline void load_p_tile_masked(const float* __restrict__ P, int ld, int n, int R0, int C0, int wr, int wc,
+                                          int l31, int lh, float (&pold)[2][2][16]) {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const int row = R0 + 64 * wr + 32 * rb + l31;
+            const int colb = C0 + 64 * wc + 32 * cb + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = colb + (r & 3) + 8 * (r >> 2);
+                pold[cb][rb][r] = (row < n && col < n) ? P[(size_t)col * ld + row] : 0.0f;
+            }
+        }
+}
+
+__device__ inline void store_p_tile_masked(float* __restrict__ P, int ld, int n, int R0, int C0, int wr, int wc, int l31,
+                                           int lh, const float (&pold)[2][2][16], const f32x16 (&acc)[2][2], float* sT) {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const int rowb = R0 + 64 * wr + 32 * rb;
+            const int colb = C0 + 64 * wc + 32 * cb;
+            const int row = rowb + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = 4 * lh + (r & 3) + 8 * (r >> 2);
+                const int col = colb + ci;
+                const float val = pold[cb][rb][r] - acc[cb][rb][r];
+                if (row < n && col < n && row >= col) P[(size_t)col * ld + row] = val;
+                sT[l31 * TP + ci] = val;
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int rr = 2 * s + lh;
+                const float val = sT[rr * TP + l31];
+                const int rowI = rowb + rr, colJ = colb + l31;
+                if (rowI < n && colJ < n && rowI > colJ) P[(size_t)rowI * ld + colJ] = val;
+            }
+            wave_lds_fence();
+        }
+}
+
 __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ P, int ld, int n,
                                                             const float* __restrict__ X, const float* __restrict__ Y,
                                                             int pitch, int kp, const int2* __restrict__ tiles,
@@ -74,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ 
     __shared__ __attribute__((aligned(16))) float smem[2][2][TILE][LDSP];   // [buffer][X|Y][row][k]  73,728 B
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // provably wave-uniform
     const int wr = wave & 1;          // row half of the tile
     const int wc = wave >> 1;         // column half
     const int l31 = lane & 31;
@@ -103,24 +208,13 @@ __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ 
         gy[s] = *reinterpret_cast<const f32x4*>(ysrc + (size_t)(32 * s) * pitch);
     }
 
-
     // P tile -> registers AFTER the first panel chunk was requested (vmcnt retires in order, so the
     // first LDS fill only waits for the chunk); in flight during the whole k-loop
     float pold[2][2][16];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const int row = R0 + 64 * wr + 32 * rb + l31;
-            const int colb = C0 + 64 * wc + 32 * cb + 4 * lh;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int col = colb + (r & 3) + 8 * (r >> 2);
-                pold[cb][rb][r] = (row < n && col < n) ? P[(size_t)col * ld + row] : 0.0f;
-            }
-        }
+    if (diag) load_p_tile_masked(P, ld, n, R0, C0, wr, wc, l31, lh, pold);
+    else load_p_tile_fast(P, ld, R0, C0, wr, wc, l31, lh, pold);
 
-    const int nchunks = kp / KC;
+    const int nchunks = (kp + KC - 1) / KC;                   // kp is a multiple of 16: the last chunk may be half
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
 #pragma unroll
@@ -136,55 +230,31 @@ __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ 
                 gy[s] = *reinterpret_cast<const f32x4*>(ysrc + (size_t)(32 * s) * pitch + (c + 1) * KC);
             }
         }
+        const int kend = (kp - c * KC < KC) ? kp - c * KC : KC;
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 8) {
-            f32x4 a[2], b[2];
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-                a[cb] = *reinterpret_cast<const f32x4*>(&smem[buf][1][64 * wc + 32 * cb + l31][kk + 4 * lh]);
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-                b[rb] = *reinterpret_cast<const f32x4*>(&smem[buf][0][64 * wr + 32 * rb + l31][kk + 4 * lh]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
+            if (kk < kend) {
+                f32x4 a[2], b[2];
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
+                    a[cb] = *reinterpret_cast<const f32x4*>(&smem[buf][1][64 * wc + 32 * cb + l31][kk + 4 * lh]);
 #pragma unroll
-                    for (int rb = 0; rb < 2; ++rb)
-                        acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cb][t], b[rb][t], acc[cb][rb], 0, 0, 0);
+                for (int rb = 0; rb < 2; ++rb)
+                    b[rb] = *reinterpret_cast<const f32x4*>(&smem[buf][0][64 * wr + 32 * rb + l31][kk + 4 * lh]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb)
+                            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cb][t], b[rb][t], acc[cb][rb], 0, 0, 0);
+            }
         }
     }
     __syncthreads();                  // every wave is done with the panels: reuse LDS as transpose scratch
     float* sT = &smem[0][0][0][0] + wave * (32 * TP);
-
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const int rowb = R0 + 64 * wr + 32 * rb;
-            const int colb = C0 + 64 * wc + 32 * cb;
-            const int row = rowb + l31;
-            // direct store: rows on the lanes, 32 consecutive rows of one column per half-wave
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ci = 4 * lh + (r & 3) + 8 * (r >> 2);
-                const int col = colb + ci;
-                const float val = pold[cb][rb][r] - acc[cb][rb][r];
-                if (row < n && col < n && (!diag || row >= col)) P[(size_t)col * ld + row] = val;
-                sT[l31 * TP + ci] = val;
-            }
-            wave_lds_fence();
-            // mirrored store: element (row rr, col c) goes to P[c, rr]; c on the lanes
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int rr = 2 * s + lh;
-                const float val = sT[rr * TP + l31];
-                const int rowI = rowb + rr;
-                const int colJ = colb + l31;
-                if (rowI < n && colJ < n && (!diag || rowI > colJ)) P[(size_t)rowI * ld + colJ] = val;
-            }
-            wave_lds_fence();
-        }
+    if (diag) store_p_tile_masked(P, ld, n, R0, C0, wr, wc, l31, lh, pold, acc, sT);
+    else store_p_tile_fast(P, ld, R0, C0, wr, wc, l31, lh, pold, acc, sT);
 }
 
 // ---- fp64 VALU down-date -----------------------------------------------------

@@ -90,69 +90,82 @@ __global__ __launch_bounds__(256) void pht_kernel(const T* __restrict__ x, const
 // which is the reference's inv(chol(S)) (unique: upper, positive diagonal,
 // C*C' = inv(S)).
 //
-// For kp <= 128 the matrix lives in REGISTERS during the elimination: the 1024
-// threads form a 32 x 32 grid and thread (ty, tx) owns the elements
-// (ty + 32u, tx + 32v) -- a cyclic distribution, so every thread stays busy as the
+// For kp <= 128 the matrix lives in REGISTERS during the elimination: 256
+// threads form a 16 x 16 grid and thread (ty, tx) owns the elements
+// (ty + 16u, tx + 16v) -- a cyclic distribution, so every thread stays busy as the
 // active rows shrink.  Per step the owners publish row j and column j through a
 // double-buffered LDS line, one barrier, and everyone updates its registers.
 // Larger k falls back to an elimination in global memory (two barriers per step).
 // ---------------------------------------------------------------------------
-constexpr int FACTOR_THREADS = 1024;
+constexpr int FACTOR_THREADS = 512;      // 8 waves: 256 VGPRs each, so the 4 worker waves can hold 64 doubles
 
-template <int NB>
+template <int NB>      // NB = kp / 16
 __device__ inline bool eliminate_in_registers(double* M, int mp, int k, int kp, double* rowbuf, double* colbuf) {
+    // Four waves (one per SIMD) hold the matrix: thread (ty, tx) of a 16 x 16 grid owns the elements
+    // (ty + 16u, tx + 16v).  More waves only multiply the per-step overhead (the pivot reciprocal, the
+    // LDS reads, the predicates) that every wave pays; the other twelve waves just keep the barriers.
     const int tid = threadIdx.x;
-    const int tx = tid & 31, ty = tid >> 5;
+    const bool worker = tid < 256;
+    const int tx = tid & 15, ty = (tid >> 4) & 15;
     double a[NB][NB];
+    if (worker) {
+        // load with the symmetrisation S = (S + S')*0.5 (ekf.jl:69) folded in
 #pragma unroll
-    for (int u = 0; u < NB; ++u)
+        for (int u = 0; u < NB; ++u)
 #pragma unroll
-        for (int v = 0; v < NB; ++v) a[u][v] = M[(size_t)(ty + 32 * u) * mp + tx + 32 * v];
+            for (int v = 0; v < NB; ++v) {
+                const int i = ty + 16 * u, c = tx + 16 * v;
+                a[u][v] = (M[(size_t)i * mp + c] + M[(size_t)c * mp + i]) * 0.5;
+            }
+    }
     bool bad = false;
 #pragma unroll
     for (int ub = 0; ub < NB; ++ub) {
-        for (int jj = 0; jj < 32; ++jj) {
-            const int j = 32 * ub + jj;
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = 16 * ub + jj;
             if (j >= k || bad) break;                     // uniform
             double* rb = rowbuf + (j & 1) * kp;
             double* cb = colbuf + (j & 1) * kp;
-            if (ty == jj) {
+            if (worker && ty == jj) {
 #pragma unroll
-                for (int v = 0; v < NB; ++v) rb[tx + 32 * v] = a[ub][v];
+                for (int v = 0; v < NB; ++v) rb[tx + 16 * v] = a[ub][v];
             }
-            if (tx == jj) {
+            if (worker && tx == jj) {
 #pragma unroll
-                for (int u = 0; u < NB; ++u) cb[ty + 32 * u] = a[u][ub];
+                for (int u = 0; u < NB; ++u) cb[ty + 16 * u] = a[u][ub];
             }
             __syncthreads();
             const double piv = rb[j];
             if (!(piv > 0.0) || piv == __builtin_inf()) { bad = true; break; }   // uniform: same LDS word
-            // 1/piv: hardware estimate + two Newton steps (every thread needs it; a full IEEE divide
-            // here is a tenth of the step)
-            double rp = __builtin_amdgcn_rcp(piv);
-            rp = __builtin_fma(rp, __builtin_fma(-piv, rp, 1.0), rp);
-            rp = __builtin_fma(rp, __builtin_fma(-piv, rp, 1.0), rp);
-            double rowv[NB];
+            if (worker) {
+                // 1/piv: hardware estimate + two Newton steps
+                double rp = __builtin_amdgcn_rcp(piv);
+                rp = __builtin_fma(rp, __builtin_fma(-piv, rp, 1.0), rp);
+                rp = __builtin_fma(rp, __builtin_fma(-piv, rp, 1.0), rp);
+                double rowv[NB];
 #pragma unroll
-            for (int v = 0; v < NB; ++v) rowv[v] = rb[tx + 32 * v];
-            // rows i = ty + 32u: u < ub is finished (i < j), u > ub is active, u == ub is active iff ty > jj.
-            // Padding rows (i >= k) carry a zero in column j, so their multiplier is zero: no guard needed.
+                for (int v = 0; v < NB; ++v) rowv[v] = rb[tx + 16 * v];
+                // rows i = ty + 16u: u < ub is finished (i < j), u > ub is active, u == ub is active iff ty > jj.
+                // Padding rows (i >= k) carry a zero in column j, so their multiplier is zero: no guard needed.
 #pragma unroll
-            for (int u = ub; u < NB; ++u) {
-                const double mu = cb[ty + 32 * u] * rp;
-                if (u > ub || ty > jj) {
+                for (int u = ub; u < NB; ++u) {
+                    const double mu = cb[ty + 16 * u] * rp;
+                    if (u > ub || ty > jj) {
 #pragma unroll
-                    for (int v = 0; v < NB; ++v) a[u][v] = __builtin_fma(-mu, rowv[v], a[u][v]);
-                    if (tx == jj) a[u][ub] = -mu;          // column j now holds column j of inv(L)
+                        for (int v = 0; v < NB; ++v) a[u][v] = __builtin_fma(-mu, rowv[v], a[u][v]);
+                        if (tx == jj) a[u][ub] = -mu;      // column j now holds column j of inv(L)
+                    }
                 }
             }
         }
     }
     __syncthreads();
+    if (worker) {
 #pragma unroll
-    for (int u = 0; u < NB; ++u)
+        for (int u = 0; u < NB; ++u)
 #pragma unroll
-        for (int v = 0; v < NB; ++v) M[(size_t)(ty + 32 * u) * mp + tx + 32 * v] = a[u][v];
+            for (int v = 0; v < NB; ++v) M[(size_t)(ty + 16 * u) * mp + tx + 16 * v] = a[u][v];
+    }
     __syncthreads();
     return !bad;
 }
@@ -222,8 +235,8 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
 
     // S = H*PHt + RR (ekf.jl:68); rows/cols >= k are padded with the identity
     if (!Mglobal) {
-        // kp <= 128: thread (grp, b) owns column b and the observations grp, grp+G, ... (at most 8);
-        // its <= 19 loads of PHt are all issued before the first use.
+        // kp <= 128: thread (grp, b) owns column b and the observations grp, grp+G, ... (at most 16);
+        // its <= 35 loads of PHt are all issued before the first use.
         const int G = nt / kp;
         const int b = tid % kp, grp = tid / kp;
         for (int idx = tid; idx < kp * kp; idx += nt) {                 // identity padding first
@@ -234,16 +247,16 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
             const double p0 = PHt[(size_t)0 * pht_pitch + b];
             const double p1 = PHt[(size_t)1 * pht_pitch + b];
             const double p2 = PHt[(size_t)2 * pht_pitch + b];
-            double q0[8], q1[8];
+            double q0[16], q1[16];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
+            for (int t = 0; t < 16; ++t) {
                 const int i = grp + t * G;
                 const int f = sf[i < m ? i : 0];
                 q0[t] = PHt[(size_t)f * pht_pitch + b];
                 q1[t] = PHt[(size_t)(f + 1) * pht_pitch + b];
             }
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
+            for (int t = 0; t < 16; ++t) {
                 const int i = grp + t * G;
                 if (i < m) {
                     const double* h = hb + 10 * i;
@@ -276,31 +289,33 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
     }
     __syncthreads();
     STAMP(2);
-    // S = (S + S')*0.5 (ekf.jl:69)
-    for (int idx = tid; idx < k * k; idx += nt) {
-        const int a = idx / k, b = idx - a * k;
-        if (a < b) {
-            const double s = (M[(size_t)a * mp + b] + M[(size_t)b * mp + a]) * 0.5;
-            M[(size_t)a * mp + b] = s;
-            M[(size_t)b * mp + a] = s;
+    // S = (S + S')*0.5 (ekf.jl:69): folded into the register load of the elimination (LDS path)
+    if (Mglobal) {
+        for (int idx = tid; idx < k * k; idx += nt) {
+            const int a = idx / k, b = idx - a * k;
+            if (a < b) {
+                const double s = (M[(size_t)a * mp + b] + M[(size_t)b * mp + a]) * 0.5;
+                M[(size_t)a * mp + b] = s;
+                M[(size_t)b * mp + a] = s;
+            }
         }
+        __syncthreads();
     }
-    __syncthreads();
     if (Sout) {
         for (int idx = tid; idx < kp * kp; idx += nt) {
             const int a = idx / kp, b = idx - a * kp;
-            Sout[(size_t)a * c_pitch + b] = (a < k && b < k) ? M[(size_t)a * mp + b] : 0.0;
+            Sout[(size_t)a * c_pitch + b] =
+                (a < k && b < k) ? (M[(size_t)a * mp + b] + M[(size_t)b * mp + a]) * 0.5 : 0.0;
         }
+        __syncthreads();
     }
-    __syncthreads();
-
     STAMP(3);
     bool ok;
     if (Mglobal) ok = eliminate_in_memory(M, mp, k, mvec);
-    else if (kp == 32) ok = eliminate_in_registers<1>(M, mp, k, kp, rowbuf, colbuf);
-    else if (kp == 64) ok = eliminate_in_registers<2>(M, mp, k, kp, rowbuf, colbuf);
-    else if (kp == 96) ok = eliminate_in_registers<3>(M, mp, k, kp, rowbuf, colbuf);
-    else ok = eliminate_in_registers<4>(M, mp, k, kp, rowbuf, colbuf);
+    else if (kp == 32) ok = eliminate_in_registers<2>(M, mp, k, kp, rowbuf, colbuf);
+    else if (kp == 64) ok = eliminate_in_registers<4>(M, mp, k, kp, rowbuf, colbuf);
+    else if (kp == 96) ok = eliminate_in_registers<6>(M, mp, k, kp, rowbuf, colbuf);
+    else ok = eliminate_in_registers<8>(M, mp, k, kp, rowbuf, colbuf);
     if (!ok) {
         if (tid == 0) { status[0] = 1; status[1] = 1; }    // [1] is sticky until slam_ekf_sync reads it
         return;
@@ -336,8 +351,8 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
     if (!want_sinv) {
         // C[a][b] = Linv[b][a]/sqrt(D_b) (a<b), 1/sqrt(D_b) (a==b), 0 below and in the padding
         for (int idx = tid; idx < kp * kp; idx += nt) {
-            const int b = idx / kp, a = idx - b * kp;         // consecutive threads walk a row of M
-            double c = 0.0;
+            const int a = idx / kp, b = idx - a * kp;         // consecutive threads: consecutive b (coalesced store,
+            double c = 0.0;                                   //   conflict-free LDS column walk thanks to the odd pitch)
             if (a < k && b < k) {
                 if (a == b) c = mvec[b];
                 else if (a < b) c = M[(size_t)b * mp + a] * mvec[b];
@@ -512,7 +527,7 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form) {
             hipLaunchKernelGGL(panel_gemm_kernel<T>, pg_grid, dim3(256), 0, h->stream, h->PHt, pitchA, h->Cmat, pitchA, kp, 1,
                                1.0, (const double*)nullptr, 0, 0.0, W1, pitchW, 0, (T*)nullptr, 0, 0, (double*)nullptr, 0,
                                h->d_status);
-            kp_total = kp;
+            kp_total = round_up(k, 16);      // W1 is zero in columns k..kp-1: the down-date stops at the next multiple of 16
         } else {
             // K = PHt*inv(S)            -> W1[:, 0:kp], W2[:, kp:2kp], Kd (double)
             hipLaunchKernelGGL(panel_gemm_kernel<T>, pg_grid, dim3(256), 0, h->stream, h->PHt, pitchA, h->Cmat, pitchA, kp, 0,
