@@ -49,6 +49,7 @@ struct TimingPair {
 struct slam_ekf {
     int dtype;        // SLAM_F32 / SLAM_F64
     int device;
+    int num_cus;      // compute units of the device
     int maxN;         // landmark capacity
     int N;            // landmarks in the map
     int ncap;         // 3 + 2*maxN

@@ -167,6 +167,9 @@ extern "C" int slam_ekf_destroy(slam_ekf_t h) {
 
 static int create_impl(slam_ekf* h) {
     HIP_TRY(hipSetDevice(h->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, h->device));
+    h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&h->stage_ev, hipEventDisableTiming));
     int rc;

@@ -169,13 +169,40 @@ __device__ inline void store_p_tile_masked(float* __restrict__ P, int ld, int n,
         }
 }
 
+// One k-chunk of MFMAs out of LDS buffer `buf`; `kend` (16 or 32) columns are live.
+__device__ inline void mfma_chunk(const float (&sm)[2][2][TILE][LDSP], int buf, int kend, int wr, int wc, int l31, int lh,
+                                  f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 8) {
+        if (kk < kend) {
+            f32x4 a[2], b[2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+                a[cb] = *reinterpret_cast<const f32x4*>(&sm[buf][1][64 * wc + 32 * cb + l31][kk + 4 * lh]);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+                b[rb] = *reinterpret_cast<const f32x4*>(&sm[buf][0][64 * wr + 32 * rb + l31][kk + 4 * lh]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+                        acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cb][t], b[rb][t], acc[cb][rb], 0, 0, 0);
+        }
+    }
+}
+
+// PERSISTENT kernel: gridDim.x = 8 * nper workgroups (two per CU); workgroup b walks the tile list
+// of XCD b % 8 with stride nper.  Memory operations of one wave are asynchronous, so a wave that
+// moves on to the next tile's MFMAs lets its epilogue stores drain behind them; what remains
+// exposed per tile (store issue, first-chunk latency) is covered by the CU's second workgroup,
+// which is started half a tile late so that the two do not run their phases in lockstep.
 __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ P, int ld, int n,
                                                             const float* __restrict__ X, const float* __restrict__ Y,
-                                                            int pitch, int kp, const int2* __restrict__ tiles,
+                                                            int pitch, int kp, const int2* __restrict__ tiles, int L,
                                                             const int32_t* __restrict__ status) {
     if (status[0] != 0) return;
-    const int2 tile = tiles[blockIdx.x];
-    if (tile.x < 0) return;                                   // padding entry of the tile list
     __shared__ __attribute__((aligned(16))) float smem[2][2][TILE][LDSP];   // [buffer][X|Y][row][k]  73,728 B
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -184,77 +211,101 @@ __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ 
     const int wc = wave >> 1;         // column half
     const int l31 = lane & 31;
     const int lh = lane >> 5;
-    const int R0 = tile.x * TILE;     // rows  (I)
-    const int C0 = tile.y * TILE;     // cols  (J <= I)
-    const bool diag = tile.x == tile.y;
-
-    f32x16 acc[2][2];                 // [cb][rb]
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[cb][rb][r] = 0.0f;
+    const int xcd = blockIdx.x & 7;
+    const int rk = blockIdx.x >> 3;
+    const int nper = gridDim.x >> 3;
+    if (rk >= (nper >> 1)) __builtin_amdgcn_s_sleep(127);                  // ~3.4 us stagger (speed only)
+    const int2* list = tiles + (size_t)xcd * L;
+    int slot = rk;
+    int2 tile = slot < L ? list[slot] : make_int2(-1, -1);
 
     // staging registers: 128 x 32 floats per panel = 1024 float4, 4 per thread per panel
     f32x4 gx[4], gy[4];
     const int srow = tid >> 3;        // + 32*s
     const int sc4 = tid & 7;
-    const float* xsrc = X + (size_t)(R0 + srow) * pitch + 4 * sc4;
-    const float* ysrc = Y + (size_t)(C0 + srow) * pitch + 4 * sc4;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        gx[s] = *reinterpret_cast<const f32x4*>(xsrc + (size_t)(32 * s) * pitch);
-        gy[s] = *reinterpret_cast<const f32x4*>(ysrc + (size_t)(32 * s) * pitch);
-    }
-
-    // P tile -> registers AFTER the first panel chunk was requested (vmcnt retires in order, so the
-    // first LDS fill only waits for the chunk); in flight during the whole k-loop
-    float pold[2][2][16];
-    if (diag) load_p_tile_masked(P, ld, n, R0, C0, wr, wc, l31, lh, pold);
-    else load_p_tile_fast(P, ld, R0, C0, wr, wc, l31, lh, pold);
-
     const int nchunks = (kp + KC - 1) / KC;                   // kp is a multiple of 16: the last chunk may be half
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
+    float* sT = &smem[0][0][0][0] + wave * (32 * TP);
+
+    if (tile.x >= 0) {
+        const float* xsrc = X + (size_t)(tile.x * TILE + srow) * pitch + 4 * sc4;
+        const float* ysrc = Y + (size_t)(tile.y * TILE + srow) * pitch + 4 * sc4;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            *reinterpret_cast<f32x4*>(&smem[buf][0][srow + 32 * s][4 * sc4]) = gx[s];
-            *reinterpret_cast<f32x4*>(&smem[buf][1][srow + 32 * s][4 * sc4]) = gy[s];
-        }
-        __syncthreads();
-        if (c + 1 < nchunks) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                gx[s] = *reinterpret_cast<const f32x4*>(xsrc + (size_t)(32 * s) * pitch + (c + 1) * KC);
-                gy[s] = *reinterpret_cast<const f32x4*>(ysrc + (size_t)(32 * s) * pitch + (c + 1) * KC);
-            }
-        }
-        const int kend = (kp - c * KC < KC) ? kp - c * KC : KC;
-#pragma unroll
-        for (int kk = 0; kk < KC; kk += 8) {
-            if (kk < kend) {
-                f32x4 a[2], b[2];
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
-                    a[cb] = *reinterpret_cast<const f32x4*>(&smem[buf][1][64 * wc + 32 * cb + l31][kk + 4 * lh]);
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
-                    b[rb] = *reinterpret_cast<const f32x4*>(&smem[buf][0][64 * wr + 32 * rb + l31][kk + 4 * lh]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                        for (int rb = 0; rb < 2; ++rb)
-                            acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cb][t], b[rb][t], acc[cb][rb], 0, 0, 0);
-            }
+            gx[s] = *reinterpret_cast<const f32x4*>(xsrc + (size_t)(32 * s) * pitch);
+            gy[s] = *reinterpret_cast<const f32x4*>(ysrc + (size_t)(32 * s) * pitch);
         }
     }
-    __syncthreads();                  // every wave is done with the panels: reuse LDS as transpose scratch
-    float* sT = &smem[0][0][0][0] + wave * (32 * TP);
-    if (diag) store_p_tile_masked(P, ld, n, R0, C0, wr, wc, l31, lh, pold, acc, sT);
-    else store_p_tile_fast(P, ld, R0, C0, wr, wc, l31, lh, pold, acc, sT);
+    while (tile.x >= 0) {
+        const int R0 = tile.x * TILE;     // rows  (I)
+        const int C0 = tile.y * TILE;     // cols  (J <= I)
+        const bool diag = tile.x == tile.y;
+        const float* xsrc = X + (size_t)(R0 + srow) * pitch + 4 * sc4;
+        const float* ysrc = Y + (size_t)(C0 + srow) * pitch + 4 * sc4;
+
+        f32x16 acc[2][2];                 // [cb][rb]
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cb][rb][r] = 0.0f;
+
+        // chunk 0 (requested before the previous tile's epilogue)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            *reinterpret_cast<f32x4*>(&smem[0][0][srow + 32 * s][4 * sc4]) = gx[s];
+            *reinterpret_cast<f32x4*>(&smem[0][1][srow + 32 * s][4 * sc4]) = gy[s];
+        }
+        __syncthreads();
+        if (nchunks > 1) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                gx[s] = *reinterpret_cast<const f32x4*>(xsrc + (size_t)(32 * s) * pitch + KC);
+                gy[s] = *reinterpret_cast<const f32x4*>(ysrc + (size_t)(32 * s) * pitch + KC);
+            }
+        }
+        // P tile -> registers; in flight during the k-loop
+        float pold[2][2][16];
+        if (diag) load_p_tile_masked(P, ld, n, R0, C0, wr, wc, l31, lh, pold);
+        else load_p_tile_fast(P, ld, R0, C0, wr, wc, l31, lh, pold);
+        mfma_chunk(smem, 0, kp < KC ? kp : KC, wr, wc, l31, lh, acc);
+
+        for (int c = 1; c < nchunks; ++c) {
+            const int buf = c & 1;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                *reinterpret_cast<f32x4*>(&smem[buf][0][srow + 32 * s][4 * sc4]) = gx[s];
+                *reinterpret_cast<f32x4*>(&smem[buf][1][srow + 32 * s][4 * sc4]) = gy[s];
+            }
+            __syncthreads();
+            if (c + 1 < nchunks) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    gx[s] = *reinterpret_cast<const f32x4*>(xsrc + (size_t)(32 * s) * pitch + (c + 1) * KC);
+                    gy[s] = *reinterpret_cast<const f32x4*>(ysrc + (size_t)(32 * s) * pitch + (c + 1) * KC);
+                }
+            }
+            mfma_chunk(smem, buf, (kp - c * KC < KC) ? kp - c * KC : KC, wr, wc, l31, lh, acc);
+        }
+
+        // next tile: request its first panel chunk now, ahead of this tile's 128 stores per lane
+        slot += nper;
+        const int2 next = slot < L ? list[slot] : make_int2(-1, -1);
+        __syncthreads();                  // every wave is done with the panels: LDS becomes transpose scratch
+        if (next.x >= 0) {
+            const float* nx = X + (size_t)(next.x * TILE + srow) * pitch + 4 * sc4;
+            const float* ny = Y + (size_t)(next.y * TILE + srow) * pitch + 4 * sc4;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                gx[s] = *reinterpret_cast<const f32x4*>(nx + (size_t)(32 * s) * pitch);
+                gy[s] = *reinterpret_cast<const f32x4*>(ny + (size_t)(32 * s) * pitch);
+            }
+        }
+        if (diag) store_p_tile_masked(P, ld, n, R0, C0, wr, wc, l31, lh, pold, acc, sT);
+        else store_p_tile_fast(P, ld, R0, C0, wr, wc, l31, lh, pold, acc, sT);
+        __syncthreads();                  // scratch free again before the next tile's LDS fill
+        tile = next;
+    }
 }
 
 // ---- fp64 VALU down-date -----------------------------------------------------
@@ -264,9 +315,10 @@ constexpr int DK = 16;     // k-chunk
 template <typename T>
 __global__ __launch_bounds__(256) void downdate_valu(T* __restrict__ P, int ld, int n, const T* __restrict__ X,
                                                      const T* __restrict__ Y, int pitch, int kp,
-                                                     const int2* __restrict__ tiles, const int32_t* __restrict__ status) {
+                                                     const int2* __restrict__ tiles, int L,
+                                                     const int32_t* __restrict__ status) {
     if (status[0] != 0) return;
-    const int2 tile = tiles[blockIdx.x];
+    const int2 tile = tiles[(size_t)(blockIdx.x & 7) * L + (blockIdx.x >> 3)];     // workgroup b -> list b % 8, slot b / 8
     if (tile.x < 0) return;
     __shared__ T sX[DT][DK + 1];
     __shared__ T sY[DT][DK + 1];
@@ -339,8 +391,9 @@ __global__ __launch_bounds__(256) void downdate_valu(T* __restrict__ P, int ld, 
     }
 }
 
-// Tile list: entry b is the tile of workgroup b; XCD x (= b % 8 under round-robin
-// dispatch) walks super-rows of SR tile rows, largest first, column by column.
+// Tile lists: eight lists of equal length L (padded with -1), laid out [xcd][slot].  XCD x
+// (= workgroup id % 8 under round-robin dispatch) walks super-rows of SR tile rows, largest
+// first, column by column; its workgroups take slots rk, rk + nper, ...
 void build_tile_order(int T, std::vector<int2>& out) {
     constexpr int NX = 8, SR = 4;
     const int nsr = (T + SR - 1) / SR;
@@ -368,7 +421,7 @@ void build_tile_order(int T, std::vector<int2>& out) {
     }
     out.assign(L * NX, make_int2(-1, -1));
     for (int xcd = 0; xcd < NX; ++xcd)
-        for (size_t slot = 0; slot < lists[xcd].size(); ++slot) out[slot * NX + xcd] = lists[xcd][slot];
+        for (size_t slot = 0; slot < lists[xcd].size(); ++slot) out[xcd * L + slot] = lists[xcd][slot];
 }
 
 int ensure_tile_order(slam_ekf* h, int T) {
@@ -385,7 +438,7 @@ int ensure_tile_order(slam_ekf* h, int T) {
     }
     HIP_TRY(hipMemcpy(h->tiles, order.data(), sizeof(int2) * order.size(), hipMemcpyHostToDevice));
     h->tiles_T = T;
-    h->tiles_len = (int)order.size();
+    h->tiles_len = (int)order.size() / 8;          // L: entries per XCD list
     return SLAM_OK;
 }
 
@@ -397,12 +450,19 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
     const int rc = ensure_tile_order(h, (n + edge - 1) / edge);
     if (rc) return rc;
     KTimer t(h, SLAM_K_SYRK);
-    if (h->dtype == SLAM_F32)
-        hipLaunchKernelGGL(downdate_f32_mfma, dim3(h->tiles_len), dim3(256), 0, h->stream, (float*)h->P, h->ld, n,
-                           (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->d_status);
-    else
-        hipLaunchKernelGGL(downdate_valu<double>, dim3(h->tiles_len), dim3(256), 0, h->stream, (double*)h->P, h->ld, n,
-                           (const double*)X, (const double*)Y, pitch, kp_total, (const int2*)h->tiles, h->d_status);
+    if (h->dtype == SLAM_F32) {
+        // persistent: two workgroups per CU (VGPR- and LDS-limited residency), never more than there are tiles
+        int per_xcd = 2 * h->num_cus / 8;
+        if (per_xcd > h->tiles_len) per_xcd = h->tiles_len;
+        if (per_xcd < 1) per_xcd = 1;
+        hipLaunchKernelGGL(downdate_f32_mfma, dim3(8 * per_xcd), dim3(256), 0, h->stream, (float*)h->P, h->ld, n,
+                           (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
+                           h->d_status);
+    } else {
+        hipLaunchKernelGGL(downdate_valu<double>, dim3(8 * h->tiles_len), dim3(256), 0, h->stream, (double*)h->P, h->ld, n,
+                           (const double*)X, (const double*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
+                           h->d_status);
+    }
     HIP_TRY(hipGetLastError());
     return SLAM_OK;
 }
