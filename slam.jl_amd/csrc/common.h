@@ -94,6 +94,7 @@ struct slam_ekf {
     int32_t* d_status;   // [4]  [0] = not-PD flag of the last update
     int32_t* h_status;   // pinned
 
+    int debug_flags;     // SLAMHIP_DEBUG env: 1 = skip mirrored stores, 2 = skip MFMAs (timing experiments, WRONG results)
     int debug_stamps;    // factor kernel writes 100 MHz wall-clock stamps into d_small[40..47]
     int async_updates;
     int deferred;        // first deferred error

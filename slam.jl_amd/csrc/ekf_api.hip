@@ -218,6 +218,7 @@ extern "C" int slam_ekf_create(slam_ekf_t* out, int dtype, int max_landmarks, in
     h->d_small = h->h_small = nullptr;
     h->d_status = h->h_status = nullptr;
     h->async_updates = 0; h->deferred = 0; h->pending_status = 0; h->debug_stamps = 0;
+    h->debug_flags = getenv("SLAMHIP_DEBUG") ? atoi(getenv("SLAMHIP_DEBUG")) : 0;
     h->timing = 0;
     for (int i = 0; i < SLAM_K_COUNT; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
     const int rc = create_impl(h);

@@ -96,7 +96,7 @@ __device__ inline void load_p_tile_fast(const float* __restrict__ P, int ld, int
 }
 
 __device__ inline void store_p_tile_fast(float* __restrict__ P, int ld, int R0, int C0, int wr, int wc, int l31, int lh,
-                                         const float (&pold)[2][2][16], const f32x16 (&acc)[2][2], float* sT) {
+                                         const float (&pold)[2][2][16], const f32x16 (&acc)[2][2], float* sT, int dbg) {
     const auto rs = band_rsrc(P + (size_t)C0 * ld, ld);       // direct:   columns C0.., rows R0..
     const auto rsm = band_rsrc(P + (size_t)R0 * ld, ld);      // mirrored: columns R0.., rows C0..
     const int voff = (l31 + lh * 4 * ld) * 4;
@@ -118,7 +118,7 @@ __device__ inline void store_p_tile_fast(float* __restrict__ P, int ld, int R0, 
             for (int s = 0; s < 16; ++s) {
                 const float val = sT[(2 * s + lh) * TP + l31];
                 const int soff = ((64 * wr + 32 * rb + 2 * s) * ld + C0 + 64 * wc + 32 * cb) * 4;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rsm, voff_m, soff, 0);
+                if (!(dbg & 1)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rsm, voff_m, soff, 0);
             }
             wave_lds_fence();
         }
@@ -201,7 +201,7 @@ __device__ inline void mfma_chunk(const float (&sm)[2][2][TILE][LDSP], int buf, 
 __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ P, int ld, int n,
                                                             const float* __restrict__ X, const float* __restrict__ Y,
                                                             int pitch, int kp, const int2* __restrict__ tiles, int L,
-                                                            const int32_t* __restrict__ status) {
+                                                            const int32_t* __restrict__ status, int dbg) {
     if (status[0] != 0) return;
     __shared__ __attribute__((aligned(16))) float smem[2][2][TILE][LDSP];   // [buffer][X|Y][row][k]  73,728 B
     const int tid = threadIdx.x;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ 
         float pold[2][2][16];
         if (diag) load_p_tile_masked(P, ld, n, R0, C0, wr, wc, l31, lh, pold);
         else load_p_tile_fast(P, ld, R0, C0, wr, wc, l31, lh, pold);
-        mfma_chunk(smem, 0, kp < KC ? kp : KC, wr, wc, l31, lh, acc);
+        if (!(dbg & 2)) mfma_chunk(smem, 0, kp < KC ? kp : KC, wr, wc, l31, lh, acc);
 
         for (int c = 1; c < nchunks; ++c) {
             const int buf = c & 1;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ 
                     gy[s] = *reinterpret_cast<const f32x4*>(ysrc + (size_t)(32 * s) * pitch + (c + 1) * KC);
                 }
             }
-            mfma_chunk(smem, buf, (kp - c * KC < KC) ? kp - c * KC : KC, wr, wc, l31, lh, acc);
+            if (!(dbg & 2)) mfma_chunk(smem, buf, (kp - c * KC < KC) ? kp - c * KC : KC, wr, wc, l31, lh, acc);
         }
 
         // next tile: request its first panel chunk now, ahead of this tile's 128 stores per lane
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ 
             }
         }
         if (diag) store_p_tile_masked(P, ld, n, R0, C0, wr, wc, l31, lh, pold, acc, sT);
-        else store_p_tile_fast(P, ld, R0, C0, wr, wc, l31, lh, pold, acc, sT);
+        else store_p_tile_fast(P, ld, R0, C0, wr, wc, l31, lh, pold, acc, sT, dbg);
         __syncthreads();                  // scratch free again before the next tile's LDS fill
         tile = next;
     }
@@ -457,7 +457,7 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
         if (per_xcd < 1) per_xcd = 1;
         hipLaunchKernelGGL(downdate_f32_mfma, dim3(8 * per_xcd), dim3(256), 0, h->stream, (float*)h->P, h->ld, n,
                            (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
-                           h->d_status);
+                           h->d_status, h->debug_flags);
     } else {
         hipLaunchKernelGGL(downdate_valu<double>, dim3(8 * h->tiles_len), dim3(256), 0, h->stream, (double*)h->P, h->ld, n,
                            (const double*)X, (const double*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
