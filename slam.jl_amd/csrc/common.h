@@ -83,6 +83,8 @@ struct slam_ekf {
     // down-date tile order (ekf_syrk.hip): workgroup b computes tile tiles[b]
     int2* tiles;
     int tiles_T, tiles_len, tiles_cap;
+    int tiles_xlen[8];   // valid entries of each XCD's list
+    int diag_off, diag_len, diag_xlen[8];   // fp32: the diagonal tiles, listed after the main lists
 
     // gating partials
     double* gate_part;   // [gate_blocks][ocap][3]

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void pht_kernel(const T* __restrict__ x, const
 constexpr int FACTOR_THREADS = 512;      // 8 waves: 256 VGPRs each, so the 4 worker waves can hold 64 doubles
 
 template <int NB>      // NB = kp / 16
-__device__ inline bool eliminate_in_registers(double* M, int mp, int k, int kp, double* rowbuf, double* colbuf) {
+__device__ __forceinline__ bool eliminate_in_registers(double* M, int mp, int k, int kp, double* rowbuf, double* colbuf) {
     // Four waves (one per SIMD) hold the matrix: thread (ty, tx) of a 16 x 16 grid owns the elements
     // (ty + 16u, tx + 16v).  More waves only multiply the per-step overhead (the pivot reciprocal, the
     // LDS reads, the predicates) that every wave pays; the other twelve waves just keep the barriers.
@@ -192,7 +192,9 @@ __device__ inline bool eliminate_in_memory(double* M, int mp, int k, double* mve
     return true;
 }
 
-template <typename T>
+// INLDS = true: M lives in LDS and is addressed as LDS (ds_* instructions).  A single kernel that picked
+// "LDS or global" at run time made every access a FLAT instruction -- 3x slower per elimination step.
+template <typename T, bool INLDS>
 __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
     const T* __restrict__ x, const double* __restrict__ PHt, int pht_pitch, const double* __restrict__ z,
     const int32_t* __restrict__ idf, int m, int k, int kp, double R0, double R1, double R2, double R3,
@@ -207,8 +209,15 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
     const int tid = threadIdx.x;
     const int nt = blockDim.x;
     const int mp = kp + 1;                                   // odd pitch: conflict-free column walks
-    double* M = Mglobal ? Mglobal : lds;
-    double* aux = Mglobal ? lds : lds + (size_t)kp * mp;
+    double* M;
+    double* aux;
+    if constexpr (INLDS) {
+        M = lds;
+        aux = lds + (size_t)kp * mp;
+    } else {
+        M = Mglobal;
+        aux = lds;
+    }
     double* mvec = aux;                                      // [kp]  multipliers, later 1/sqrt(D)
     double* vvec = aux + kp;                                 // [kp]  innovation
     double* yvec = aux + 2 * kp;                             // [kp]
@@ -234,7 +243,7 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
     STAMP(1);
 
     // S = H*PHt + RR (ekf.jl:68); rows/cols >= k are padded with the identity
-    if (!Mglobal) {
+    if constexpr (INLDS) {
         // kp <= 128: thread (grp, b) owns column b and the observations grp, grp+G, ... (at most 16);
         // its <= 35 loads of PHt are all issued before the first use.
         const int G = nt / kp;
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
                 }
             }
         }
-    } else
+    } else {
     for (int idx = tid; idx < kp * kp; idx += nt) {
         const int a = idx / kp, b = idx - a * kp;
         double s;
@@ -287,10 +296,11 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
         }
         M[(size_t)a * mp + b] = s;
     }
+    }
     __syncthreads();
     STAMP(2);
     // S = (S + S')*0.5 (ekf.jl:69): folded into the register load of the elimination (LDS path)
-    if (Mglobal) {
+    if constexpr (!INLDS) {
         for (int idx = tid; idx < k * k; idx += nt) {
             const int a = idx / k, b = idx - a * k;
             if (a < b) {
@@ -311,7 +321,7 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
     }
     STAMP(3);
     bool ok;
-    if (Mglobal) ok = eliminate_in_memory(M, mp, k, mvec);
+    if constexpr (!INLDS) ok = eliminate_in_memory(M, mp, k, mvec);
     else if (kp == 32) ok = eliminate_in_registers<2>(M, mp, k, kp, rowbuf, colbuf);
     else if (kp == 64) ok = eliminate_in_registers<4>(M, mp, k, kp, rowbuf, colbuf);
     else if (kp == 96) ok = eliminate_in_registers<6>(M, mp, k, kp, rowbuf, colbuf);
@@ -512,10 +522,15 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form) {
         const bool in_lds = kp <= 128;
         const size_t aux = (size_t)7 * kp * sizeof(double) + (size_t)m * (10 * sizeof(double) + sizeof(int));
         const size_t shm = aux + (in_lds ? (size_t)kp * (kp + 1) * sizeof(double) : 0);
-        hipLaunchKernelGGL(factor_kernel<T>, dim3(1), dim3(FACTOR_THREADS), shm, h->stream, x, h->PHt, pitchA, h->obsbuf,
-                           h->idfbuf, m, k, kp, R[0], R[1], R[2], R[3], h->Cmat, pitchA, h->gvec,
-                           joseph ? h->Smat : (double*)nullptr, joseph ? 1 : 0, in_lds ? (double*)nullptr : h->Mwork,
-                           h->d_status, h->debug_stamps ? (unsigned long long*)(h->d_small + 40) : (unsigned long long*)nullptr);
+        unsigned long long* stamps = h->debug_stamps ? (unsigned long long*)(h->d_small + 40) : (unsigned long long*)nullptr;
+        if (in_lds)
+            hipLaunchKernelGGL((factor_kernel<T, true>), dim3(1), dim3(FACTOR_THREADS), shm, h->stream, x, h->PHt, pitchA,
+                               h->obsbuf, h->idfbuf, m, k, kp, R[0], R[1], R[2], R[3], h->Cmat, pitchA, h->gvec,
+                               joseph ? h->Smat : (double*)nullptr, joseph ? 1 : 0, (double*)nullptr, h->d_status, stamps);
+        else
+            hipLaunchKernelGGL((factor_kernel<T, false>), dim3(1), dim3(FACTOR_THREADS), shm, h->stream, x, h->PHt, pitchA,
+                               h->obsbuf, h->idfbuf, m, k, kp, R[0], R[1], R[2], R[3], h->Cmat, pitchA, h->gvec,
+                               joseph ? h->Smat : (double*)nullptr, joseph ? 1 : 0, h->Mwork, h->d_status, stamps);
     }
     HIP_TRY(hipGetLastError());
     const dim3 pg_grid(h->npad / PG_ROWS, (kp + PG_COLS - 1) / PG_COLS);
@@ -555,9 +570,9 @@ int launch_update(slam_ekf* h, int m, const double R[4], int form) {
 int update_kernels_init() {
     // the factor kernel keeps a 128 x 129 double matrix in LDS: raise the dynamic-LDS cap
     const int big = 160 * 1024;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_kernel<float>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_kernel<float, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_kernel<double>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_kernel<double, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, big));
     return SLAM_OK;
 }
