@@ -142,19 +142,23 @@ __device__ __forceinline__ bool eliminate_in_registers(double* M, int mp, int k,
                 double rp = __builtin_amdgcn_rcp(piv);
                 rp = __builtin_fma(rp, __builtin_fma(-piv, rp, 1.0), rp);
                 rp = __builtin_fma(rp, __builtin_fma(-piv, rp, 1.0), rp);
-                double rowv[NB];
+                // every LDS operand of the step is requested up front (one latency, not one per row block)
+                double rowv[NB], colv[NB];
 #pragma unroll
                 for (int v = 0; v < NB; ++v) rowv[v] = rb[tx + 16 * v];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) colv[u] = cb[ty + 16 * u];
                 // rows i = ty + 16u: u < ub is finished (i < j), u > ub is active, u == ub is active iff ty > jj.
-                // Padding rows (i >= k) carry a zero in column j, so their multiplier is zero: no guard needed.
+                // Branch-free: an inactive row gets the multiplier 0.  Padding rows (i >= k) carry a zero in
+                // column j, so their multiplier is zero by itself.
+                const bool fix = tx == jj;
 #pragma unroll
                 for (int u = ub; u < NB; ++u) {
-                    const double mu = cb[ty + 16 * u] * rp;
-                    if (u > ub || ty > jj) {
+                    const bool act = (u > ub) || (ty > jj);
+                    const double mu = act ? colv[u] * rp : 0.0;
 #pragma unroll
-                        for (int v = 0; v < NB; ++v) a[u][v] = __builtin_fma(-mu, rowv[v], a[u][v]);
-                        if (tx == jj) a[u][ub] = -mu;      // column j now holds column j of inv(L)
-                    }
+                    for (int v = 0; v < NB; ++v) a[u][v] = __builtin_fma(-mu, rowv[v], a[u][v]);
+                    a[u][ub] = (act && fix) ? -mu : a[u][ub];      // column j now holds column j of inv(L)
                 }
             }
         }

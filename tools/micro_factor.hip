@@ -47,17 +47,19 @@ __global__ void elim(double* out, int k, int nthreads_work) {
                     rp = __builtin_fma(rp, __builtin_fma(-piv, rp, 1.0), rp);
                 }
                 if (VAR >= 3) {
-                    double rowv[NB];
+                    double rowv[NB], colv[NB];
 #pragma unroll
                     for (int v = 0; v < NB; ++v) rowv[v] = rb[tx + 16 * v];
 #pragma unroll
-                    for (int u = ub; u < NB; ++u) {
-                        const double mu = cb[ty + 16 * u] * rp;
-                        if (u > ub || ty > jj) {
+                    for (int u = 0; u < NB; ++u) colv[u] = cb[ty + 16 * u];
+                    const bool fix = tx == jj;
 #pragma unroll
-                            for (int v = 0; v < NB; ++v) a[u][v] = __builtin_fma(-mu, rowv[v], a[u][v]);
-                            if (tx == jj) a[u][ub] = -mu;
-                        }
+                    for (int u = ub; u < NB; ++u) {
+                        const bool act = (u > ub) || (ty > jj);
+                        const double mu = act ? colv[u] * rp : 0.0;
+#pragma unroll
+                        for (int v = 0; v < NB; ++v) a[u][v] = __builtin_fma(-mu, rowv[v], a[u][v]);
+                        a[u][ub] = (act && fix) ? -mu : a[u][ub];
                     }
                 } else {
                     a[0][0] += rp;
