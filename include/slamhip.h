@@ -143,6 +143,64 @@ int slam_ekf_timing_reset(slam_ekf_t h);
  * phase boundaries; out8 (may be NULL) receives the stamps of the last update. */
 int slam_ekf_debug_stamps(slam_ekf_t h, int enable, uint64_t* out8);
 
+/* ---- FastSLAM-1.0 particle path (known correspondences) ----------------------------
+ *
+ * The reference implements no particle filter: only the types Particle (src/common.jl:14-20)
+ * and PFSlamState (src/common.jl:31-34) exist and README.md:6 says "FastSLAM is ongoing".
+ * These entry points take over what a PFSlamState-based predict/update would do, as specified
+ * in SURVEY.md 8a rows F1-F4 from the reference's EKF building blocks (each function cites them).
+ *
+ * One handle owns the GLOBAL particle ids [first_id, first_id + n_local) of a filter with
+ * n_global particles (one process per GPU).  Random numbers are Philox4x32-10 keyed by
+ * (seed, step, global id), so results do not depend on the split.  Collectives (three scalars
+ * per step; all log-weights and the migrating particle records on a resampling step) are
+ * issued by the host between these calls (torch.distributed over RCCL): see slam.jl_amd/pf.py. */
+typedef struct slam_pf* slam_pf_t;
+
+int slam_pf_create(slam_pf_t* h, int dtype, int64_t n_local, int64_t n_global, int64_t first_id,
+                   int max_landmarks, int device, uint64_t seed);
+int slam_pf_destroy(slam_pf_t h);
+/* Every particle at `pose`, weights uniform (1 / n_global).  Particle.pose, src/common.jl:15. */
+int slam_pf_set_pose(slam_pf_t h, const double pose[3]);
+/* Landmarks 1..nl known to every particle at lm_xy + N(0, jitter_sigma^2) with covariance
+ * diag(var, var) (the synthetic start of BASELINE.json config 4).  Particle.features / .fcov. */
+int slam_pf_init_landmarks(slam_pf_t h, const double* lm_xy, int nl, double var, double jitter_sigma);
+/* F1: V, G perturbed per particle like add_control_noise! (sim/sim-utils.jl:35-38), then the
+ * pose update of predict (src/ekf.jl:39-41).  Enqueued. */
+int slam_pf_predict(slam_pf_t h, double V, double G, double wheelbase, const double Q[4], double dt);
+/* F2/F3: m (range, bearing) pairs with KNOWN 1-based landmark ids.  Seen landmark: the 2x2
+ * EKF update (src/common.jl:162 + src/ekf.jl:67-75 on the feature block) and
+ * logw += log N(v; 0, S).  First sighting: initialisation like add_features
+ * (src/ekf.jl:94-103,112) without the vehicle-covariance term.  Enqueued. */
+int slam_pf_update_known(slam_pf_t h, const double* z, const int32_t* ids, int m, const double R[4]);
+/* F4, local part: out = {max logw, sum exp(logw - max), sum exp(2 (logw - max))}.  Synchronises. */
+int slam_pf_weight_stats(slam_pf_t h, double out[3]);
+/* logw -= gmax + log(gsum) with the GLOBAL max / sum (after the all-reduce). */
+int slam_pf_normalize(slam_pf_t h, double gmax, double gsum);
+/* Copy the local log-weights (handle dtype, n_local values) into a DEVICE buffer, e.g. this
+ * rank's slice of the all-gather input.  Synchronises. */
+int slam_pf_copy_logw(slam_pf_t h, void* d_dst);
+/* Systematic resampling over the GLOBAL weights: d_logw_all holds all n_global log-weights
+ * (device, handle dtype), gmax their maximum, u0 in [0,1) the shared offset.  d_anc (device,
+ * n_local int32) receives the global ancestor id of every local slot.  Synchronises. */
+int slam_pf_ancestors(slam_pf_t h, const void* d_logw_all, double gmax, double u0, int32_t* d_anc);
+/* Rows of one particle record: 3 pose rows + 5 rows per landmark (x, y, Pxx, Pxy, Pyy). */
+int slam_pf_record_rows(slam_pf_t h, int* rows);
+/* records[row][c] = state row of local particle d_local_idx[c]  (device buffers, handle dtype):
+ * what a rank sends to the ranks whose slots descend from its particles.  Synchronises. */
+int slam_pf_pack(slam_pf_t h, const int32_t* d_local_idx, int cnt, void* d_records);
+/* Replace every local particle by its ancestor: local ancestors are gathered from the
+ * resident state, remote ones from d_remote_records ([rows][nremote], columns in the order
+ * of the ascending global ids d_remote_ids).  Weights return to 1 / n_global.  Synchronises. */
+int slam_pf_resample_apply(slam_pf_t h, const int32_t* d_anc, const int32_t* d_remote_ids, int nremote,
+                           const void* d_remote_records);
+/* out = {sum w x, sum w y, sum w sin(phi), sum w cos(phi)} over the local particles, w = exp(logw). */
+int slam_pf_mean_pose_sums(slam_pf_t h, double out[4]);
+/* Download (host buffers, handle dtype; any may be NULL): pose [3][n], logw [n], lm [nl][5][n]. */
+int slam_pf_download(slam_pf_t h, void* pose, void* logw, void* lm);
+int slam_pf_sync(slam_pf_t h);
+int slam_pf_stream(slam_pf_t h, void** stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,23 @@ SIGNATURES = {
     "slam_ekf_timing_read": (C.c_int, [_h, C.c_int, _dp, C.POINTER(C.c_int64)]),
     "slam_ekf_timing_reset": (C.c_int, [_h]),
     "slam_ekf_debug_stamps": (C.c_int, [_h, C.c_int, C.POINTER(C.c_uint64)]),
+    "slam_pf_create": (C.c_int, [C.POINTER(_h), C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_uint64]),
+    "slam_pf_destroy": (C.c_int, [_h]),
+    "slam_pf_set_pose": (C.c_int, [_h, _dp]),
+    "slam_pf_init_landmarks": (C.c_int, [_h, _dp, C.c_int, C.c_double, C.c_double]),
+    "slam_pf_predict": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, _dp, C.c_double]),
+    "slam_pf_update_known": (C.c_int, [_h, _dp, _ip, C.c_int, _dp]),
+    "slam_pf_weight_stats": (C.c_int, [_h, _dp]),
+    "slam_pf_normalize": (C.c_int, [_h, C.c_double, C.c_double]),
+    "slam_pf_copy_logw": (C.c_int, [_h, C.c_void_p]),
+    "slam_pf_ancestors": (C.c_int, [_h, C.c_void_p, C.c_double, C.c_double, C.c_void_p]),
+    "slam_pf_record_rows": (C.c_int, [_h, C.POINTER(C.c_int)]),
+    "slam_pf_pack": (C.c_int, [_h, C.c_void_p, C.c_int, C.c_void_p]),
+    "slam_pf_resample_apply": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "slam_pf_mean_pose_sums": (C.c_int, [_h, _dp]),
+    "slam_pf_download": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "slam_pf_sync": (C.c_int, [_h]),
+    "slam_pf_stream": (C.c_int, [_h, C.POINTER(C.c_void_p)]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

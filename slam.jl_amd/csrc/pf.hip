@@ -1,0 +1,703 @@
+// pf.hip -- K9..K12: the FastSLAM-1.0 particle path (known correspondences) and its C ABI.
+//
+// The reference has NO particle-filter code, only the types Particle / PFSlamState
+// (src/common.jl:14-20,31-34; README.md:6 "FastSLAM is ongoing").  The algorithm is the one
+// specified in SURVEY.md 8a rows F1-F4 from the reference's EKF building blocks:
+//   F1  control noise per particle (sim/sim-utils.jl:35-38) + pose update (src/ekf.jl:39-41)
+//   F2  per-landmark 2x2 EKF: feature block of predict_observation (src/common.jl:162) and the
+//       Cholesky-form update (src/ekf.jl:67-75) restricted to that block; w *= N(v; 0, S)
+//   F3  new landmark (src/ekf.jl:94-103,112 without the vehicle term)
+//   F4  normalisation, Neff, systematic resampling
+//
+// Layout (HBM): structure of arrays, particle index fastest --
+//   pose[3][n], logw[n], lm[max_landmarks][5][n]  with 5 = (x, y, Pxx, Pxy, Pyy)
+// so a known-correspondence update streams five fully coalesced rows per observed landmark.
+// The reference's Particle type is an array of heap objects (layout hint only).
+//
+// Sharding: one handle owns the global particle ids [first, first + n).  Random numbers are
+// Philox4x32-10 keyed by (seed, step, global id): results do not depend on the number of GPUs.
+// The only cross-particle steps are three scalars per step (max, sum w, sum w^2) and, on a
+// resampling step, the log-weights of all particles; both collectives are issued by the host
+// (torch.distributed over RCCL), this library provides the local pieces.
+#include <stdlib.h>
+
+#include <vector>
+
+#include "common.h"
+
+#define PF_PI 3.14159265358979323846
+
+struct slam_pf {
+    int dtype, device;
+    size_t esz;
+    int64_t n, n_global, first;
+    int nl;
+    uint64_t seed;
+    uint32_t step;
+    hipStream_t stream;
+    void* pose[2];       // [3][n]
+    void* lm[2];         // [nl][5][n]
+    void* logw;          // [n]
+    int cur;             // which of the two state buffers is live
+    std::vector<char> seen;
+    int32_t* d_ids;      // [ocap] observation landmark ids (0-based) ; bit 30 marks "new landmark"
+    double* d_obs;       // [ocap][2]
+    int32_t* h_ids;
+    double* h_obs;
+    int ocap;
+    double* d_part;      // [blocks][4] reduction partials
+    double* d_out;       // [8]
+    double* h_out;       // pinned [8]
+    double* d_cdf;       // [n_global]
+    double* d_bsum;      // [scan blocks]
+    int32_t* d_src;      // [n] gather source: >= 0 local index, < 0: -(recv position + 1)
+    int red_blocks;
+};
+
+namespace {
+
+// ---- Philox4x32-10 -------------------------------------------------------------------------------
+__device__ inline void philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                              uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = 0xD2511F53ull * c0;
+        const uint64_t p1 = 0xCD9E8D57ull * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+template <typename T>
+__device__ inline T u01(uint32_t x) {      // 24 random bits, offset by half a step: never 0 or 1
+    return ((T)(x >> 8) + (T)0.5) * (T)(1.0 / 16777216.0);
+}
+
+template <typename T>
+__device__ inline void normals2(uint64_t gid, uint32_t step, uint32_t stream, uint64_t seed, T& e1, T& e2) {
+    uint32_t r[4];
+    philox((uint32_t)gid, (uint32_t)(gid >> 32), step, stream, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const T u1 = u01<T>(r[0]), u2 = u01<T>(r[1]);
+    const T rad = sqrt((T)-2.0 * log(u1));
+    const T ang = (T)(2.0 * PF_PI) * u2;
+    e1 = rad * cos(ang);
+    e2 = rad * sin(ang);
+}
+
+template <typename T>
+__device__ inline T wrap_pi(T a) {         // mpi_to_pi, src/common.jl:102-110: single conditional wrap
+    if (a > (T)PF_PI) return a - (T)(2.0 * PF_PI);
+    if (a < (T)-PF_PI) return a + (T)(2.0 * PF_PI);
+    return a;
+}
+
+constexpr uint32_t STREAM_PREDICT = 0, STREAM_INIT = 1;
+
+// ---- F1 ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pf_predict_kernel(T* __restrict__ pose, int64_t n, int64_t first, uint32_t step,
+                                                          uint64_t seed, T V, T G, T wheelbase, T sigV, T sigG, T dt) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    T e1, e2;
+    normals2<T>((uint64_t)(first + p), step, STREAM_PREDICT, seed, e1, e2);
+    const T Vn = V + sigV * e1;                       // sim/sim-utils.jl:36
+    const T Gn = G + sigG * e2;                       // :37
+    const T x = pose[p], y = pose[n + p], phi = pose[2 * n + p];
+    pose[p] = x + Vn * dt * cos(Gn + phi);            // src/ekf.jl:39-41
+    pose[n + p] = y + Vn * dt * sin(Gn + phi);
+    pose[2 * n + p] = wrap_pi<T>(phi + Vn * dt * sin(Gn) / wheelbase);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pf_set_pose_kernel(T* __restrict__ pose, T* __restrict__ logw, int64_t n, T x, T y,
+                                                           T phi, T lw) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    pose[p] = x; pose[n + p] = y; pose[2 * n + p] = phi;
+    logw[p] = lw;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pf_init_lm_kernel(T* __restrict__ lm, int64_t n, int64_t first, uint64_t seed,
+                                                          const double* __restrict__ xy, int nl, T var, T jitter) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    for (int l = 0; l < nl; ++l) {
+        T e1, e2;
+        normals2<T>((uint64_t)(first + p), (uint32_t)l, STREAM_INIT, seed, e1, e2);
+        T* row = lm + (size_t)l * 5 * n + p;
+        row[0] = (T)xy[2 * l] + jitter * e1;
+        row[n] = (T)xy[2 * l + 1] + jitter * e2;
+        row[2 * n] = var;
+        row[3 * n] = (T)0;
+        row[4 * n] = var;
+    }
+}
+
+// ---- F2 / F3 -------------------------------------------------------------------------------------
+constexpr int32_t NEW_FLAG = 1 << 30;
+
+template <typename T>
+__global__ __launch_bounds__(256) void pf_update_kernel(const T* __restrict__ pose, T* __restrict__ lm, T* __restrict__ logw,
+                                                         int64_t n, const double* __restrict__ z, const int32_t* __restrict__ ids,
+                                                         int m, T R00, T R10, T R01, T R11) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const T x = pose[p], y = pose[n + p], phi = pose[2 * n + p];
+    T lw = logw[p];
+    for (int i = 0; i < m; ++i) {
+        const int32_t code = ids[i];
+        const int l = code & (NEW_FLAG - 1);
+        const T r = (T)z[2 * i], b = (T)z[2 * i + 1];
+        T* row = lm + (size_t)l * 5 * n + p;
+        if (code & NEW_FLAG) {                         // F3: src/ekf.jl:94-103,112 without the pose term
+            const T s = sin(phi + b), c = cos(phi + b);
+            const T g00 = c, g01 = -r * s, g10 = s, g11 = r * c;
+            const T a00 = g00 * R00 + g01 * R10, a01 = g00 * R01 + g01 * R11;
+            const T a10 = g10 * R00 + g11 * R10, a11 = g10 * R01 + g11 * R11;
+            row[0] = x + r * c;
+            row[n] = y + r * s;
+            row[2 * n] = a00 * g00 + a01 * g01;
+            row[3 * n] = a00 * g10 + a01 * g11;
+            row[4 * n] = a10 * g10 + a11 * g11;
+            continue;
+        }
+        const T lx = row[0], ly = row[n], pxx = row[2 * n], pxy = row[3 * n], pyy = row[4 * n];
+        const T dx = lx - x, dy = ly - y;
+        const T d2 = dx * dx + dy * dy;
+        const T d = sqrt(d2);
+        const T v0 = r - d;                                               // src/ekf.jl:58
+        const T v1 = wrap_pi<T>(b - (atan2(dy, dx) - phi));
+        const T h00 = dx / d, h01 = dy / d, h10 = -dy / d2, h11 = dx / d2;  // src/common.jl:162
+        const T t00 = pxx * h00 + pxy * h01, t01 = pxx * h10 + pxy * h11;  // PHt
+        const T t10 = pxy * h00 + pyy * h01, t11 = pxy * h10 + pyy * h11;
+        const T s00 = h00 * t00 + h01 * t10 + R00;                         // S = Hf PHt + R (:68)
+        const T s01a = h00 * t01 + h01 * t11 + R01;
+        const T s10a = h10 * t00 + h11 * t10 + R10;
+        const T s11 = h10 * t01 + h11 * t11 + R11;
+        const T s01 = (T)0.5 * (s01a + s10a);                             // (:69)
+        const T u00 = sqrt(s00), u01 = s01 / u00;                         // chol(S), upper (:70)
+        const T u11 = sqrt(s11 - u01 * u01);
+        const T c00 = (T)1 / u00, c01 = -u01 / (u00 * u11), c11 = (T)1 / u11;   // C = inv(U)
+        const T w00 = t00 * c00, w01 = t00 * c01 + t01 * c11;             // W1 = PHt C (:71)
+        const T w10 = t10 * c00, w11 = t10 * c01 + t11 * c11;
+        const T y0 = c00 * v0, y1 = c01 * v0 + c11 * v1;                  // C' v
+        row[0] = lx + w00 * y0 + w01 * y1;                                // x += W v (:72,:74)
+        row[n] = ly + w10 * y0 + w11 * y1;
+        row[2 * n] = pxx - (w00 * w00 + w01 * w01);                       // P -= W1 W1' (:75)
+        row[3 * n] = pxy - (w00 * w10 + w01 * w11);
+        row[4 * n] = pyy - (w10 * w10 + w11 * w11);
+        lw += (T)-0.5 * (y0 * y0 + y1 * y1) - log(u00 * u11) - (T)1.8378770664093453;   // log(2 pi)
+    }
+    logw[p] = lw;
+}
+
+// ---- F4: reductions ------------------------------------------------------------------------------
+__device__ inline double block_reduce(double v, double* sh, bool is_max) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double o = __shfl_xor(v, off);
+        v = is_max ? fmax(v, o) : v + o;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double r = sh[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = is_max ? fmax(r, sh[w]) : r + sh[w];
+    return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pf_max_kernel(const T* __restrict__ logw, int64_t n, double* __restrict__ part) {
+    __shared__ double sh[4];
+    double m = -__builtin_inf();
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x)
+        m = fmax(m, (double)logw[p]);
+    m = block_reduce(m, sh, true);
+    if (threadIdx.x == 0) part[blockIdx.x] = m;
+}
+
+// pass 2: with the local max known: sums of exp(logw - max), exp(2(logw - max)) and the weighted pose sums
+template <typename T>
+__global__ __launch_bounds__(256) void pf_sums_kernel(const T* __restrict__ logw, const T* __restrict__ pose, int64_t n,
+                                                       const double* __restrict__ maxpart, int nmax, double shift_is_max,
+                                                       double* __restrict__ part) {
+    __shared__ double sh[4];
+    double mx = -__builtin_inf();
+    for (int i = 0; i < nmax; ++i) mx = fmax(mx, maxpart[i]);
+    const double shift = shift_is_max != 0.0 ? mx : 0.0;
+    double s1 = 0, s2 = 0, sx = 0, sy = 0, ss = 0, sc = 0;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const double e = exp((double)logw[p] - shift);
+        s1 += e;
+        s2 += e * e;
+        const double ph = (double)pose[2 * n + p];
+        sx += e * (double)pose[p];
+        sy += e * (double)pose[n + p];
+        ss += e * sin(ph);
+        sc += e * cos(ph);
+    }
+    s1 = block_reduce(s1, sh, false); s2 = block_reduce(s2, sh, false);
+    sx = block_reduce(sx, sh, false); sy = block_reduce(sy, sh, false);
+    ss = block_reduce(ss, sh, false); sc = block_reduce(sc, sh, false);
+    if (threadIdx.x == 0) {
+        double* o = part + (size_t)blockIdx.x * 8;
+        o[0] = mx; o[1] = s1; o[2] = s2; o[3] = sx; o[4] = sy; o[5] = ss; o[6] = sc;
+    }
+}
+
+__global__ void pf_fold_kernel(const double* __restrict__ part, int nblocks, double* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double acc[7] = {part[0], 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < nblocks; ++b)
+        for (int q = 1; q < 7; ++q) acc[q] += part[(size_t)b * 8 + q];
+    for (int q = 0; q < 7; ++q) out[q] = acc[q];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pf_fill_kernel(T* __restrict__ a, int64_t n, T v) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) a[p] = v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pf_shift_kernel(T* __restrict__ logw, int64_t n, T shift) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) logw[p] -= shift;
+}
+
+// ---- F4: systematic resampling over the GLOBAL weights -----------------------------------------------
+constexpr int SCAN_BLOCK = 1024;
+
+// per-block inclusive scan of w = exp(logw - max) (double) + block totals
+template <typename T>
+__global__ __launch_bounds__(SCAN_BLOCK) void pf_scan1_kernel(const T* __restrict__ logw_all, int64_t n, double gmax,
+                                                               double* __restrict__ cdf, double* __restrict__ bsum) {
+    __shared__ double sh[SCAN_BLOCK];
+    const int64_t i = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    sh[threadIdx.x] = i < n ? exp((double)logw_all[i] - gmax) : 0.0;
+    __syncthreads();
+    for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
+        const double v = threadIdx.x >= off ? sh[threadIdx.x - off] : 0.0;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (i < n) cdf[i] = sh[threadIdx.x];
+    if (threadIdx.x == SCAN_BLOCK - 1) bsum[blockIdx.x] = sh[threadIdx.x];
+}
+
+// exclusive scan of the block totals, in place, one thread (<= a few hundred blocks)
+__global__ void pf_scan2_kernel(double* __restrict__ bsum, int nb) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double run = 0;
+    for (int b = 0; b < nb; ++b) {
+        const double v = bsum[b];
+        bsum[b] = run;
+        run += v;
+    }
+    bsum[nb] = run;                      // grand total
+}
+
+// ancestor of global slot g = first j with cdf[j] >= (g + u0)/N * total   (binary search)
+__global__ __launch_bounds__(256) void pf_ancestor_kernel(const double* __restrict__ cdf, const double* __restrict__ bsum,
+                                                           int nb, int64_t n_global, int64_t first, int64_t n, double u0,
+                                                           int32_t* __restrict__ anc) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const double total = bsum[nb];
+    const double target = ((double)(first + p) + u0) / (double)n_global * total;
+    int64_t lo = 0, hi = n_global - 1;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const double c = cdf[mid] + bsum[mid / SCAN_BLOCK];
+        if (c >= target) hi = mid; else lo = mid + 1;
+    }
+    anc[p] = (int32_t)lo;
+}
+
+// gather source per local slot: >= 0 local index, < 0: -(position in the sorted remote id list + 1)
+__global__ __launch_bounds__(256) void pf_src_kernel(const int32_t* __restrict__ anc, int64_t n, int64_t first,
+                                                      const int32_t* __restrict__ remote_ids, int nremote,
+                                                      int32_t* __restrict__ src) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int64_t a = anc[p];
+    if (a >= first && a < first + n) { src[p] = (int32_t)(a - first); return; }
+    int lo = 0, hi = nremote - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (remote_ids[mid] >= a) hi = mid; else lo = mid + 1;
+    }
+    src[p] = -(lo + 1);
+}
+
+// new[row][p] = old[row][src] or remote[row][pos];  grid.y = row (3 pose rows, then landmark rows)
+template <typename T>
+__global__ __launch_bounds__(256) void pf_gather_kernel(const T* __restrict__ pose_old, const T* __restrict__ lm_old,
+                                                         T* __restrict__ pose_new, T* __restrict__ lm_new, int64_t n,
+                                                         const int32_t* __restrict__ src, const T* __restrict__ remote,
+                                                         int nremote) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int row = blockIdx.y;
+    const int32_t s = src[p];
+    const T* old_row = row < 3 ? pose_old + (size_t)row * n : lm_old + (size_t)(row - 3) * n;
+    T* new_row = row < 3 ? pose_new + (size_t)row * n : lm_new + (size_t)(row - 3) * n;
+    new_row[p] = s >= 0 ? old_row[s] : remote[(size_t)row * nremote + (-s - 1)];
+}
+
+// records[row][c] = state[row][idx[c]]
+template <typename T>
+__global__ __launch_bounds__(256) void pf_pack_kernel(const T* __restrict__ pose, const T* __restrict__ lm, int64_t n,
+                                                       const int32_t* __restrict__ idx, int cnt, T* __restrict__ rec) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cnt) return;
+    const int row = blockIdx.y;
+    const T* src_row = row < 3 ? pose + (size_t)row * n : lm + (size_t)(row - 3) * n;
+    rec[(size_t)row * cnt + c] = src_row[idx[c]];
+}
+
+template <typename P>
+int pf_alloc(P** p, size_t bytes, hipStream_t s) {
+    *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    HIP_TRY(hipMalloc((void**)p, bytes));
+    HIP_TRY(hipMemsetAsync(*p, 0, bytes, s));
+    return SLAM_OK;
+}
+
+inline int grid_for(int64_t n) { return (int)((n + 255) / 256); }
+
+}  // namespace
+
+#define PF_DISPATCH(h, CALL_F, CALL_D) \
+    do {                               \
+        if ((h)->dtype == SLAM_F32) {  \
+            typedef float T;           \
+            CALL_F;                    \
+        } else {                       \
+            typedef double T;          \
+            CALL_D;                    \
+        }                              \
+    } while (0)
+
+extern "C" int slam_pf_destroy(slam_pf_t h) {
+    if (!h) return SLAM_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (int b = 0; b < 2; ++b) {
+        if (h->pose[b]) (void)hipFree(h->pose[b]);
+        if (h->lm[b]) (void)hipFree(h->lm[b]);
+    }
+    void* devs[] = {h->logw, h->d_ids, h->d_obs, h->d_part, h->d_out, h->d_cdf, h->d_bsum, h->d_src};
+    for (void* p : devs)
+        if (p) (void)hipFree(p);
+    if (h->h_ids) (void)hipHostFree(h->h_ids);
+    if (h->h_obs) (void)hipHostFree(h->h_obs);
+    if (h->h_out) (void)hipHostFree(h->h_out);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return SLAM_OK;
+}
+
+static int pf_create_impl(slam_pf* h) {
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    int rc;
+    const size_t n = (size_t)h->n;
+    for (int b = 0; b < 2; ++b) {
+        if ((rc = pf_alloc(&h->pose[b], h->esz * 3 * n, h->stream))) return rc;
+        if ((rc = pf_alloc(&h->lm[b], h->esz * 5 * n * (size_t)h->nl, h->stream))) return rc;
+    }
+    if ((rc = pf_alloc(&h->logw, h->esz * n, h->stream))) return rc;
+    h->ocap = 1024;
+    if ((rc = pf_alloc(&h->d_ids, sizeof(int32_t) * h->ocap, h->stream))) return rc;
+    if ((rc = pf_alloc(&h->d_obs, sizeof(double) * 2 * h->ocap, h->stream))) return rc;
+    h->red_blocks = 256;
+    if ((rc = pf_alloc(&h->d_part, sizeof(double) * 9 * h->red_blocks, h->stream))) return rc;
+    if ((rc = pf_alloc(&h->d_out, sizeof(double) * 8, h->stream))) return rc;
+    if ((rc = pf_alloc(&h->d_cdf, sizeof(double) * (size_t)h->n_global, h->stream))) return rc;
+    const size_t nb = ((size_t)h->n_global + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    if ((rc = pf_alloc(&h->d_bsum, sizeof(double) * (nb + 1), h->stream))) return rc;
+    if ((rc = pf_alloc(&h->d_src, sizeof(int32_t) * n, h->stream))) return rc;
+    HIP_TRY(hipHostMalloc((void**)&h->h_ids, sizeof(int32_t) * h->ocap, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&h->h_obs, sizeof(double) * 2 * h->ocap, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&h->h_out, sizeof(double) * 8, hipHostMallocDefault));
+    // uniform weights over the GLOBAL particle set
+    const double lw = -log((double)h->n_global);
+    PF_DISPATCH(h,
+                hipLaunchKernelGGL(pf_set_pose_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->pose[0],
+                                   (T*)h->logw, h->n, (T)0, (T)0, (T)0, (T)lw),
+                hipLaunchKernelGGL(pf_set_pose_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->pose[0],
+                                   (T*)h->logw, h->n, (T)0, (T)0, (T)0, (T)lw));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SLAM_OK;
+}
+
+extern "C" int slam_pf_create(slam_pf_t* out, int dtype, int64_t n_local, int64_t n_global, int64_t first_id,
+                              int max_landmarks, int device, uint64_t seed) {
+    ARG_CHECK(out != nullptr, "handle pointer is null");
+    *out = nullptr;
+    ARG_CHECK(dtype == SLAM_F32 || dtype == SLAM_F64, "dtype must be SLAM_F32 or SLAM_F64");
+    ARG_CHECK(n_local > 0 && n_global >= n_local && first_id >= 0 && first_id + n_local <= n_global,
+              "particle range [first, first + n_local) must lie inside [0, n_global)");
+    ARG_CHECK(n_global < (1ll << 31), "n_global must fit 31 bits");
+    ARG_CHECK(max_landmarks > 0 && max_landmarks < (1 << 20), "max_landmarks out of range");
+    const int ndev = slam_device_count();
+    if (ndev <= 0) {
+        slam_set_error("no HIP device available: libslamhip has no CPU fallback");
+        return SLAM_E_HIP;
+    }
+    ARG_CHECK(device >= 0 && device < ndev, "device index out of range");
+    slam_pf* h = new slam_pf();
+    h->dtype = dtype; h->device = device; h->esz = dtype == SLAM_F32 ? 4 : 8;
+    h->n = n_local; h->n_global = n_global; h->first = first_id; h->nl = max_landmarks;
+    h->seed = seed; h->step = 0; h->cur = 0; h->stream = nullptr;
+    h->pose[0] = h->pose[1] = h->lm[0] = h->lm[1] = h->logw = nullptr;
+    h->d_ids = nullptr; h->d_obs = nullptr; h->h_ids = nullptr; h->h_obs = nullptr; h->ocap = 0;
+    h->d_part = h->d_out = h->h_out = h->d_cdf = h->d_bsum = nullptr; h->d_src = nullptr;
+    h->seen.assign(max_landmarks, 0);
+    const int rc = pf_create_impl(h);
+    if (rc) { slam_pf_destroy(h); return rc; }
+    *out = h;
+    return SLAM_OK;
+}
+
+extern "C" int slam_pf_set_pose(slam_pf_t h, const double pose[3]) {
+    ARG_CHECK(h != nullptr && pose != nullptr, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const double lw = -log((double)h->n_global);
+    PF_DISPATCH(h,
+                hipLaunchKernelGGL(pf_set_pose_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream,
+                                   (T*)h->pose[h->cur], (T*)h->logw, h->n, (T)pose[0], (T)pose[1], (T)pose[2], (T)lw),
+                hipLaunchKernelGGL(pf_set_pose_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream,
+                                   (T*)h->pose[h->cur], (T*)h->logw, h->n, (T)pose[0], (T)pose[1], (T)pose[2], (T)lw));
+    HIP_TRY(hipGetLastError());
+    return SLAM_OK;
+}
+
+extern "C" int slam_pf_init_landmarks(slam_pf_t h, const double* lm_xy, int nl, double var, double jitter_sigma) {
+    ARG_CHECK(h != nullptr && lm_xy != nullptr, "null argument");
+    ARG_CHECK(nl >= 0 && nl <= h->nl, "more landmarks than capacity");
+    if (nl == 0) return SLAM_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    double* d_xy = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_xy, sizeof(double) * 2 * nl));
+    HIP_TRY(hipMemcpyAsync(d_xy, lm_xy, sizeof(double) * 2 * nl, hipMemcpyHostToDevice, h->stream));
+    PF_DISPATCH(h,
+                hipLaunchKernelGGL(pf_init_lm_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->lm[h->cur],
+                                   h->n, h->first, h->seed, d_xy, nl, (T)var, (T)jitter_sigma),
+                hipLaunchKernelGGL(pf_init_lm_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->lm[h->cur],
+                                   h->n, h->first, h->seed, d_xy, nl, (T)var, (T)jitter_sigma));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    (void)hipFree(d_xy);
+    for (int l = 0; l < nl; ++l) h->seen[l] = 1;
+    return SLAM_OK;
+}
+
+extern "C" int slam_pf_predict(slam_pf_t h, double V, double G, double wheelbase, const double Q[4], double dt) {
+    ARG_CHECK(h != nullptr && Q != nullptr, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const double sV = sqrt(Q[0]), sG = sqrt(Q[3]);
+    PF_DISPATCH(h,
+                hipLaunchKernelGGL(pf_predict_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->pose[h->cur],
+                                   h->n, h->first, h->step, h->seed, (T)V, (T)G, (T)wheelbase, (T)sV, (T)sG, (T)dt),
+                hipLaunchKernelGGL(pf_predict_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->pose[h->cur],
+                                   h->n, h->first, h->step, h->seed, (T)V, (T)G, (T)wheelbase, (T)sV, (T)sG, (T)dt));
+    HIP_TRY(hipGetLastError());
+    h->step += 1;
+    return SLAM_OK;
+}
+
+extern "C" int slam_pf_update_known(slam_pf_t h, const double* z, const int32_t* ids, int m, const double R[4]) {
+    ARG_CHECK(h != nullptr, "null handle");
+    ARG_CHECK(m >= 0, "m < 0");
+    if (m == 0) return SLAM_OK;
+    ARG_CHECK(z != nullptr && ids != nullptr && R != nullptr, "null argument");
+    ARG_CHECK(m <= h->ocap, "too many observations in one call (max 1024)");
+    for (int i = 0; i < m; ++i) ARG_CHECK(ids[i] >= 1 && ids[i] <= h->nl, "landmark id out of range");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));          // pinned staging may still be in flight
+    for (int i = 0; i < m; ++i) {
+        const int l = ids[i] - 1;
+        h->h_ids[i] = l | (h->seen[l] ? 0 : NEW_FLAG);
+        h->seen[l] = 1;
+        h->h_obs[2 * i] = z[2 * i];
+        h->h_obs[2 * i + 1] = z[2 * i + 1];
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_ids, h->h_ids, sizeof(int32_t) * m, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_obs, h->h_obs, sizeof(double) * 2 * m, hipMemcpyHostToDevice, h->stream));
+    PF_DISPATCH(h,
+                hipLaunchKernelGGL(pf_update_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream,
+                                   (const T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->d_obs, h->d_ids, m,
+                                   (T)R[0], (T)R[1], (T)R[2], (T)R[3]),
+                hipLaunchKernelGGL(pf_update_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream,
+                                   (const T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->d_obs, h->d_ids, m,
+                                   (T)R[0], (T)R[1], (T)R[2], (T)R[3]));
+    HIP_TRY(hipGetLastError());
+    return SLAM_OK;
+}
+
+// out = {max logw, sum exp(logw - max), sum exp(2(logw - max)),  sum w x, sum w y, sum w sin phi, sum w cos phi}
+// with w = exp(logw - shift), shift = local max if relative_to_max else 0.
+static int pf_stats(slam_pf* h, int relative_to_max, double out[7]) {
+    HIP_TRY(hipSetDevice(h->device));
+    const int nb = h->red_blocks;
+    double* maxpart = h->d_part;                 // [nb]
+    double* sums = h->d_part + nb;               // [nb][8]
+    PF_DISPATCH(h,
+                hipLaunchKernelGGL(pf_max_kernel<T>, dim3(nb), dim3(256), 0, h->stream, (const T*)h->logw, h->n, maxpart),
+                hipLaunchKernelGGL(pf_max_kernel<T>, dim3(nb), dim3(256), 0, h->stream, (const T*)h->logw, h->n, maxpart));
+    PF_DISPATCH(h,
+                hipLaunchKernelGGL(pf_sums_kernel<T>, dim3(nb), dim3(256), 0, h->stream, (const T*)h->logw,
+                                   (const T*)h->pose[h->cur], h->n, maxpart, nb, relative_to_max ? 1.0 : 0.0, sums),
+                hipLaunchKernelGGL(pf_sums_kernel<T>, dim3(nb), dim3(256), 0, h->stream, (const T*)h->logw,
+                                   (const T*)h->pose[h->cur], h->n, maxpart, nb, relative_to_max ? 1.0 : 0.0, sums));
+    hipLaunchKernelGGL(pf_fold_kernel, dim3(1), dim3(64), 0, h->stream, sums, nb, h->d_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h->h_out, h->d_out, sizeof(double) * 7, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 7; ++i) out[i] = h->h_out[i];
+    return SLAM_OK;
+}
+
+extern "C" int slam_pf_weight_stats(slam_pf_t h, double out[3]) {
+    ARG_CHECK(h != nullptr && out != nullptr, "null argument");
+    double s[7];
+    const int rc = pf_stats(h, 1, s);
+    if (rc) return rc;
+    out[0] = s[0]; out[1] = s[1]; out[2] = s[2];
+    return SLAM_OK;
+}
+
+extern "C" int slam_pf_mean_pose_sums(slam_pf_t h, double out[4]) {
+    ARG_CHECK(h != nullptr && out != nullptr, "null argument");
+    double s[7];
+    const int rc = pf_stats(h, 0, s);
+    if (rc) return rc;
+    out[0] = s[3]; out[1] = s[4]; out[2] = s[5]; out[3] = s[6];
+    return SLAM_OK;
+}
+
+extern "C" int slam_pf_normalize(slam_pf_t h, double gmax, double gsum) {
+    ARG_CHECK(h != nullptr, "null handle");
+    ARG_CHECK(gsum > 0.0, "gsum must be positive");
+    HIP_TRY(hipSetDevice(h->device));
+    const double shift = gmax + log(gsum);
+    PF_DISPATCH(h,
+                hipLaunchKernelGGL(pf_shift_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->logw, h->n, (T)shift),
+                hipLaunchKernelGGL(pf_shift_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->logw, h->n, (T)shift));
+    HIP_TRY(hipGetLastError());
+    return SLAM_OK;
+}
+
+extern "C" int slam_pf_copy_logw(slam_pf_t h, void* d_dst) {
+    ARG_CHECK(h != nullptr && d_dst != nullptr, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(d_dst, h->logw, h->esz * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SLAM_OK;
+}
+
+extern "C" int slam_pf_ancestors(slam_pf_t h, const void* d_logw_all, double gmax, double u0, int32_t* d_anc) {
+    ARG_CHECK(h != nullptr && d_logw_all != nullptr && d_anc != nullptr, "null argument");
+    ARG_CHECK(u0 >= 0.0 && u0 < 1.0, "u0 must be in [0, 1)");
+    HIP_TRY(hipSetDevice(h->device));
+    const int nb = (int)((h->n_global + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    PF_DISPATCH(h,
+                hipLaunchKernelGGL(pf_scan1_kernel<T>, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, (const T*)d_logw_all,
+                                   h->n_global, gmax, h->d_cdf, h->d_bsum),
+                hipLaunchKernelGGL(pf_scan1_kernel<T>, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, (const T*)d_logw_all,
+                                   h->n_global, gmax, h->d_cdf, h->d_bsum));
+    hipLaunchKernelGGL(pf_scan2_kernel, dim3(1), dim3(64), 0, h->stream, h->d_bsum, nb);
+    hipLaunchKernelGGL(pf_ancestor_kernel, dim3(grid_for(h->n)), dim3(256), 0, h->stream, h->d_cdf, h->d_bsum, nb, h->n_global,
+                       h->first, h->n, u0, d_anc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SLAM_OK;
+}
+
+extern "C" int slam_pf_record_rows(slam_pf_t h, int* rows) {
+    ARG_CHECK(h != nullptr && rows != nullptr, "null argument");
+    *rows = 3 + 5 * h->nl;
+    return SLAM_OK;
+}
+
+extern "C" int slam_pf_pack(slam_pf_t h, const int32_t* d_local_idx, int cnt, void* d_records) {
+    ARG_CHECK(h != nullptr, "null handle");
+    ARG_CHECK(cnt >= 0, "cnt < 0");
+    if (cnt == 0) return SLAM_OK;
+    ARG_CHECK(d_local_idx != nullptr && d_records != nullptr, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const dim3 grid((cnt + 255) / 256, 3 + 5 * h->nl);
+    PF_DISPATCH(h,
+                hipLaunchKernelGGL(pf_pack_kernel<T>, grid, dim3(256), 0, h->stream, (const T*)h->pose[h->cur],
+                                   (const T*)h->lm[h->cur], h->n, d_local_idx, cnt, (T*)d_records),
+                hipLaunchKernelGGL(pf_pack_kernel<T>, grid, dim3(256), 0, h->stream, (const T*)h->pose[h->cur],
+                                   (const T*)h->lm[h->cur], h->n, d_local_idx, cnt, (T*)d_records));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SLAM_OK;
+}
+
+extern "C" int slam_pf_resample_apply(slam_pf_t h, const int32_t* d_anc, const int32_t* d_remote_ids, int nremote,
+                                      const void* d_remote_records) {
+    ARG_CHECK(h != nullptr && d_anc != nullptr, "null argument");
+    ARG_CHECK(nremote >= 0, "nremote < 0");
+    ARG_CHECK(nremote == 0 || (d_remote_ids != nullptr && d_remote_records != nullptr), "remote buffers missing");
+    HIP_TRY(hipSetDevice(h->device));
+    hipLaunchKernelGGL(pf_src_kernel, dim3(grid_for(h->n)), dim3(256), 0, h->stream, d_anc, h->n, h->first, d_remote_ids,
+                       nremote, h->d_src);
+    const int nxt = h->cur ^ 1;
+    const dim3 grid(grid_for(h->n), 3 + 5 * h->nl);
+    PF_DISPATCH(h,
+                hipLaunchKernelGGL(pf_gather_kernel<T>, grid, dim3(256), 0, h->stream, (const T*)h->pose[h->cur],
+                                   (const T*)h->lm[h->cur], (T*)h->pose[nxt], (T*)h->lm[nxt], h->n, h->d_src,
+                                   (const T*)d_remote_records, nremote),
+                hipLaunchKernelGGL(pf_gather_kernel<T>, grid, dim3(256), 0, h->stream, (const T*)h->pose[h->cur],
+                                   (const T*)h->lm[h->cur], (T*)h->pose[nxt], (T*)h->lm[nxt], h->n, h->d_src,
+                                   (const T*)d_remote_records, nremote));
+    const double lw = -log((double)h->n_global);      // uniform weights again
+    PF_DISPATCH(h,
+                hipLaunchKernelGGL(pf_fill_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->logw, h->n, (T)lw),
+                hipLaunchKernelGGL(pf_fill_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->logw, h->n, (T)lw));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->cur = nxt;
+    return SLAM_OK;
+}
+
+extern "C" int slam_pf_download(slam_pf_t h, void* pose, void* logw, void* lm) {
+    ARG_CHECK(h != nullptr, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t n = (size_t)h->n;
+    if (pose) HIP_TRY(hipMemcpyAsync(pose, h->pose[h->cur], h->esz * 3 * n, hipMemcpyDeviceToHost, h->stream));
+    if (logw) HIP_TRY(hipMemcpyAsync(logw, h->logw, h->esz * n, hipMemcpyDeviceToHost, h->stream));
+    if (lm) HIP_TRY(hipMemcpyAsync(lm, h->lm[h->cur], h->esz * 5 * n * (size_t)h->nl, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SLAM_OK;
+}
+
+extern "C" int slam_pf_sync(slam_pf_t h) {
+    ARG_CHECK(h != nullptr, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SLAM_OK;
+}
+
+extern "C" int slam_pf_stream(slam_pf_t h, void** stream) {
+    ARG_CHECK(h != nullptr && stream != nullptr, "null argument");
+    *stream = (void*)h->stream;
+    return SLAM_OK;
+}

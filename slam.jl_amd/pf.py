@@ -1,0 +1,323 @@
+"""FastSLAM-1.0 (known correspondences) on the GPU: ``PFSlamState`` and its sharded driver.
+
+The reference only declares the types ``Particle`` / ``PFSlamState`` (src/common.jl:14-20,31-34)
+and no particle-filter code (README.md:6); the algorithm is SURVEY.md 8a rows F1-F4.
+
+Two layers:
+
+* :class:`PFShard` -- one process's slice of the particles, a thin wrapper of the ``slam_pf_*``
+  C ABI (HIP kernels, SoA state resident in HBM).  No CPU fallback.
+* :class:`FastSLAM` -- the host logic that is the same for 1 and for G GPUs: per step an
+  all-reduce of three scalars (max log-weight, sum w, sum w^2) for normalisation and Neff; on a
+  resampling step an all-gather of the log-weights (the RCCL collective BASELINE.json names),
+  the same global systematic-resampling table on every rank, and an exchange of the particle
+  records whose ancestor lives on another rank.  It talks to the shard through a small protocol
+  (the methods of :class:`PFShard`) and to the other ranks through ``torch.distributed``
+  (``nccl`` = RCCL on the GPUs; the multi-process CPU tests drive the same logic over ``gloo``
+  with a NumPy shard that lives in the test-suite, never here).
+
+Random numbers are Philox4x32-10 keyed by (seed, step, global particle id): a run gives the same
+particles whatever the number of ranks.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from ._lib import SLAM_F32, SLAM_F64, check, lib
+from .ekf import _obs, _small, _ptr
+
+__all__ = ["PFShard", "PFSlamState", "FastSLAM", "philox_uniform"]
+
+_M0, _M1, _W0, _W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+STREAM_RESAMPLE = 2
+
+
+def philox_uniform(step: int, stream: int, seed: int) -> float:
+    """One U(0,1) from Philox4x32-10 with counter (0, 0, step, stream): the systematic-resampling
+    offset every rank derives for itself (host scalar; same generator as the kernels)."""
+    c = [0, 0, step & 0xFFFFFFFF, stream & 0xFFFFFFFF]
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    for _ in range(10):
+        p0, p1 = _M0 * c[0], _M1 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c[3] ^ k1) & 0xFFFFFFFF, p0 & 0xFFFFFFFF]
+        k0, k1 = (k0 + _W0) & 0xFFFFFFFF, (k1 + _W1) & 0xFFFFFFFF
+    return ((c[0] >> 8) + 0.5) / 16777216.0
+
+
+class PFShard:
+    """Global particle ids [first, first + n) of an n_global-particle filter on one GPU."""
+
+    def __init__(self, n_local, max_landmarks, seed, dtype="f32", first=0, n_global=None, device=0):
+        import torch
+        self.n = int(n_local)
+        self.first = int(first)
+        self.n_global = int(n_global if n_global is not None else n_local)
+        self.nl = int(max_landmarks)
+        self.seed = int(seed)
+        self.np_dtype = np.float32 if dtype == "f32" else np.float64
+        self.torch_dtype = torch.float32 if dtype == "f32" else torch.float64
+        self.device = torch.device("cuda", int(device))
+        self._h = C.c_void_p()
+        check(lib.slam_pf_create(C.byref(self._h), SLAM_F32 if dtype == "f32" else SLAM_F64, self.n, self.n_global,
+                                 self.first, self.nl, int(device), C.c_uint64(self.seed)))
+        rows = C.c_int()
+        check(lib.slam_pf_record_rows(self._h, C.byref(rows)))
+        self.rows = rows.value
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib.slam_pf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- filter operations ---------------------------------------------------------------------
+    def set_pose(self, pose):
+        p = np.ascontiguousarray(np.asarray(pose, dtype=np.float64).reshape(3))
+        check(lib.slam_pf_set_pose(self._h, _ptr(p)))
+
+    def init_landmarks(self, lm_xy, var, jitter_sigma):
+        xy = np.ascontiguousarray(np.asarray(lm_xy, dtype=np.float64).reshape(-1, 2))
+        check(lib.slam_pf_init_landmarks(self._h, _ptr(xy), xy.shape[0], float(var), float(jitter_sigma)))
+
+    def predict(self, V, G, wheelbase, Q, dt):
+        q = _small(Q)
+        check(lib.slam_pf_predict(self._h, float(V), float(G), float(wheelbase), _ptr(q), float(dt)))
+
+    def update_known(self, z, ids, R):
+        zp = _obs(z)
+        idv = np.ascontiguousarray(np.asarray(ids, dtype=np.int32).reshape(-1))
+        if idv.shape[0] != zp.shape[0]:
+            raise ValueError("ids and z disagree on the number of observations")
+        if zp.shape[0] == 0:
+            return
+        r = _small(R)
+        check(lib.slam_pf_update_known(self._h, _ptr(zp), _ptr(idv, C.c_int32), zp.shape[0], _ptr(r)))
+
+    def weight_stats(self):
+        out = np.empty(3)
+        check(lib.slam_pf_weight_stats(self._h, _ptr(out)))
+        return float(out[0]), float(out[1]), float(out[2])
+
+    def normalize(self, gmax, gsum):
+        check(lib.slam_pf_normalize(self._h, float(gmax), float(gsum)))
+
+    def mean_pose_sums(self):
+        out = np.empty(4)
+        check(lib.slam_pf_mean_pose_sums(self._h, _ptr(out)))
+        return out
+
+    # -- resampling pieces (torch tensors on this shard's device) ---------------------------------
+    def logw_tensor(self):
+        import torch
+        t = torch.empty(self.n, dtype=self.torch_dtype, device=self.device)
+        check(lib.slam_pf_copy_logw(self._h, C.c_void_p(t.data_ptr())))
+        return t
+
+    def ancestors(self, logw_all, gmax, u0):
+        import torch
+        assert logw_all.is_cuda and logw_all.dtype == self.torch_dtype and logw_all.numel() == self.n_global
+        torch.cuda.synchronize(self.device)            # logw_all was produced on torch's stream
+        anc = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        check(lib.slam_pf_ancestors(self._h, C.c_void_p(logw_all.data_ptr()), float(gmax), float(u0),
+                                    C.c_void_p(anc.data_ptr())))
+        return anc
+
+    def pack(self, local_idx):
+        import torch
+        idx = local_idx.to(device=self.device, dtype=torch.int32).contiguous()
+        rec = torch.empty((self.rows, idx.numel()), dtype=self.torch_dtype, device=self.device)
+        if idx.numel():
+            torch.cuda.synchronize(self.device)
+            check(lib.slam_pf_pack(self._h, C.c_void_p(idx.data_ptr()), idx.numel(), C.c_void_p(rec.data_ptr())))
+        return rec
+
+    def resample_apply(self, anc, remote_ids, remote_records):
+        import torch
+        torch.cuda.synchronize(self.device)
+        nrem = 0 if remote_ids is None else int(remote_ids.numel())
+        if nrem:
+            ids = remote_ids.to(device=self.device, dtype=torch.int32).contiguous()
+            rec = remote_records.to(device=self.device, dtype=self.torch_dtype).contiguous()
+            assert rec.shape == (self.rows, nrem)
+            check(lib.slam_pf_resample_apply(self._h, C.c_void_p(anc.data_ptr()), C.c_void_p(ids.data_ptr()), nrem,
+                                             C.c_void_p(rec.data_ptr())))
+        else:
+            check(lib.slam_pf_resample_apply(self._h, C.c_void_p(anc.data_ptr()), None, 0, None))
+
+    # -- inspection ---------------------------------------------------------------------------------
+    def download(self, landmarks=True):
+        """(pose [3, n], logw [n], lm [nl, 5, n] or None) as NumPy arrays in the shard's dtype."""
+        pose = np.empty((3, self.n), dtype=self.np_dtype)
+        logw = np.empty(self.n, dtype=self.np_dtype)
+        lm = np.empty((self.nl, 5, self.n), dtype=self.np_dtype) if landmarks else None
+        check(lib.slam_pf_download(self._h, pose.ctypes.data, logw.ctypes.data, lm.ctypes.data if landmarks else None))
+        return pose, logw, lm
+
+    def sync(self):
+        check(lib.slam_pf_sync(self._h))
+
+
+class _SingleProcess:
+    """The world of one rank."""
+    rank, world = 0, 1
+
+    def allreduce_max(self, v):
+        return v
+
+    def allreduce_sum(self, vec):
+        return vec
+
+    def all_gather(self, t, n_global):
+        return t
+
+    def all_to_all_v(self, send, send_counts, recv_counts):
+        return send
+
+
+class TorchComm:
+    """torch.distributed (nccl = RCCL over xGMI on the GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, device):
+        import torch.distributed as dist
+        self.dist = dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.device = device
+
+    def allreduce_max(self, v):
+        import torch
+        t = torch.tensor([v], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def allreduce_sum(self, vec):
+        import torch
+        t = torch.tensor(list(vec), dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(x) for x in t.tolist()]
+
+    def all_gather(self, t, n_global):
+        import torch
+        out = torch.empty(n_global, dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(out, t.contiguous())       # equal slices: rank r owns [r*n, (r+1)*n)
+        return out
+
+    def all_to_all_v(self, send, send_counts, recv_counts):
+        """Rows of `send` (dim 0) are grouped by destination rank; returns the rows received, grouped by source."""
+        import torch
+        out = torch.empty((int(sum(recv_counts)),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        self.dist.all_to_all_single(out, send.contiguous(), [int(c) for c in recv_counts], [int(c) for c in send_counts])
+        return out
+
+
+class FastSLAM:
+    """Host logic of the particle filter, identical for one and for many ranks.
+
+    ``shard`` follows the :class:`PFShard` protocol; ``comm`` is ``None`` (single process) or a
+    :class:`TorchComm`.  Equal slices are assumed: rank r owns [r * n, (r + 1) * n).
+    """
+
+    def __init__(self, shard, comm=None, neff_frac=0.75):
+        self.shard = shard
+        self.comm = comm if comm is not None else _SingleProcess()
+        self.neff_frac = float(neff_frac)
+        self.resamples = 0
+        self.last_neff = float(shard.n_global)
+        assert shard.n * self.comm.world == shard.n_global and shard.first == self.comm.rank * shard.n, (
+            "ranks must own equal, contiguous slices in rank order")
+
+    def predict(self, V, G, wheelbase, Q, dt):
+        self.shard.predict(V, G, wheelbase, Q, dt)
+
+    def update_known(self, z, ids, R):
+        self.shard.update_known(z, ids, R)
+
+    def global_stats(self):
+        """(gmax, sum w, sum w^2) with w = exp(logw - gmax): one MAX and one SUM all-reduce of scalars."""
+        lmax, s1, s2 = self.shard.weight_stats()
+        gmax = self.comm.allreduce_max(lmax)
+        f = math.exp(lmax - gmax)
+        gs1, gs2 = self.comm.allreduce_sum([s1 * f, s2 * f * f])
+        return gmax, gs1, gs2
+
+    def normalize(self):
+        """Normalise the weights, return Neff = 1 / sum(w_normalised^2)."""
+        gmax, gs1, gs2 = self.global_stats()
+        self.shard.normalize(gmax, gs1)
+        self.last_neff = gs1 * gs1 / gs2
+        return self.last_neff
+
+    def resample(self):
+        """Systematic resampling over the global weights (call after normalize())."""
+        import torch
+        sh, comm = self.shard, self.comm
+        u0 = philox_uniform(self.resamples, STREAM_RESAMPLE, sh.seed)
+        logw_all = comm.all_gather(sh.logw_tensor(), sh.n_global)      # the all-gather of log-weights
+        gmax = float(logw_all.max().item())
+        anc = sh.ancestors(logw_all, gmax, u0)                          # global ancestor id per local slot, ascending
+        anc64 = anc.to(torch.int64)
+        owner = torch.div(anc64, sh.n, rounding_mode="floor")
+        remote = owner != comm.rank
+        need_ids = torch.unique(anc64[remote])                          # ascending global ids = grouped by owner rank
+        need_owner = torch.div(need_ids, sh.n, rounding_mode="floor")
+        req_counts = torch.bincount(need_owner, minlength=comm.world).to(torch.int64)
+        if comm.world > 1:
+            serve_counts = comm.all_to_all_v(req_counts.reshape(-1, 1), [1] * comm.world, [1] * comm.world).reshape(-1)
+            rc, sc = req_counts.tolist(), serve_counts.tolist()
+            serve_ids = comm.all_to_all_v(need_ids.reshape(-1, 1), rc, sc).reshape(-1)      # ids other ranks want from me
+            rec = sh.pack((serve_ids - sh.first).to(torch.int32))                            # [rows, n_serve]
+            got = comm.all_to_all_v(rec.t().contiguous(), sc, rc)                            # [n_need, rows], ascending ids
+            sh.resample_apply(anc, need_ids.to(torch.int32), got.t().contiguous())
+        else:
+            sh.resample_apply(anc, None, None)
+        self.resamples += 1
+        return int(need_ids.numel())
+
+    def step(self, V, G, wheelbase, Q, dt, z, ids, R, force_resample=None):
+        """predict + known-id updates + normalise + (Neff-triggered) resample.  Returns (Neff, resampled?)."""
+        self.predict(V, G, wheelbase, Q, dt)
+        self.update_known(z, ids, R)
+        neff = self.normalize()
+        do = force_resample if force_resample is not None else (neff < self.neff_frac * self.shard.n_global)
+        if do:
+            self.resample()
+        return neff, bool(do)
+
+    def mean_pose(self):
+        s = self.comm.allreduce_sum(list(self.shard.mean_pose_sums()))
+        return np.array([s[0], s[1], math.atan2(s[2], s[3])])       # weights are normalised: sums are means
+
+
+class PFSlamState(FastSLAM):
+    """``PFSlamState{T}`` (src/common.jl:31-34) as a device-resident, optionally sharded filter.
+
+    ``n`` particles in total; under ``torch.distributed`` every rank constructs it with the same
+    arguments and owns n / world of them on its own GPU.
+    """
+
+    def __init__(self, n, max_landmarks, seed=0, dtype="f32", device=0, neff_frac=0.75, distributed=None):
+        import torch.distributed as dist
+        use_dist = dist.is_available() and dist.is_initialized() if distributed is None else distributed
+        if use_dist:
+            import torch
+            rank, world = dist.get_rank(), dist.get_world_size()
+            if n % world:
+                raise ValueError("n must be divisible by the number of ranks")
+            per = n // world
+            shard = PFShard(per, max_landmarks, seed, dtype=dtype, first=rank * per, n_global=n, device=device)
+            comm = TorchComm(torch.device("cuda", int(device)))
+        else:
+            shard = PFShard(n, max_landmarks, seed, dtype=dtype, device=device)
+            comm = None
+        super().__init__(shard, comm, neff_frac)
+        self.n = n
+
+    def close(self):
+        self.shard.close()
