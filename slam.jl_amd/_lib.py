@@ -39,6 +39,14 @@ class NotPositiveDefinite(SlamHipError):
 
 
 def _load():
+    # libslamhip.so itself does not depend on torch.  But when torch is used in the same process (the
+    # FastSLAM collectives, bench.py) both must share ONE HIP runtime: torch's wheel bundles its own
+    # libamdhip64, and if the system runtime gets loaded first torch later reports "No HIP GPUs are
+    # available".  So torch, if installed, is imported before the library is opened.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
