@@ -257,10 +257,17 @@ def main():
         alg_bytes = 1.5 * n * n * esz                                 # lower triangle read + full matrix written
         tflops = alg_flops / syrk_avg_s / 1e12 if syrk_avg_s > 0 else 0.0
         gbps = alg_bytes / syrk_avg_s / 1e9 if syrk_avg_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_downdate_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            w = tj.get("workload", {})
+            if (w.get("landmarks"), w.get("obs_per_step"), w.get("dtype"), w.get("form")) == (N, nz, args.dtype, args.form):
+                traffic = tj["hbm_bytes_per_launch"]           # PMC-derived (separate rocprofv3 --pmc passes), see profiles/
         if args.dtype == "f32":
             roof = {"kernel": "downdate (P -= W1*W1')", "bound": "mfma", "achieved": tflops,
                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_F32_PEAK_TFLOPS,
-                    "traffic": None, "avg_launch_ms": syrk_avg_s * 1e3, "launches": syrk_n,
+                    "traffic": traffic, "avg_launch_ms": syrk_avg_s * 1e3, "launches": syrk_n,
                     "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
                     "hbm_achieved_GBps": gbps, "hbm_frac_of_8TBps": gbps / HBM_PEAK_GBPS}
         else:
