@@ -53,125 +53,110 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int TILE = SLAM_TILE;      // 128
 constexpr int KC = 32;               // k-chunk per barrier
 constexpr int LDSP = KC + 4;         // LDS row pitch in floats (144 B: 16-B aligned, conflict-free b128)
-constexpr int TP = 33;               // pitch of the per-wave 32 x 32 transpose scratch
 
-// The transpose scratch is private to a wave; LDS executes one wave's instructions in order, so a
+// The epilogue scratch is private to a wave; LDS executes one wave's instructions in order, so a
 // compiler-level fence is all that is needed between its writes and reads.  (A __syncthreads()
 // here would also drain every outstanding global store of the epilogue: vmcnt(0) per barrier.)
-__device__ inline void wave_lds_fence() {
+__device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// P tile <-> registers.
+// P tile <-> registers, 16 bytes per lane per instruction.
 //
-// Off-diagonal tiles need no masks at all (P is allocated in whole 128 x 128 tiles: rows/columns
-// >= n are padding that stays zero because the panels are zero there), and every address is
-// "wave-uniform column offset + per-lane row offset".  They go through buffer loads/stores whose
-// column offset rides in an SGPR (soffset): no per-element 64-bit VALU address arithmetic, no
-// branches.  A buffer descriptor covers one 128-column band of P (128*ld*4 bytes < 4 GiB).
-// Diagonal tiles (1 in 80 at N = 10k) take the masked path: lower triangle stored directly,
-// upper triangle from the mirror.
+// P is allocated in whole 128 x 128 tiles (rows/columns >= n are padding that stays zero because
+// the panels are zero there), so no element of an off-diagonal tile needs a mask.  Every access is
+// a buffer instruction "descriptor of a 128-column band + per-lane offset (VGPR) + wave-uniform
+// offset (SGPR)": no per-element 64-bit VALU address arithmetic.  In the "x4" layout lane
+// (q = lane & 7, cl = lane >> 3) owns rows 4q..4q+3 of column cl + 8s (s = 0..3) of a 32 x 32
+// sub-block: eight lanes cover one full 128-byte line, a wave instruction eight lines.  A wave
+// therefore issues 16 loads and 32 stores per tile instead of 64 and 128 dword ones -- few enough
+// that the in-order vmcnt counter (max 63) can wait for the NEXT tile's first panel chunk while this
+// tile's stores are still draining.
 typedef __attribute__((__vector_size__(4 * sizeof(int)))) int rsrc_t;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ inline auto band_rsrc(const float* band, int ld) {
+__device__ __forceinline__ auto band_rsrc(const float* band, int ld) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(band), (short)0, TILE * ld * 4, 0x00020000);
 }
 
-__device__ inline void load_p_tile_fast(const float* __restrict__ P, int ld, int R0, int C0, int wr, int wc, int l31,
-                                        int lh, float (&pold)[2][2][16]) {
+constexpr int SP = 36;                 // pitch of the per-wave 32 x 32 epilogue scratches (16-byte aligned rows)
+
+__device__ __forceinline__ void load_p_tile(const float* __restrict__ P, int ld, int R0, int C0, int wr, int wc, int q, int cl,
+                                            f32x4 (&pold)[4][4]) {
     const auto rs = band_rsrc(P + (size_t)C0 * ld, ld);
-    const int voff = (l31 + lh * 4 * ld) * 4;                 // bytes: row on the lane, upper half-wave 4 columns on
+    const int voff = (cl * ld + 4 * q) * 4;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int sub = 0; sub < 4; ++sub) {
+        const int cb = sub >> 1, rb = sub & 1;
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ci0 = (r & 3) + 8 * (r >> 2);
-                const int soff = ((64 * wc + 32 * cb + ci0) * ld + R0 + 64 * wr + 32 * rb) * 4;
-                pold[cb][rb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
-            }
+        for (int s = 0; s < 4; ++s) {
+            const int soff = ((64 * wc + 32 * cb + 8 * s) * ld + R0 + 64 * wr + 32 * rb) * 4;
+            pold[sub][s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+        }
+    }
 }
 
-__device__ inline void store_p_tile_fast(float* __restrict__ P, int ld, int R0, int C0, int wr, int wc, int l31, int lh,
-                                         const float (&pold)[2][2][16], const f32x16 (&acc)[2][2], float* sT, int dbg) {
+// Epilogue of one tile.  Per 32 x 32 sub-block: the product leaves the MFMA layout through LDS
+// ([col][row]), comes back in the x4 layout, P_old - product is stored to tile (I,J), written to a
+// second scratch transposed ([row][col]) and stored from there to tile (J,I).  `diag`: tile (I,I) --
+// the direct store keeps row >= col, the mirrored store row > col, element by element where a
+// 4-group straddles the diagonal, so P stays bit-for-bit symmetric.
+template <bool diag>
+__device__ __forceinline__ void store_p_tile(float* __restrict__ P, int ld, int R0, int C0, int wr, int wc, int l31,
+                                             int lh, int q, int cl, const f32x4 (&pold)[4][4], const f32x16 (&acc)[2][2],
+                                             float* sD, float* sV, int dbg) {
     const auto rs = band_rsrc(P + (size_t)C0 * ld, ld);       // direct:   columns C0.., rows R0..
     const auto rsm = band_rsrc(P + (size_t)R0 * ld, ld);      // mirrored: columns R0.., rows C0..
-    const int voff = (l31 + lh * 4 * ld) * 4;
-    const int voff_m = (l31 + lh * ld) * 4;                   // columns on lanes, upper half-wave 1 row on
+    const int voff = (cl * ld + 4 * q) * 4;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int sub = 0; sub < 4; ++sub) {
+        const int cb = sub >> 1, rb = sub & 1;
+        const int rowb = R0 + 64 * wr + 32 * rb, colb = C0 + 64 * wc + 32 * cb;
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
+        for (int r = 0; r < 16; ++r) sD[(4 * lh + (r & 3) + 8 * (r >> 2)) * SP + l31] = acc[cb][rb][r];
+        wave_lds_fence();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ci0 = (r & 3) + 8 * (r >> 2);
-                const float val = pold[cb][rb][r] - acc[cb][rb][r];
-                const int soff = ((64 * wc + 32 * cb + ci0) * ld + R0 + 64 * wr + 32 * rb) * 4;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rs, voff, soff, 0);
-                sT[l31 * TP + 4 * lh + ci0] = val;
+        for (int s = 0; s < 4; ++s) {
+            const int c = cl + 8 * s;
+            const f32x4 prod = *reinterpret_cast<const f32x4*>(&sD[c * SP + 4 * q]);
+            const f32x4 val = pold[sub][s] - prod;
+            const int soff = ((64 * wc + 32 * cb + 8 * s) * ld + R0 + 64 * wr + 32 * rb) * 4;
+            if (!diag) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rs, voff, soff, 0);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (rowb + 4 * q + t >= colb + c)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val[t]), rs, voff + 4 * t, soff, 0);
             }
-            wave_lds_fence();
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const float val = sT[(2 * s + lh) * TP + l31];
-                const int soff = ((64 * wr + 32 * rb + 2 * s) * ld + C0 + 64 * wc + 32 * cb) * 4;
-                if (!(dbg & 1)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rsm, voff_m, soff, 0);
-            }
-            wave_lds_fence();
+            for (int t = 0; t < 4; ++t) sV[(4 * q + t) * SP + c] = val[t];
         }
-}
-
-__device__ inline void load_p_tile_masked(const float* __restrict__ P, int ld, int n, int R0, int C0, int wr, int wc,
-                                          int l31, int lh, float (&pold)[2][2][16]) {
+        wave_lds_fence();
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+        for (int s = 0; s < 4; ++s) {
+            const int rr = cl + 8 * s;                             // row of the sub-block -> column of the mirror
+            const f32x4 val = *reinterpret_cast<const f32x4*>(&sV[rr * SP + 4 * q]);
+            const int soff = ((64 * wr + 32 * rb + 8 * s) * ld + C0 + 64 * wc + 32 * cb) * 4;
+            if (dbg & 1) continue;
+            if (!diag) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rsm, voff, soff, 0);
+            } else {
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const int row = R0 + 64 * wr + 32 * rb + l31;
-            const int colb = C0 + 64 * wc + 32 * cb + 4 * lh;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int col = colb + (r & 3) + 8 * (r >> 2);
-                pold[cb][rb][r] = (row < n && col < n) ? P[(size_t)col * ld + row] : 0.0f;
+                for (int t = 0; t < 4; ++t)
+                    if (rowb + rr > colb + 4 * q + t)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val[t]), rsm, voff + 4 * t, soff, 0);
             }
         }
-}
-
-__device__ inline void store_p_tile_masked(float* __restrict__ P, int ld, int n, int R0, int C0, int wr, int wc, int l31,
-                                           int lh, const float (&pold)[2][2][16], const f32x16 (&acc)[2][2], float* sT) {
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const int rowb = R0 + 64 * wr + 32 * rb;
-            const int colb = C0 + 64 * wc + 32 * cb;
-            const int row = rowb + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ci = 4 * lh + (r & 3) + 8 * (r >> 2);
-                const int col = colb + ci;
-                const float val = pold[cb][rb][r] - acc[cb][rb][r];
-                if (row < n && col < n && row >= col) P[(size_t)col * ld + row] = val;
-                sT[l31 * TP + ci] = val;
-            }
-            wave_lds_fence();
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int rr = 2 * s + lh;
-                const float val = sT[rr * TP + l31];
-                const int rowI = rowb + rr, colJ = colb + l31;
-                if (rowI < n && colJ < n && rowI > colJ) P[(size_t)rowI * ld + colJ] = val;
-            }
-            wave_lds_fence();
-        }
+        wave_lds_fence();
+    }
 }
 
 // One k-chunk of MFMAs out of LDS buffer `buf`; `kend` (16 or 32) columns are live.
-__device__ inline void mfma_chunk(const float (&sm)[2][2][TILE][LDSP], int buf, int kend, int wr, int wc, int l31, int lh,
-                                  f32x16 (&acc)[2][2]) {
+__device__ __forceinline__ void mfma_chunk(const float (&sm)[2][2][TILE][LDSP], int buf, int kend, int wr, int wc, int l31,
+                                           int lh, f32x16 (&acc)[2][2]) {
 #pragma unroll
     for (int kk = 0; kk < KC; kk += 8) {
         if (kk < kend) {
@@ -193,11 +178,73 @@ __device__ inline void mfma_chunk(const float (&sm)[2][2][TILE][LDSP], int buf, 
     }
 }
 
+struct DdCtx {       // per-thread constants of the down-date kernel
+    float* P;
+    const float* X;
+    const float* Y;
+    int ld, pitch, kp, nchunks, dbg;
+    int wr, wc, l31, lh, q, cl, srow, sc4;
+};
+
+typedef float smem_t[2][2][TILE][LDSP];
+
+__device__ __forceinline__ void request_chunk(const DdCtx& c, int2 t, int chunk, f32x4 (&gx)[4], f32x4 (&gy)[4]) {
+    const float* xs = c.X + (size_t)(t.x * TILE + c.srow) * c.pitch + 4 * c.sc4 + chunk * KC;
+    const float* ys = c.Y + (size_t)(t.y * TILE + c.srow) * c.pitch + 4 * c.sc4 + chunk * KC;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        gx[s] = *reinterpret_cast<const f32x4*>(xs + (size_t)(32 * s) * c.pitch);
+        gy[s] = *reinterpret_cast<const f32x4*>(ys + (size_t)(32 * s) * c.pitch);
+    }
+}
+
+__device__ __forceinline__ void fill_lds(const DdCtx& c, smem_t& smem, int buf, const f32x4 (&gx)[4], const f32x4 (&gy)[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        *reinterpret_cast<f32x4*>(&smem[buf][0][c.srow + 32 * s][4 * c.sc4]) = gx[s];
+        *reinterpret_cast<f32x4*>(&smem[buf][1][c.srow + 32 * s][4 * c.sc4]) = gy[s];
+    }
+}
+
+// One tile, start to finish.  On entry gx/gy hold (or are about to receive) the first panel chunk of
+// `tile`; on exit they hold the request for the first chunk of `next` (if valid), issued BEFORE this
+// tile's stores.
+template <bool DIAG>
+__device__ __forceinline__ void dd_tile(const DdCtx& c, int2 tile, int2 next, smem_t& smem, float* sD, float* sV,
+                                        f32x4 (&gx)[4], f32x4 (&gy)[4]) {
+    const int R0 = tile.x * TILE;     // rows  (I)
+    const int C0 = tile.y * TILE;     // cols  (J <= I)
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][rb][r] = 0.0f;
+
+    fill_lds(c, smem, 0, gx, gy);
+    __syncthreads();
+    if (c.nchunks > 1) request_chunk(c, tile, 1, gx, gy);
+    f32x4 pold[4][4];                 // P tile -> registers; in flight during the k-loop
+    load_p_tile(c.P, c.ld, R0, C0, c.wr, c.wc, c.q, c.cl, pold);
+    if (!(c.dbg & 2)) mfma_chunk(smem, 0, c.kp < KC ? c.kp : KC, c.wr, c.wc, c.l31, c.lh, acc);
+    for (int ch = 1; ch < c.nchunks; ++ch) {
+        fill_lds(c, smem, ch & 1, gx, gy);
+        __syncthreads();
+        if (ch + 1 < c.nchunks) request_chunk(c, tile, ch + 1, gx, gy);
+        if (!(c.dbg & 2)) mfma_chunk(smem, ch & 1, (c.kp - ch * KC < KC) ? c.kp - ch * KC : KC, c.wr, c.wc, c.l31, c.lh, acc);
+    }
+    __syncthreads();                  // every wave is done with the panels: LDS becomes epilogue scratch
+    if (next.x >= 0) request_chunk(c, next, 0, gx, gy);
+    store_p_tile<DIAG>(c.P, c.ld, R0, C0, c.wr, c.wc, c.l31, c.lh, c.q, c.cl, pold, acc, sD, sV, c.dbg);
+    __syncthreads();                  // scratch free again before the next tile's LDS fill
+}
+
 // PERSISTENT kernel: gridDim.x = 8 * nper workgroups (two per CU); workgroup b walks the tile list
-// of XCD b % 8 with stride nper.  Memory operations of one wave are asynchronous, so a wave that
-// moves on to the next tile's MFMAs lets its epilogue stores drain behind them; what remains
-// exposed per tile (store issue, first-chunk latency) is covered by the CU's second workgroup,
-// which is started half a tile late so that the two do not run their phases in lockstep.
+// of XCD b % 8 with stride nper.  Memory operations of a wave are asynchronous: a wave that moves on
+// to the next tile's MFMAs lets its 32 stores drain behind them.  The first tile is peeled so that
+// the loop header sees the same "8 loads, then 32 stores" history on both of its incoming edges and
+// the compiler can emit the counted wait vmcnt(32) for the panel chunk instead of vmcnt(0).
 __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ P, int ld, int n,
                                                             const float* __restrict__ X, const float* __restrict__ Y,
                                                             int pitch, int kp, const int2* __restrict__ tiles, int L,
@@ -207,104 +254,52 @@ __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // provably wave-uniform
-    const int wr = wave & 1;          // row half of the tile
-    const int wc = wave >> 1;         // column half
-    const int l31 = lane & 31;
-    const int lh = lane >> 5;
+    DdCtx c;
+    c.P = P; c.X = X; c.Y = Y; c.ld = ld; c.pitch = pitch; c.kp = kp; c.dbg = dbg;
+    c.nchunks = (kp + KC - 1) / KC;                           // kp is a multiple of 16: the last chunk may be half
+    c.wr = wave & 1;                  // row half of the tile
+    c.wc = wave >> 1;                 // column half
+    c.l31 = lane & 31;
+    c.lh = lane >> 5;
+    c.q = lane & 7;
+    c.cl = lane >> 3;
+    c.srow = tid >> 3;                // staging: 128 x 32 floats per panel = 1024 float4, 4 per thread per panel
+    c.sc4 = tid & 7;
     const int xcd = blockIdx.x & 7;
     const int rk = blockIdx.x >> 3;
     const int nper = gridDim.x >> 3;
     if (rk >= (nper >> 1)) __builtin_amdgcn_s_sleep(127);                  // ~3.4 us stagger (speed only)
     const int2* list = tiles + (size_t)xcd * L;
+    float* sD = &smem[0][0][0][0] + wave * (2 * 32 * SP);                   // per-wave scratches alias the panel buffers
+    float* sV = sD + 32 * SP;
+    (void)n;
+
     int slot = rk;
     int2 tile = slot < L ? list[slot] : make_int2(-1, -1);
-
-    // staging registers: 128 x 32 floats per panel = 1024 float4, 4 per thread per panel
+    if (tile.x < 0) return;
     f32x4 gx[4], gy[4];
-    const int srow = tid >> 3;        // + 32*s
-    const int sc4 = tid & 7;
-    const int nchunks = (kp + KC - 1) / KC;                   // kp is a multiple of 16: the last chunk may be half
-    float* sT = &smem[0][0][0][0] + wave * (32 * TP);
-
-    if (tile.x >= 0) {
-        const float* xsrc = X + (size_t)(tile.x * TILE + srow) * pitch + 4 * sc4;
-        const float* ysrc = Y + (size_t)(tile.y * TILE + srow) * pitch + 4 * sc4;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            gx[s] = *reinterpret_cast<const f32x4*>(xsrc + (size_t)(32 * s) * pitch);
-            gy[s] = *reinterpret_cast<const f32x4*>(ysrc + (size_t)(32 * s) * pitch);
+    request_chunk(c, tile, 0, gx, gy);
+    slot += nper;
+    int2 next = slot < L ? list[slot] : make_int2(-1, -1);
+    // off-diagonal tiles first (the lists keep the diagonal ones at their end): branch-free hot loop
+    if (tile.x != tile.y) {
+        dd_tile<false>(c, tile, next, smem, sD, sV, gx, gy);               // peeled first tile
+        while (next.x >= 0 && next.x != next.y) {
+            tile = next;
+            slot += nper;
+            next = slot < L ? list[slot] : make_int2(-1, -1);
+            dd_tile<false>(c, tile, next, smem, sD, sV, gx, gy);
         }
-    }
-    while (tile.x >= 0) {
-        const int R0 = tile.x * TILE;     // rows  (I)
-        const int C0 = tile.y * TILE;     // cols  (J <= I)
-        const bool diag = tile.x == tile.y;
-        const float* xsrc = X + (size_t)(R0 + srow) * pitch + 4 * sc4;
-        const float* ysrc = Y + (size_t)(C0 + srow) * pitch + 4 * sc4;
-
-        f32x16 acc[2][2];                 // [cb][rb]
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[cb][rb][r] = 0.0f;
-
-        // chunk 0 (requested before the previous tile's epilogue)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            *reinterpret_cast<f32x4*>(&smem[0][0][srow + 32 * s][4 * sc4]) = gx[s];
-            *reinterpret_cast<f32x4*>(&smem[0][1][srow + 32 * s][4 * sc4]) = gy[s];
-        }
-        __syncthreads();
-        if (nchunks > 1) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                gx[s] = *reinterpret_cast<const f32x4*>(xsrc + (size_t)(32 * s) * pitch + KC);
-                gy[s] = *reinterpret_cast<const f32x4*>(ysrc + (size_t)(32 * s) * pitch + KC);
-            }
-        }
-        // P tile -> registers; in flight during the k-loop
-        float pold[2][2][16];
-        if (diag) load_p_tile_masked(P, ld, n, R0, C0, wr, wc, l31, lh, pold);
-        else load_p_tile_fast(P, ld, R0, C0, wr, wc, l31, lh, pold);
-        if (!(dbg & 2)) mfma_chunk(smem, 0, kp < KC ? kp : KC, wr, wc, l31, lh, acc);
-
-        for (int c = 1; c < nchunks; ++c) {
-            const int buf = c & 1;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                *reinterpret_cast<f32x4*>(&smem[buf][0][srow + 32 * s][4 * sc4]) = gx[s];
-                *reinterpret_cast<f32x4*>(&smem[buf][1][srow + 32 * s][4 * sc4]) = gy[s];
-            }
-            __syncthreads();
-            if (c + 1 < nchunks) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    gx[s] = *reinterpret_cast<const f32x4*>(xsrc + (size_t)(32 * s) * pitch + (c + 1) * KC);
-                    gy[s] = *reinterpret_cast<const f32x4*>(ysrc + (size_t)(32 * s) * pitch + (c + 1) * KC);
-                }
-            }
-            if (!(dbg & 2)) mfma_chunk(smem, buf, (kp - c * KC < KC) ? kp - c * KC : KC, wr, wc, l31, lh, acc);
-        }
-
-        // next tile: request its first panel chunk now, ahead of this tile's 128 stores per lane
-        slot += nper;
-        const int2 next = slot < L ? list[slot] : make_int2(-1, -1);
-        __syncthreads();                  // every wave is done with the panels: LDS becomes transpose scratch
-        if (next.x >= 0) {
-            const float* nx = X + (size_t)(next.x * TILE + srow) * pitch + 4 * sc4;
-            const float* ny = Y + (size_t)(next.y * TILE + srow) * pitch + 4 * sc4;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                gx[s] = *reinterpret_cast<const f32x4*>(nx + (size_t)(32 * s) * pitch);
-                gy[s] = *reinterpret_cast<const f32x4*>(ny + (size_t)(32 * s) * pitch);
-            }
-        }
-        if (diag) store_p_tile_masked(P, ld, n, R0, C0, wr, wc, l31, lh, pold, acc, sT);
-        else store_p_tile_fast(P, ld, R0, C0, wr, wc, l31, lh, pold, acc, sT, dbg);
-        __syncthreads();                  // scratch free again before the next tile's LDS fill
         tile = next;
+        slot += nper;
+        next = slot < L ? list[slot] : make_int2(-1, -1);
+    }
+    // diagonal tiles: same pipeline, element-wise masks where a 4-group straddles the diagonal
+    while (tile.x >= 0) {
+        dd_tile<true>(c, tile, next, smem, sD, sV, gx, gy);
+        tile = next;
+        slot += nper;
+        next = slot < L ? list[slot] : make_int2(-1, -1);
     }
 }
 
@@ -393,7 +388,7 @@ __global__ __launch_bounds__(256) void downdate_valu(T* __restrict__ P, int ld, 
 
 // Tile lists: eight lists of equal length L (padded with -1), laid out [xcd][slot].  XCD x
 // (= workgroup id % 8 under round-robin dispatch) walks super-rows of SR tile rows, largest
-// first, column by column; its workgroups take slots rk, rk + nper, ...
+// first, column by column; its workgroups take slots rk, rk + nper, ...  Diagonal tiles come last.
 void build_tile_order(int T, std::vector<int2>& out) {
     constexpr int NX = 8, SR = 4;
     const int nsr = (T + SR - 1) / SR;
@@ -402,7 +397,7 @@ void build_tile_order(int T, std::vector<int2>& out) {
     for (int s = nsr - 1; s >= 0; --s) {
         const int I0 = s * SR, I1 = std::min(T, I0 + SR);
         long cnt = 0;
-        for (int I = I0; I < I1; ++I) cnt += I + 1;
+        for (int I = I0; I < I1; ++I) cnt += I;            // off-diagonal tiles of these rows
         int best = 0;
         for (int xcd = 1; xcd < NX; ++xcd)
             if (load[xcd] < load[best]) best = xcd;
@@ -410,15 +405,21 @@ void build_tile_order(int T, std::vector<int2>& out) {
         mine[best].push_back(s);
     }
     std::vector<std::vector<int2>> lists(NX);
-    size_t L = 0;
-    for (int xcd = 0; xcd < NX; ++xcd) {
+    for (int xcd = 0; xcd < NX; ++xcd)
         for (int s : mine[xcd]) {
             const int I0 = s * SR, I1 = std::min(T, I0 + SR);
             for (int J = 0; J < I1; ++J)
-                for (int I = std::max(I0, J); I < I1; ++I) lists[xcd].push_back(make_int2(I, J));
+                for (int I = std::max(I0, J + 1); I < I1; ++I) lists[xcd].push_back(make_int2(I, J));
         }
-        L = std::max(L, lists[xcd].size());
+    // the T diagonal tiles go to the END of the lists, shortest list first: they fill the ragged last round
+    for (int I = 0; I < T; ++I) {
+        int best = 0;
+        for (int xcd = 1; xcd < NX; ++xcd)
+            if (lists[xcd].size() < lists[best].size()) best = xcd;
+        lists[best].push_back(make_int2(I, I));
     }
+    size_t L = 0;
+    for (int xcd = 0; xcd < NX; ++xcd) L = std::max(L, lists[xcd].size());
     out.assign(L * NX, make_int2(-1, -1));
     for (int xcd = 0; xcd < NX; ++xcd)
         for (size_t slot = 0; slot < lists[xcd].size(); ++slot) out[xcd * L + slot] = lists[xcd][slot];
