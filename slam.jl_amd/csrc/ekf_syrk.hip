@@ -126,10 +126,12 @@ __device__ __forceinline__ void store_p_tile(float* __restrict__ P, int ld, int 
             if (!diag) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rs, voff, soff, 0);
             } else {
+                // (scalar copies: bit-casting val[t] directly made hipcc 7.2 store element 0 four times)
+                const float ve[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                     if (rowb + 4 * q + t >= colb + c)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val[t]), rs, voff + 4 * t, soff, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ve[t]), rs, voff + 4 * t, soff, 0);
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) sV[(4 * q + t) * SP + c] = val[t];
@@ -144,10 +146,11 @@ __device__ __forceinline__ void store_p_tile(float* __restrict__ P, int ld, int 
             if (!diag) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rsm, voff, soff, 0);
             } else {
+                const float ve[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                     if (rowb + rr > colb + 4 * q + t)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val[t]), rsm, voff + 4 * t, soff, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ve[t]), rsm, voff + 4 * t, soff, 0);
             }
         }
         wave_lds_fence();
