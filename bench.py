@@ -252,9 +252,9 @@ def main():
         k_avg = 2.0 * matched / max(syrk_n, 1)                       # actual k = 2m per launch
         if args.form == "joseph":
             k_avg *= 2.0
-        # the down-date computes the tiles on/below the diagonal and mirrors them:
-        alg_flops = 1.0 * n * n * k_avg                               # one triangle: n^2*k
-        alg_bytes = 1.5 * n * n * esz                                 # lower triangle read + full matrix written
+        # the down-date updates ONE triangle (the tiles on/below the diagonal), like BLAS syrk:
+        alg_flops = 1.0 * n * n * k_avg                               # n^2*k (one triangle)
+        alg_bytes = 1.0 * n * n * esz                                 # lower triangle read + lower triangle written
         tflops = alg_flops / syrk_avg_s / 1e12 if syrk_avg_s > 0 else 0.0
         gbps = alg_bytes / syrk_avg_s / 1e9 if syrk_avg_s > 0 else 0.0
         traffic = None

@@ -86,7 +86,10 @@ int slam_ekf_get_pose(slam_ekf_t h, double pose[3]);       /* state.x[1:3]      
 int slam_ekf_num_landmarks(slam_ekf_t h, int* N);          /* (length(x)-3)/2       */
 int slam_ekf_dtype(slam_ekf_t h, int* dtype);
 /* Raw device views (for zero-copy interop, e.g. a torch tensor over P):
- * d_x has 3+2*max_landmarks elements, d_P is column-major with leading dim ld. */
+ * d_x has 3+2*max_landmarks elements, d_P is column-major with leading dim ld.
+ * NOTE: like BLAS syrk, the covariance down-date maintains only the square tiles (128 for
+ * fp32, 64 for fp64) on and below the diagonal; the tiles above it are stale in this raw
+ * view.  slam_ekf_get_state mirrors them and returns the full symmetric matrix. */
 int slam_ekf_device_ptrs(slam_ekf_t h, void** d_x, void** d_P, int* ld, void** stream);
 
 /* ---- the hot path ----------------------------------------------------------- */

@@ -120,6 +120,7 @@ struct KTimer {
 };
 
 // ---- kernel launchers (one per .hip file) -----------------------------------
+int launch_mirror(slam_ekf* h);     // make the tiles above the diagonal valid (before a download)
 int launch_predict(slam_ekf* h, double v, double g, double w, const double Q[4], double dt);
 int launch_augment(slam_ekf* h, int nn, const double R[4]);   // observations already in obsbuf
 int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gate2);

@@ -38,3 +38,11 @@ __host__ __device__ inline ObsModel obs_model(double xv, double yv, double phi, 
     o.Hf[2] = -yd2; o.Hf[3] = xd2;
     return o;
 }
+
+// P is stored "block lower": the square tiles (edge 2^tile_log2: 128 for fp32, 64 for fp64) on and
+// below the diagonal are maintained, the tiles above it are not (the rank-k down-date updates one
+// triangle, like BLAS syrk).  Every read of P goes through this: element (r, c) of the symmetric matrix.
+template <typename T>
+__device__ inline T sym_at(const T* __restrict__ P, int ld, int tile_log2, int r, int c) {
+    return ((r >> tile_log2) >= (c >> tile_log2)) ? P[(size_t)c * ld + r] : P[(size_t)r * ld + c];
+}

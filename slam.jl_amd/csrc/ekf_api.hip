@@ -268,6 +268,10 @@ extern "C" int slam_ekf_get_state(slam_ekf_t h, void* x, void* P, int n, int ldP
     ARG_CHECK(P == nullptr || ldP >= n, "ldP < n");
     HIP_TRY(hipSetDevice(h->device));
     if (x) HIP_TRY(hipMemcpyAsync(x, h->x, h->esz * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    if (P) {
+        const int rc = launch_mirror(h);            // the down-date maintains only the tiles on/below the diagonal
+        if (rc) return rc;
+    }
     if (P)
         HIP_TRY(hipMemcpy2DAsync(P, h->esz * (size_t)ldP, h->P, h->esz * (size_t)h->ld, h->esz * (size_t)n, (size_t)n,
                                  hipMemcpyDeviceToHost, h->stream));

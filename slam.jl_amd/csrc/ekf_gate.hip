@@ -99,8 +99,8 @@ __device__ inline PairConst landmark_const(const T* __restrict__ x, const T* __r
     }
     double pff[4];
     pff[0] = (double)P[(size_t)f * ld + f];           // P[f][f]
-    pff[1] = (double)P[(size_t)(f + 1) * ld + f];     // P[f][f+1]
-    pff[2] = (double)P[(size_t)f * ld + f + 1];       // P[f+1][f]
+    pff[2] = (double)P[(size_t)f * ld + f + 1];       // P[f+1][f]  (lower: always maintained)
+    pff[1] = pff[2];                                  // P[f][f+1]  = its mirror (it may lie in a tile above the diagonal)
     pff[3] = (double)P[(size_t)(f + 1) * ld + f + 1]; // P[f+1][f+1]
     return pair_const(om, pvv, pfv, pff, R);
 }

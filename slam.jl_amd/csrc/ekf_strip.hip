@@ -155,7 +155,38 @@ __global__ __launch_bounds__(256) void augment_kernel(T* __restrict__ x, T* __re
     }
 }
 
+// Copy the maintained tiles (on/below the diagonal) onto their mirrors above it, 32 x 32 blocks through LDS
+// so that both the read and the write are coalesced.  Used before a download: slam_ekf_get_state returns the
+// full symmetric matrix like the reference's state.cov.
+template <typename T>
+__global__ __launch_bounds__(256) void mirror_kernel(T* __restrict__ P, int ld, int n, int tile_log2) {
+    __shared__ T sh[32][33];
+    const int br = blockIdx.x, bc = blockIdx.y;                    // destination block: rows 32*br.., cols 32*bc..
+    if (((32 * br) >> tile_log2) >= ((32 * bc) >> tile_log2)) return;     // destination must lie above the diagonal tiles
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
+    for (int j = ty; j < 32; j += 8) {                             // source block: rows 32*bc.., cols 32*br..
+        const int r = 32 * bc + tx, c = 32 * br + j;
+        sh[j][tx] = (r < n && c < n) ? P[(size_t)c * ld + r] : (T)0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int r = 32 * br + tx, c = 32 * bc + j;
+        if (r < n && c < n) P[(size_t)c * ld + r] = sh[tx][j];     // P[r, c] = P[c, r]
+    }
+}
+
 }  // namespace
+
+int launch_mirror(slam_ekf* h) {
+    const int n = 3 + 2 * h->N;
+    const int nb = (n + 31) / 32;
+    if (h->dtype == SLAM_F32)
+        hipLaunchKernelGGL(mirror_kernel<float>, dim3(nb, nb), dim3(256), 0, h->stream, (float*)h->P, h->ld, n, 7);
+    else
+        hipLaunchKernelGGL(mirror_kernel<double>, dim3(nb, nb), dim3(256), 0, h->stream, (double*)h->P, h->ld, n, 6);
+    HIP_TRY(hipGetLastError());
+    return SLAM_OK;
+}
 
 int launch_predict(slam_ekf* h, double v, double g, double w, const double Q[4], double dt) {
     const int n = 3 + 2 * h->N;

@@ -7,14 +7,15 @@
 // [npad][pitch] panels, zero in rows >= n and in padding columns.  This kernel
 // is where >= 90 % of an update's time goes.
 //
-// Symmetry.  X*Y' is symmetric in both forms and P is kept EXACTLY symmetric,
-// so only the tiles on and below the diagonal are computed: tile (I,J), I >= J,
-// reads P(I,J) once, forms P(I,J) - X_I*Y_J', and stores it to (I,J) and,
-// transposed through LDS so that both stores are full 128-byte lines, to (J,I).
-// Algorithmic traffic per update: n^2/2 elements read + n^2 written; algorithmic
-// work n^2*k flops (half of the full product).  Diagonal tiles store their lower
-// triangle directly and their upper triangle from the mirror, which keeps P
-// bit-for-bit symmetric also in the Joseph form.
+// Symmetry.  X*Y' is symmetric in both forms, so -- like BLAS syrk, which is what
+// Julia's W1*W1' dispatches to -- only ONE triangle is updated: the tiles on and
+// below the diagonal.  Tile (I,J), I > J, is read once, P(I,J) - X_I*Y_J' is stored
+// once; the tiles ABOVE the diagonal are not maintained (every reader of P goes
+// through sym_at() in device_math.h, and slam_ekf_get_state mirrors the lower tiles
+// on download).  Diagonal tiles stay complete: they store their lower triangle
+// directly and their upper triangle from an in-tile mirror through LDS, which keeps
+// them bit-for-bit symmetric also in the Joseph form.  Algorithmic traffic per
+// update: n^2/2 elements read + n^2/2 written; algorithmic work n^2*k flops.
 //
 // fp32: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).  A 256-thread
 // workgroup owns a 128 x 128 tile; its four waves own 64 x 64 quadrants as 2 x 2
@@ -133,28 +134,28 @@ __device__ __forceinline__ void store_p_tile(float* __restrict__ P, int ld, int 
                     if (rowb + 4 * q + t >= colb + c)
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ve[t]), rs, voff + 4 * t, soff, 0);
             }
+            if (diag) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) sV[(4 * q + t) * SP + c] = val[t];
+                for (int t = 0; t < 4; ++t) sV[(4 * q + t) * SP + c] = val[t];
+            }
         }
         wave_lds_fence();
+        if (diag) {                                               // in-tile mirror: upper triangle of a diagonal tile
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int rr = cl + 8 * s;                             // row of the sub-block -> column of the mirror
-            const f32x4 val = *reinterpret_cast<const f32x4*>(&sV[rr * SP + 4 * q]);
-            const int soff = ((64 * wr + 32 * rb + 8 * s) * ld + C0 + 64 * wc + 32 * cb) * 4;
-            if (dbg & 1) continue;
-            if (!diag) {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rsm, voff, soff, 0);
-            } else {
+            for (int s = 0; s < 4; ++s) {
+                const int rr = cl + 8 * s;                         // row of the sub-block -> column of the mirror
+                const f32x4 val = *reinterpret_cast<const f32x4*>(&sV[rr * SP + 4 * q]);
+                const int soff = ((64 * wr + 32 * rb + 8 * s) * ld + C0 + 64 * wc + 32 * cb) * 4;
                 const float ve[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                     if (rowb + rr > colb + 4 * q + t)
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ve[t]), rsm, voff + 4 * t, soff, 0);
             }
+            wave_lds_fence();
         }
-        wave_lds_fence();
     }
+    (void)dbg;
 }
 
 // One k-chunk of MFMAs out of LDS buffer `buf`; `kend` (16 or 32) columns are live.
@@ -375,7 +376,8 @@ __global__ __launch_bounds__(256) void downdate_valu(T* __restrict__ P, int ld, 
         }
     }
     __syncthreads();
-    // mirror: thread (tx, ty) stores element (row = ty+16v, col = tx+16u) to P[col, row]; col on tx
+    if (!diag) return;          // tiles above the diagonal are not maintained (see the header comment)
+    // in-tile mirror: thread (tx, ty) stores element (row = ty+16v, col = tx+16u) to P[col, row]; col on tx
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const int rl = ty + 16 * v;
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(256) void downdate_valu(T* __restrict__ P, int ld, 
         for (int u = 0; u < 4; ++u) {
             const int cl = tx + 16 * u;
             const int colJ = C0 + cl;
-            if (rowI < n && colJ < n && (!diag || rowI > colJ)) P[(size_t)rowI * ld + colJ] = sT[rl][cl];
+            if (rowI < n && colJ < n && rowI > colJ) P[(size_t)rowI * ld + colJ] = sT[rl][cl];
         }
     }
 }

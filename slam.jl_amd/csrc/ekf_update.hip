@@ -33,7 +33,7 @@ constexpr int PHT_OBS = 16;
 template <typename T>
 __global__ __launch_bounds__(256) void pht_kernel(const T* __restrict__ x, const T* __restrict__ P, int ld, int n,
                                                    const int32_t* __restrict__ idf, int m, int k, int kp,
-                                                   double* __restrict__ PHt, int pitch) {
+                                                   double* __restrict__ PHt, int pitch, int tile_log2) {
     __shared__ double sh[PHT_OBS][10];
     __shared__ int sf[PHT_OBS];
     const int tid = threadIdx.x;
@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256) void pht_kernel(const T* __restrict__ x, const
 #pragma unroll
         for (int i = 0; i < PHT_OBS; ++i) {
             const int f = sf[i < mc ? i : 0];
-            q0[i] = P[(size_t)f * ld + r];
-            q1[i] = P[(size_t)(f + 1) * ld + r];
+            q0[i] = sym_at(P, ld, tile_log2, r, f);          // P[r, f]: from row f where (r, f) lies above the diagonal tiles
+            q1[i] = sym_at(P, ld, tile_log2, r, f + 1);
         }
 #pragma unroll
         for (int i = 0; i < PHT_OBS; ++i) {
@@ -518,7 +518,8 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form) {
     {   // K2/K3
         KTimer t(h, SLAM_K_PHT);
         const dim3 grid((n + 255) / 256, kp / (2 * PHT_OBS));
-        hipLaunchKernelGGL(pht_kernel<T>, grid, dim3(256), 0, h->stream, x, P, h->ld, n, h->idfbuf, m, k, kp, h->PHt, pitchA);
+        hipLaunchKernelGGL(pht_kernel<T>, grid, dim3(256), 0, h->stream, x, P, h->ld, n, h->idfbuf, m, k, kp, h->PHt, pitchA,
+                           h->dtype == SLAM_F32 ? 7 : 6);
     }
     HIP_TRY(hipGetLastError());
     {   // K4
