@@ -96,7 +96,8 @@ struct slam_ekf {
     int32_t* d_status;   // [4]  [0] = not-PD flag of the last update
     int32_t* h_status;   // pinned
 
-    int debug_flags;     // SLAMHIP_DEBUG env: 1 = skip mirrored stores, 2 = skip MFMAs (timing experiments, WRONG results)
+    int debug_flags;     // SLAMHIP_DEBUG env bits: 1 = no P stores, 2 = no MFMAs, 4 = no P loads (timing experiments, WRONG results)
+    void* dd_prof;       // SLAMHIP_DEBUG & 8: per-wave phase clocks of the fp32 down-date (printed at destroy)
     int debug_stamps;    // factor kernel writes 100 MHz wall-clock stamps into d_small[40..47]
     int async_updates;
     int deferred;        // first deferred error

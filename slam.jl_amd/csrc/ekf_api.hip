@@ -3,7 +3,9 @@
 // operation on the state is a HIP kernel in the other translation units.  There
 // is deliberately no CPU fallback: without a usable device create() fails.
 #include <stdarg.h>
+#include <stdio.h>
 #include <stdlib.h>
+#include <vector>
 
 #include "common.h"
 
@@ -148,6 +150,24 @@ extern "C" int slam_ekf_destroy(slam_ekf_t h) {
     if (!h) return SLAM_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->dd_prof) {                // experiment output: mean per-wave phase clocks of the LAST down-date
+        const size_t cnt = (size_t)4096 * 4 * 4;
+        std::vector<unsigned long long> v(cnt);
+        if (hipMemcpy(v.data(), h->dd_prof, cnt * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            double s[4] = {0, 0, 0, 0}, mx = 0;
+            size_t waves = 0;
+            for (size_t w = 0; w < cnt / 4; ++w) {
+                if (!v[4 * w + 3]) continue;
+                ++waves;
+                for (int i = 0; i < 4; ++i) s[i] += (double)v[4 * w + i];
+                if ((double)v[4 * w + 3] > mx) mx = (double)v[4 * w + 3];
+            }
+            if (waves)
+                fprintf(stderr, "[slamhip] down-date per-wave (mean of %zu waves): panel-wait %.0f clk  lifetime %.0f x 10 ns  epilogue %.0f clk  lifetime %.0f clk (max %.0f)\n",
+                        waves, s[0] / waves, s[1] / waves, s[2] / waves, s[3] / waves, mx);
+        }
+        dev_free(h->dd_prof);
+    }
     for (auto& p : h->pairs) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto& p : h->free_pairs) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     free_update_workspace(h);
@@ -177,6 +197,7 @@ static int create_impl(slam_ekf* h) {
     if ((rc = dev_alloc_zero(&h->x, h->esz * (size_t)h->ncap, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->P, h->esz * (size_t)h->ld * h->npad, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->d_small, sizeof(double) * 64, h->stream))) return rc;
+    if ((h->debug_flags & 8) && (rc = dev_alloc_zero(&h->dd_prof, (size_t)4096 * 4 * 4 * 8, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->d_status, sizeof(int32_t) * 4, h->stream))) return rc;
     HIP_TRY(hipHostMalloc((void**)&h->h_small, sizeof(double) * 64, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&h->h_status, sizeof(int32_t) * 4, hipHostMallocDefault));
@@ -219,6 +240,7 @@ extern "C" int slam_ekf_create(slam_ekf_t* out, int dtype, int max_landmarks, in
     h->d_status = h->h_status = nullptr;
     h->async_updates = 0; h->deferred = 0; h->pending_status = 0; h->debug_stamps = 0;
     h->debug_flags = getenv("SLAMHIP_DEBUG") ? atoi(getenv("SLAMHIP_DEBUG")) : 0;
+    h->dd_prof = nullptr;
     h->timing = 0;
     for (int i = 0; i < SLAM_K_COUNT; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
     const int rc = create_impl(h);

@@ -124,6 +124,7 @@ __device__ __forceinline__ void store_p_tile(float* __restrict__ P, int ld, int 
             const f32x4 prod = *reinterpret_cast<const f32x4*>(&sD[c * SP + 4 * q]);
             const f32x4 val = pold[sub][s] - prod;
             const int soff = ((64 * wc + 32 * cb + 8 * s) * ld + R0 + 64 * wr + 32 * rb) * 4;
+            if (dbg & 1) continue;                                 // experiment: no stores (P stays as it is)
             if (!diag) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rs, voff, soff, 0);
             } else {
@@ -140,7 +141,7 @@ __device__ __forceinline__ void store_p_tile(float* __restrict__ P, int ld, int 
             }
         }
         wave_lds_fence();
-        if (diag) {                                               // in-tile mirror: upper triangle of a diagonal tile
+        if (diag && !(dbg & 1)) {                                 // in-tile mirror: upper triangle of a diagonal tile
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int rr = cl + 8 * s;                         // row of the sub-block -> column of the mirror
@@ -155,32 +156,13 @@ __device__ __forceinline__ void store_p_tile(float* __restrict__ P, int ld, int 
             wave_lds_fence();
         }
     }
-    (void)dbg;
 }
 
-// One k-chunk of MFMAs out of LDS buffer `buf`; `kend` (16 or 32) columns are live.
-__device__ __forceinline__ void mfma_chunk(const float (&sm)[2][2][TILE][LDSP], int buf, int kend, int wr, int wc, int l31,
-                                           int lh, f32x16 (&acc)[2][2]) {
-#pragma unroll
-    for (int kk = 0; kk < KC; kk += 8) {
-        if (kk < kend) {
-            f32x4 a[2], b[2];
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-                a[cb] = *reinterpret_cast<const f32x4*>(&sm[buf][1][64 * wc + 32 * cb + l31][kk + 4 * lh]);
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-                b[rb] = *reinterpret_cast<const f32x4*>(&sm[buf][0][64 * wr + 32 * rb + l31][kk + 4 * lh]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                    for (int rb = 0; rb < 2; ++rb)
-                        acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cb][t], b[rb][t], acc[cb][rb], 0, 0, 0);
-        }
-    }
-}
+// One "step" = 8 columns of k: each lane holds four consecutive k of its row for both row blocks of
+// either operand (4 x ds_read_b128) and feeds 16 MFMAs.
+struct Frag {
+    f32x4 a[2], b[2];
+};
 
 struct DdCtx {       // per-thread constants of the down-date kernel
     float* P;
@@ -188,6 +170,7 @@ struct DdCtx {       // per-thread constants of the down-date kernel
     const float* Y;
     int ld, pitch, kp, nchunks, dbg;
     int wr, wc, l31, lh, q, cl, srow, sc4;
+    unsigned long long t_head, t_wait, t_epi, t_total;     // PROF instantiation only (shader clocks, summed over tiles)
 };
 
 typedef float smem_t[2][2][TILE][LDSP];
@@ -210,14 +193,42 @@ __device__ __forceinline__ void fill_lds(const DdCtx& c, smem_t& smem, int buf, 
     }
 }
 
+__device__ __forceinline__ void read_frag(const DdCtx& c, const smem_t& sm, int buf, int kk, Frag& f) {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+        f.a[cb] = *reinterpret_cast<const f32x4*>(&sm[buf][1][64 * c.wc + 32 * cb + c.l31][kk + 4 * c.lh]);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+        f.b[rb] = *reinterpret_cast<const f32x4*>(&sm[buf][0][64 * c.wr + 32 * rb + c.l31][kk + 4 * c.lh]);
+}
+
+template <bool DBG>
+__device__ __forceinline__ void mfma_step(const DdCtx& c, const Frag& f, f32x16 (&acc)[2][2]) {
+    if (DBG && (c.dbg & 2)) return;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+                acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[cb][t], f.b[rb][t], acc[cb][rb], 0, 0, 0);
+}
+
 // One tile, start to finish.  On entry gx/gy hold (or are about to receive) the first panel chunk of
 // `tile`; on exit they hold the request for the first chunk of `next` (if valid), issued BEFORE this
 // tile's stores.
-template <bool DIAG>
-__device__ __forceinline__ void dd_tile(const DdCtx& c, int2 tile, int2 next, smem_t& smem, float* sD, float* sV,
+//
+// The k-loop is a software pipeline over steps: the LDS reads of step s+1 are issued before the MFMAs
+// of step s (two register sets), also across the chunk barrier.  Vector-memory results return in issue
+// order, so anything waited for after the 64 KiB P tile has been requested also waits for the P tile:
+// the P loads are therefore issued right after the LAST panel request of the tile (WHEN = the chunk
+// iteration that does it) and nothing but the epilogue ever waits behind them.
+template <bool DIAG, bool DBG>
+__device__ __forceinline__ void dd_tile(DdCtx& c, int2 tile, int2 next, smem_t& smem, float* sD, float* sV,
                                         f32x4 (&gx)[4], f32x4 (&gy)[4]) {
     const int R0 = tile.x * TILE;     // rows  (I)
     const int C0 = tile.y * TILE;     // cols  (J <= I)
+    const int nch = c.nchunks;
     f32x16 acc[2][2];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
@@ -225,23 +236,65 @@ __device__ __forceinline__ void dd_tile(const DdCtx& c, int2 tile, int2 next, sm
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[cb][rb][r] = 0.0f;
+    f32x4 pold[4][4];                 // P tile -> registers
+    Frag f0, f1;
 
+    constexpr bool PROF = DBG;
+    unsigned long long tp0 = 0, tp1 = 0;
+    if (PROF) tp0 = __builtin_amdgcn_s_memtime();
     fill_lds(c, smem, 0, gx, gy);
     __syncthreads();
-    if (c.nchunks > 1) request_chunk(c, tile, 1, gx, gy);
-    f32x4 pold[4][4];                 // P tile -> registers; in flight during the k-loop
-    load_p_tile(c.P, c.ld, R0, C0, c.wr, c.wc, c.q, c.cl, pold);
-    if (!(c.dbg & 2)) mfma_chunk(smem, 0, c.kp < KC ? c.kp : KC, c.wr, c.wc, c.l31, c.lh, acc);
-    for (int ch = 1; ch < c.nchunks; ++ch) {
-        fill_lds(c, smem, ch & 1, gx, gy);
-        __syncthreads();
-        if (ch + 1 < c.nchunks) request_chunk(c, tile, ch + 1, gx, gy);
-        if (!(c.dbg & 2)) mfma_chunk(smem, ch & 1, (c.kp - ch * KC < KC) ? c.kp - ch * KC : KC, c.wr, c.wc, c.l31, c.lh, acc);
+    if (PROF) { tp1 = __builtin_amdgcn_s_memtime(); c.t_head += tp1 - tp0; }
+    if (nch > 1) request_chunk(c, tile, 1, gx, gy);
+    if (nch <= 2 && !(DBG && (c.dbg & 4))) load_p_tile(c.P, c.ld, R0, C0, c.wr, c.wc, c.q, c.cl, pold);
+    read_frag(c, smem, 0, 0, f0);
+    int ch = 0;
+    // chunk ch is followed by chunk ch+1: three steps, hand-over, the fourth step behind the barrier
+#define DD_CHUNK(REQUEST, LOADP)                                                                   \
+    {                                                                                              \
+        const int buf = ch & 1;                                                                    \
+        read_frag(c, smem, buf, 8, f1);                                                            \
+        mfma_step<DBG>(c, f0, acc);                                                                \
+        read_frag(c, smem, buf, 16, f0);                                                           \
+        mfma_step<DBG>(c, f1, acc);                                                                \
+        read_frag(c, smem, buf, 24, f1);                                                           \
+        mfma_step<DBG>(c, f0, acc);                                                                \
+        if (PROF) tp1 = __builtin_amdgcn_s_memtime();                                              \
+        fill_lds(c, smem, buf ^ 1, gx, gy);                                                        \
+        __syncthreads();                                                                           \
+        if (PROF) c.t_wait += __builtin_amdgcn_s_memtime() - tp1;                                  \
+        if (REQUEST) request_chunk(c, tile, ch + 2, gx, gy);                                       \
+        if ((LOADP) && !(DBG && (c.dbg & 4))) load_p_tile(c.P, c.ld, R0, C0, c.wr, c.wc, c.q, c.cl, pold); \
+        read_frag(c, smem, buf ^ 1, 0, f0);                                                        \
+        mfma_step<DBG>(c, f1, acc);                                                                \
+        ++ch;                                                                                      \
     }
+    while (ch + 3 < nch) DD_CHUNK(true, false)
+    if (nch >= 3) DD_CHUNK(true, true)          // ch = nch-3: the last panel request, then the P tile
+    if (nch >= 2) DD_CHUNK(false, false)        // ch = nch-2
+#undef DD_CHUNK
+    {   // last chunk: two or four steps (kp is a multiple of 16)
+        const int buf = ch & 1;
+        read_frag(c, smem, buf, 8, f1);
+        mfma_step<DBG>(c, f0, acc);
+        if (c.kp - ch * KC > 16) {
+            read_frag(c, smem, buf, 16, f0);
+            mfma_step<DBG>(c, f1, acc);
+            read_frag(c, smem, buf, 24, f1);
+            mfma_step<DBG>(c, f0, acc);
+        }
+        mfma_step<DBG>(c, f1, acc);
+    }
+    if (PROF) tp1 = __builtin_amdgcn_s_memtime();
     __syncthreads();                  // every wave is done with the panels: LDS becomes epilogue scratch
     if (next.x >= 0) request_chunk(c, next, 0, gx, gy);
-    store_p_tile<DIAG>(c.P, c.ld, R0, C0, c.wr, c.wc, c.l31, c.lh, c.q, c.cl, pold, acc, sD, sV, c.dbg);
+    store_p_tile<DIAG>(c.P, c.ld, R0, C0, c.wr, c.wc, c.l31, c.lh, c.q, c.cl, pold, acc, sD, sV, DBG ? c.dbg : 0);
     __syncthreads();                  // scratch free again before the next tile's LDS fill
+    if (PROF) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        c.t_epi += t - tp1;
+        c.t_total += t - tp0;
+    }
 }
 
 // PERSISTENT kernel: gridDim.x = 8 * nper workgroups (two per CU); workgroup b walks the tile list
@@ -249,10 +302,12 @@ __device__ __forceinline__ void dd_tile(const DdCtx& c, int2 tile, int2 next, sm
 // to the next tile's MFMAs lets its 32 stores drain behind them.  The first tile is peeled so that
 // the loop header sees the same "8 loads, then 32 stores" history on both of its incoming edges and
 // the compiler can emit the counted wait vmcnt(32) for the panel chunk instead of vmcnt(0).
+template <bool DBG>
 __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ P, int ld, int n,
                                                             const float* __restrict__ X, const float* __restrict__ Y,
                                                             int pitch, int kp, const int2* __restrict__ tiles, int L,
-                                                            const int32_t* __restrict__ status, int dbg) {
+                                                            const int32_t* __restrict__ status, int dbg,
+                                                            unsigned long long* __restrict__ prof) {
     if (status[0] != 0) return;
     __shared__ __attribute__((aligned(16))) float smem[2][2][TILE][LDSP];   // [buffer][X|Y][row][k]  73,728 B
     const int tid = threadIdx.x;
@@ -269,6 +324,8 @@ __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ 
     c.cl = lane >> 3;
     c.srow = tid >> 3;                // staging: 128 x 32 floats per panel = 1024 float4, 4 per thread per panel
     c.sc4 = tid & 7;
+    c.t_head = c.t_wait = c.t_epi = c.t_total = 0;
+    const unsigned long long rt0 = DBG ? __builtin_amdgcn_s_memrealtime() : 0, mt0 = DBG ? __builtin_amdgcn_s_memtime() : 0;
     const int xcd = blockIdx.x & 7;
     const int rk = blockIdx.x >> 3;
     const int nper = gridDim.x >> 3;
@@ -287,12 +344,12 @@ __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ 
     int2 next = slot < L ? list[slot] : make_int2(-1, -1);
     // off-diagonal tiles first (the lists keep the diagonal ones at their end): branch-free hot loop
     if (tile.x != tile.y) {
-        dd_tile<false>(c, tile, next, smem, sD, sV, gx, gy);               // peeled first tile
+        dd_tile<false, DBG>(c, tile, next, smem, sD, sV, gx, gy);               // peeled first tile
         while (next.x >= 0 && next.x != next.y) {
             tile = next;
             slot += nper;
             next = slot < L ? list[slot] : make_int2(-1, -1);
-            dd_tile<false>(c, tile, next, smem, sD, sV, gx, gy);
+            dd_tile<false, DBG>(c, tile, next, smem, sD, sV, gx, gy);
         }
         tile = next;
         slot += nper;
@@ -300,10 +357,15 @@ __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ 
     }
     // diagonal tiles: same pipeline, element-wise masks where a 4-group straddles the diagonal
     while (tile.x >= 0) {
-        dd_tile<true>(c, tile, next, smem, sD, sV, gx, gy);
+        dd_tile<true, DBG>(c, tile, next, smem, sD, sV, gx, gy);
         tile = next;
         slot += nper;
         next = slot < L ? list[slot] : make_int2(-1, -1);
+    }
+    if (DBG && prof && lane == 0) {                   // per wave: head wait, chunk hand-over wait, epilogue, total
+        unsigned long long* o = prof + ((size_t)blockIdx.x * 4 + wave) * 4;
+        o[0] = c.t_head + c.t_wait; o[1] = __builtin_amdgcn_s_memrealtime() - rt0; o[2] = c.t_epi;
+        o[3] = __builtin_amdgcn_s_memtime() - mt0;
     }
 }
 
@@ -461,9 +523,14 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
         int per_xcd = 2 * h->num_cus / 8;
         if (per_xcd > h->tiles_len) per_xcd = h->tiles_len;
         if (per_xcd < 1) per_xcd = 1;
-        hipLaunchKernelGGL(downdate_f32_mfma, dim3(8 * per_xcd), dim3(256), 0, h->stream, (float*)h->P, h->ld, n,
-                           (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
-                           h->d_status, h->debug_flags);
+        if (h->debug_flags)      // timing experiments only (SLAMHIP_DEBUG): parts of the kernel switched off
+            hipLaunchKernelGGL(downdate_f32_mfma<true>, dim3(8 * per_xcd), dim3(256), 0, h->stream, (float*)h->P, h->ld, n,
+                               (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
+                               h->d_status, h->debug_flags, (unsigned long long*)h->dd_prof);
+        else
+            hipLaunchKernelGGL(downdate_f32_mfma<false>, dim3(8 * per_xcd), dim3(256), 0, h->stream, (float*)h->P, h->ld, n,
+                               (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
+                               h->d_status, 0, (unsigned long long*)nullptr);
     } else {
         hipLaunchKernelGGL(downdate_valu<double>, dim3(8 * h->tiles_len), dim3(256), 0, h->stream, (double*)h->P, h->ld, n,
                            (const double*)X, (const double*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,

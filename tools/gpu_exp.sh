@@ -1,6 +1,6 @@
 mkdir -p gpurun_out
-for d in 0 1 2 3; do
-  SLAMHIP_DEBUG=$d timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+for d in 0 8 13 10; do
+  SLAMHIP_DEBUG=$d timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>>gpurun_out/exp.log | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
