@@ -131,6 +131,17 @@ int slam_ekf_update(slam_ekf_t h, const double* zf, const int32_t* idf, int m,
  * Returns SLAM_E_CAPACITY (state unchanged) if N + nn > max_landmarks.  Enqueued. */
 int slam_ekf_augment(slam_ekf_t h, const double* zn, int nn, const double R[4]);
 
+/* One observation step of sim!  (src/sim.jl:114-120):  associate -> update -> add_features
+ * in ONE call, same results as the three calls above in sequence.  The association
+ * vector (meaning as in slam_ekf_associate) is compacted into the update's inputs on
+ * the device and the update kernels read the matched count from device memory, so
+ * they are queued behind the gating without a host round trip; the host only waits
+ * for assoc[] (to learn how many features to append).  S not positive definite:
+ * as slam_ekf_update (the features are still appended).  SLAM_E_CAPACITY: the
+ * update was applied, no feature was added. */
+int slam_ekf_observe(slam_ekf_t h, const double* z, int nz, const double R[4],
+                     double gate1, double gate2, int form, int32_t* assoc);
+
 /* ---- stream / timing -------------------------------------------------------- */
 
 int slam_ekf_set_async(slam_ekf_t h, int async_updates);

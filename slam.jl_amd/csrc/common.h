@@ -79,6 +79,9 @@ struct slam_ekf {
     int32_t* h_idf;   // pinned staging
     int32_t* h_assoc; // pinned staging [ocap]
     int32_t* d_assoc; // [ocap]
+    double* znbuf;    // [2*ocap] observe(): the new-feature observations, compacted on the device
+    int32_t* d_count; // [4]      observe(): {matched m, new nn}
+    hipEvent_t assoc_ev;   // observe(): the association vector has reached h_assoc
 
     // down-date tile order (ekf_syrk.hip): workgroup b computes tile tiles[b]
     int2* tiles;
@@ -123,10 +126,11 @@ struct KTimer {
 // ---- kernel launchers (one per .hip file) -----------------------------------
 int launch_mirror(slam_ekf* h);     // make the tiles above the diagonal valid (before a download)
 int launch_predict(slam_ekf* h, double v, double g, double w, const double Q[4], double dt);
-int launch_augment(slam_ekf* h, int nn, const double R[4]);   // observations already in obsbuf
+int launch_augment(slam_ekf* h, int nn, const double R[4], const double* zn_dev);   // zn already on the device (obsbuf or znbuf)
+int launch_compact(slam_ekf* h, int nz);   // d_assoc -> idfbuf/obsbuf (matched, in order), znbuf (new), d_count = {m, nn}
 int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gate2);
 int launch_nis(slam_ekf* h, const double z1[2], int j, const double R[4]);
 int launch_obs_model(slam_ekf* h, int j);
-int launch_update(slam_ekf* h, int m, const double R[4], int form);
+int launch_update(slam_ekf* h, int m, const double R[4], int form, bool device_count);   // device_count: m is an upper bound, kernels read d_count[0]
 int ensure_update_workspace(slam_ekf* h, int m);
 int ensure_obs_capacity(slam_ekf* h, int nobs);

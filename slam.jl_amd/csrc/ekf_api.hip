@@ -87,17 +87,18 @@ int ensure_obs_capacity(slam_ekf* h, int nobs) {
     int cap = h->ocap ? h->ocap : 256;
     while (cap < nobs) cap *= 2;
     HIP_TRY(hipStreamSynchronize(h->stream));
-    dev_free(h->obsbuf); dev_free(h->idfbuf); dev_free(h->d_assoc); dev_free(h->gate_part);
+    dev_free(h->obsbuf); dev_free(h->idfbuf); dev_free(h->d_assoc); dev_free(h->gate_part); dev_free(h->znbuf);
     if (h->h_obs) (void)hipHostFree(h->h_obs);
     if (h->h_idf) (void)hipHostFree(h->h_idf);
     if (h->h_assoc) (void)hipHostFree(h->h_assoc);
-    h->obsbuf = nullptr; h->idfbuf = nullptr; h->d_assoc = nullptr; h->gate_part = nullptr;
+    h->obsbuf = nullptr; h->idfbuf = nullptr; h->d_assoc = nullptr; h->gate_part = nullptr; h->znbuf = nullptr;
     h->h_obs = nullptr; h->h_idf = nullptr; h->h_assoc = nullptr;
     h->ocap = 0;
     int rc;
     if ((rc = dev_alloc_zero(&h->obsbuf, sizeof(double) * 2 * cap, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->idfbuf, sizeof(int32_t) * cap, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->d_assoc, sizeof(int32_t) * cap, h->stream))) return rc;
+    if ((rc = dev_alloc_zero(&h->znbuf, sizeof(double) * 2 * cap, h->stream))) return rc;
     // gating partials: [blocks][<=256 observations per sweep][3]
     h->gate_blocks_cap = (h->maxN + 63) / 64 + 1;
     if ((rc = dev_alloc_zero(&h->gate_part, sizeof(double) * 3 * 256 * (size_t)h->gate_blocks_cap, h->stream))) return rc;
@@ -172,8 +173,9 @@ extern "C" int slam_ekf_destroy(slam_ekf_t h) {
     for (auto& p : h->free_pairs) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     free_update_workspace(h);
     dev_free(h->x); dev_free(h->P); dev_free(h->tiles);
-    dev_free(h->obsbuf); dev_free(h->idfbuf); dev_free(h->d_assoc); dev_free(h->gate_part);
-    dev_free(h->d_small); dev_free(h->d_status);
+    dev_free(h->obsbuf); dev_free(h->idfbuf); dev_free(h->d_assoc); dev_free(h->gate_part); dev_free(h->znbuf);
+    dev_free(h->d_small); dev_free(h->d_status); dev_free(h->d_count);
+    if (h->assoc_ev) (void)hipEventDestroy(h->assoc_ev);
     if (h->h_obs) (void)hipHostFree(h->h_obs);
     if (h->h_idf) (void)hipHostFree(h->h_idf);
     if (h->h_assoc) (void)hipHostFree(h->h_assoc);
@@ -197,6 +199,8 @@ static int create_impl(slam_ekf* h) {
     if ((rc = dev_alloc_zero(&h->x, h->esz * (size_t)h->ncap, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->P, h->esz * (size_t)h->ld * h->npad, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->d_small, sizeof(double) * 64, h->stream))) return rc;
+    if ((rc = dev_alloc_zero(&h->d_count, sizeof(int32_t) * 4, h->stream))) return rc;
+    HIP_TRY(hipEventCreateWithFlags(&h->assoc_ev, hipEventDisableTiming));
     if ((h->debug_flags & 8) && (rc = dev_alloc_zero(&h->dd_prof, (size_t)4096 * 4 * 4 * 8, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->d_status, sizeof(int32_t) * 4, h->stream))) return rc;
     HIP_TRY(hipHostMalloc((void**)&h->h_small, sizeof(double) * 64, hipHostMallocDefault));
@@ -237,6 +241,7 @@ extern "C" int slam_ekf_create(slam_ekf_t* out, int dtype, int max_landmarks, in
     h->h_obs = nullptr; h->h_idf = nullptr; h->h_assoc = nullptr; h->d_assoc = nullptr;
     h->gate_part = nullptr; h->gate_blocks_cap = 0;
     h->d_small = h->h_small = nullptr;
+    h->znbuf = nullptr; h->d_count = nullptr; h->assoc_ev = nullptr;
     h->d_status = h->h_status = nullptr;
     h->async_updates = 0; h->deferred = 0; h->pending_status = 0; h->debug_stamps = 0;
     h->debug_flags = getenv("SLAMHIP_DEBUG") ? atoi(getenv("SLAMHIP_DEBUG")) : 0;
@@ -438,7 +443,7 @@ extern "C" int slam_ekf_update(slam_ekf_t h, const double* zf, const int32_t* id
     HIP_TRY(hipSetDevice(h->device));
     if ((rc = ensure_update_workspace(h, m))) return rc;
     if ((rc = stage_obs(h, zf, idf, m))) return rc;
-    if ((rc = launch_update(h, m, R, form))) return rc;
+    if ((rc = launch_update(h, m, R, form, false))) return rc;
     if (h->async_updates) {
         h->pending_status = 1;
         return SLAM_OK;
@@ -459,9 +464,58 @@ extern "C" int slam_ekf_augment(slam_ekf_t h, const double* zn, int nn, const do
     }
     HIP_TRY(hipSetDevice(h->device));
     if ((rc = stage_obs(h, zn, nullptr, nn))) return rc;
-    if ((rc = launch_augment(h, nn, R))) return rc;
+    if ((rc = launch_augment(h, nn, R, h->obsbuf))) return rc;
     h->N += nn;
     return SLAM_OK;
+}
+
+/* One observation step of the reference's sim! loop without a host round trip between its parts:
+ * associate (data-association.jl:1-51) -> update (ekf.jl:46-77) -> add_features (ekf.jl:84-122).
+ * The association vector is compacted ON THE DEVICE into the update's inputs; the update kernels are launched with
+ * nz as an upper bound and read the matched count from d_count, so they are queued while the gating still runs.
+ * The host waits only for the association vector (an event recorded BEFORE the update kernels) to learn how many
+ * new features to append. */
+extern "C" int slam_ekf_observe(slam_ekf_t h, const double* z, int nz, const double R[4], double gate1, double gate2, int form,
+                                int32_t* assoc) {
+    ARG_CHECK(h != nullptr, "null handle");
+    ARG_CHECK(nz >= 0, "nz < 0");
+    ARG_CHECK(form == SLAM_FORM_CHOLESKY || form == SLAM_FORM_JOSEPH, "unknown update form");
+    if (nz == 0) return SLAM_OK;
+    ARG_CHECK(z != nullptr && assoc != nullptr, "z / assoc is null");
+    int rc = check_R(R);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->N == 0) {                       // every observation is a new feature (outer stays Inf > gate2)
+        for (int i = 0; i < nz; ++i) assoc[i] = -1;
+        return slam_ekf_augment(h, z, nz, R);
+    }
+    if ((rc = ensure_update_workspace(h, nz))) return rc;
+    if ((rc = stage_obs(h, z, nullptr, nz))) return rc;
+    if ((rc = launch_gate(h, nz, R, gate1, gate2))) return rc;
+    if ((rc = launch_compact(h, nz))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->h_assoc, h->d_assoc, sizeof(int32_t) * (size_t)nz, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipEventRecord(h->assoc_ev, h->stream));
+    if ((rc = launch_update(h, nz, R, form, true))) return rc;
+    HIP_TRY(hipEventSynchronize(h->assoc_ev));          // gating + copy only: the update runs on behind it
+    int nn = 0;
+    for (int i = 0; i < nz; ++i) {
+        assoc[i] = h->h_assoc[i];
+        nn += assoc[i] < 0;
+    }
+    if (nn) {
+        if (h->N + nn > h->maxN) {
+            slam_set_error("observe: %d + %d landmarks exceed capacity %d (the update was applied, no feature added)", h->N, nn,
+                           h->maxN);
+            return SLAM_E_CAPACITY;
+        }
+        if ((rc = launch_augment(h, nn, R, h->znbuf))) return rc;
+        h->N += nn;
+    }
+    if (h->async_updates) {
+        h->pending_status = 1;
+        return SLAM_OK;
+    }
+    return read_status(h, 0);
 }
 
 // ---- stream / timing -----------------------------------------------------------------

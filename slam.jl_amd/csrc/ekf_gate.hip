@@ -225,7 +225,50 @@ __global__ void single_pair_kernel(const T* __restrict__ x, const T* __restrict_
     out[1] = nd;
 }
 
+// observe(): turn the association vector into the update's and add_features' inputs without leaving the device.
+// One wave walks the observations in order, 64 at a time: matched ones (assoc >= 1) are compacted IN PLACE to the
+// front of zbuf/idf (a write position never passes the read position of a later chunk), new ones (assoc < 0) go
+// to zn.  count = {matched, new}.  Order is the observation order, as in data-association.jl:43-47.
+__global__ __launch_bounds__(64) void compact_kernel(const int32_t* __restrict__ assoc, int nz, double* __restrict__ zbuf,
+                                                     int32_t* __restrict__ idf, double* __restrict__ zn,
+                                                     int32_t* __restrict__ count) {
+    const int lane = threadIdx.x;
+    int m = 0, nn = 0;
+    for (int base = 0; base < nz; base += 64) {
+        const int i = base + lane;
+        const int a = i < nz ? assoc[i] : 0;
+        const double z0 = i < nz ? zbuf[2 * i] : 0.0, z1 = i < nz ? zbuf[2 * i + 1] : 0.0;
+        const unsigned long long mm = __ballot(a > 0), mn = __ballot(a < 0);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        __builtin_amdgcn_s_waitcnt(0);           // every lane holds its z before any lane overwrites the front
+        __builtin_amdgcn_wave_barrier();
+        if (a > 0) {
+            const int pos = m + __popcll(mm & below);
+            idf[pos] = a;
+            zbuf[2 * pos] = z0;
+            zbuf[2 * pos + 1] = z1;
+        } else if (a < 0) {
+            const int pos = nn + __popcll(mn & below);
+            zn[2 * pos] = z0;
+            zn[2 * pos + 1] = z1;
+        }
+        m += __popcll(mm);
+        nn += __popcll(mn);
+    }
+    if (lane == 0) {
+        count[0] = m;
+        count[1] = nn;
+    }
+}
+
 }  // namespace
+
+int launch_compact(slam_ekf* h, int nz) {
+    hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(64), 0, h->stream, (const int32_t*)h->d_assoc, nz, h->obsbuf, h->idfbuf,
+                       h->znbuf, h->d_count);
+    HIP_TRY(hipGetLastError());
+    return SLAM_OK;
+}
 
 int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gate2) {
     const int nblocks = (h->N + GATE_BLOCK - 1) / GATE_BLOCK;

@@ -213,17 +213,17 @@ int launch_predict(slam_ekf* h, double v, double g, double w, const double Q[4],
     return SLAM_OK;
 }
 
-int launch_augment(slam_ekf* h, int nn, const double R[4]) {
+int launch_augment(slam_ekf* h, int nn, const double R[4], const double* zn_dev) {
     const int n0 = 3 + 2 * h->N;
     const int blocks = (n0 + 255) / 256;
     {
         KTimer t(h, SLAM_K_AUGMENT);
         if (h->dtype == SLAM_F32)
             hipLaunchKernelGGL(augment_kernel<float>, dim3(blocks), dim3(256), 0, h->stream, (float*)h->x, (float*)h->P,
-                               h->ld, n0, h->obsbuf, nn, R[0], R[1], R[2], R[3]);
+                               h->ld, n0, zn_dev, nn, R[0], R[1], R[2], R[3]);
         else
             hipLaunchKernelGGL(augment_kernel<double>, dim3(blocks), dim3(256), 0, h->stream, (double*)h->x,
-                               (double*)h->P, h->ld, n0, h->obsbuf, nn, R[0], R[1], R[2], R[3]);
+                               (double*)h->P, h->ld, n0, zn_dev, nn, R[0], R[1], R[2], R[3]);
     }
     HIP_TRY(hipGetLastError());
     return SLAM_OK;

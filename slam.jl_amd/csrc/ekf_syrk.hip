@@ -71,11 +71,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // a buffer instruction "descriptor of a 128-column band + per-lane offset (VGPR) + wave-uniform
 // offset (SGPR)": no per-element 64-bit VALU address arithmetic.  In the "x4" layout lane
 // (q = lane & 7, cl = lane >> 3) owns rows 4q..4q+3 of column cl + 8s (s = 0..3) of a 32 x 32
-// sub-block: eight lanes cover one full 128-byte line, a wave instruction eight lines.  A wave
-// therefore issues 16 loads and 32 stores per tile instead of 64 and 128 dword ones -- few enough
-// that the in-order vmcnt counter (max 63) can wait for the NEXT tile's first panel chunk while this
-// tile's stores are still draining.
-typedef __attribute__((__vector_size__(4 * sizeof(int)))) int rsrc_t;
+// sub-block: eight lanes cover one full 128-byte line, a wave instruction eight lines.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ auto band_rsrc(const float* band, int ld) {
@@ -83,47 +79,55 @@ __device__ __forceinline__ auto band_rsrc(const float* band, int ld) {
 }
 
 constexpr int SP = 36;                 // pitch of the per-wave 32 x 32 epilogue scratches (16-byte aligned rows)
+constexpr int NWAVE = 8;               // waves per workgroup: wave (wr, wc) owns rows 64*wr.., columns 32*wc.. of the tile
+constexpr int NTHREADS = 64 * NWAVE;
 
-__device__ __forceinline__ void load_p_tile(const float* __restrict__ P, int ld, int R0, int C0, int wr, int wc, int q, int cl,
-                                            f32x4 (&pold)[4][4]) {
-    const auto rs = band_rsrc(P + (size_t)C0 * ld, ld);
-    const int voff = (cl * ld + 4 * q) * 4;
+struct DdCtx {       // per-thread constants of the down-date kernel
+    float* P;
+    const float* X;
+    const float* Y;
+    int ld, pitch, kp, nchunks, dbg;
+    int wr, wc, l31, lh, q, cl, srow, sc4;
+    unsigned long long t_head, t_wait, t_epi, t_total;     // DBG instantiation only (shader clocks, summed over tiles)
+};
+
+__device__ __forceinline__ void load_p_tile(const DdCtx& c, int R0, int C0, f32x4 (&pold)[2][4]) {
+    const auto rs = band_rsrc(c.P + (size_t)C0 * c.ld, c.ld);
+    const int voff = (c.cl * c.ld + 4 * c.q) * 4;
 #pragma unroll
-    for (int sub = 0; sub < 4; ++sub) {
-        const int cb = sub >> 1, rb = sub & 1;
+    for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int soff = ((64 * wc + 32 * cb + 8 * s) * ld + R0 + 64 * wr + 32 * rb) * 4;
-            pold[sub][s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+            const int soff = ((32 * c.wc + 8 * s) * c.ld + R0 + 64 * c.wr + 32 * rb) * 4;
+            pold[rb][s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
         }
-    }
 }
 
 // Epilogue of one tile.  Per 32 x 32 sub-block: the product leaves the MFMA layout through LDS
-// ([col][row]), comes back in the x4 layout, P_old - product is stored to tile (I,J), written to a
-// second scratch transposed ([row][col]) and stored from there to tile (J,I).  `diag`: tile (I,I) --
-// the direct store keeps row >= col, the mirrored store row > col, element by element where a
-// 4-group straddles the diagonal, so P stays bit-for-bit symmetric.
+// ([col][row]), comes back in the x4 layout, and P_old - product is stored to tile (I,J) with full
+// 128-byte lines.  `diag`: tile (I,I) -- the direct store keeps row >= col; the values also go to a
+// second scratch transposed ([row][col]) and from there to the upper triangle of the same tile
+// (row > col of the mirror), element by element where a 4-group straddles the diagonal, so P stays
+// bit-for-bit symmetric.
 template <bool diag>
-__device__ __forceinline__ void store_p_tile(float* __restrict__ P, int ld, int R0, int C0, int wr, int wc, int l31,
-                                             int lh, int q, int cl, const f32x4 (&pold)[4][4], const f32x16 (&acc)[2][2],
-                                             float* sD, float* sV, int dbg) {
-    const auto rs = band_rsrc(P + (size_t)C0 * ld, ld);       // direct:   columns C0.., rows R0..
-    const auto rsm = band_rsrc(P + (size_t)R0 * ld, ld);      // mirrored: columns R0.., rows C0..
-    const int voff = (cl * ld + 4 * q) * 4;
+__device__ __forceinline__ void store_p_tile(const DdCtx& c, int R0, int C0, const f32x4 (&pold)[2][4],
+                                             const f32x16 (&acc)[2], float* sD, float* sV, int dbg) {
+    const auto rs = band_rsrc(c.P + (size_t)C0 * c.ld, c.ld);       // direct:   columns C0.., rows R0..
+    const auto rsm = band_rsrc(c.P + (size_t)R0 * c.ld, c.ld);      // mirrored: columns R0.., rows C0..
+    const int voff = (c.cl * c.ld + 4 * c.q) * 4;
+    const int q = c.q, cl = c.cl;
 #pragma unroll
-    for (int sub = 0; sub < 4; ++sub) {
-        const int cb = sub >> 1, rb = sub & 1;
-        const int rowb = R0 + 64 * wr + 32 * rb, colb = C0 + 64 * wc + 32 * cb;
+    for (int rb = 0; rb < 2; ++rb) {
+        const int rowb = R0 + 64 * c.wr + 32 * rb, colb = C0 + 32 * c.wc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sD[(4 * lh + (r & 3) + 8 * (r >> 2)) * SP + l31] = acc[cb][rb][r];
+        for (int r = 0; r < 16; ++r) sD[(4 * c.lh + (r & 3) + 8 * (r >> 2)) * SP + c.l31] = acc[rb][r];
         wave_lds_fence();
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int c = cl + 8 * s;
-            const f32x4 prod = *reinterpret_cast<const f32x4*>(&sD[c * SP + 4 * q]);
-            const f32x4 val = pold[sub][s] - prod;
-            const int soff = ((64 * wc + 32 * cb + 8 * s) * ld + R0 + 64 * wr + 32 * rb) * 4;
+            const int col = cl + 8 * s;
+            const f32x4 prod = *reinterpret_cast<const f32x4*>(&sD[col * SP + 4 * q]);
+            const f32x4 val = pold[rb][s] - prod;
+            const int soff = ((32 * c.wc + 8 * s) * c.ld + R0 + 64 * c.wr + 32 * rb) * 4;
             if (dbg & 1) continue;                                 // experiment: no stores (P stays as it is)
             if (!diag) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rs, voff, soff, 0);
@@ -132,12 +136,10 @@ __device__ __forceinline__ void store_p_tile(float* __restrict__ P, int ld, int 
                 const float ve[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                    if (rowb + 4 * q + t >= colb + c)
+                    if (rowb + 4 * q + t >= colb + col)
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ve[t]), rs, voff + 4 * t, soff, 0);
-            }
-            if (diag) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) sV[(4 * q + t) * SP + c] = val[t];
+                for (int t = 0; t < 4; ++t) sV[(4 * q + t) * SP + col] = ve[t];
             }
         }
         wave_lds_fence();
@@ -146,7 +148,7 @@ __device__ __forceinline__ void store_p_tile(float* __restrict__ P, int ld, int 
             for (int s = 0; s < 4; ++s) {
                 const int rr = cl + 8 * s;                         // row of the sub-block -> column of the mirror
                 const f32x4 val = *reinterpret_cast<const f32x4*>(&sV[rr * SP + 4 * q]);
-                const int soff = ((64 * wr + 32 * rb + 8 * s) * ld + C0 + 64 * wc + 32 * cb) * 4;
+                const int soff = ((64 * c.wr + 32 * rb + 8 * s) * c.ld + C0 + 32 * c.wc) * 4;
                 const float ve[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
@@ -158,86 +160,76 @@ __device__ __forceinline__ void store_p_tile(float* __restrict__ P, int ld, int 
     }
 }
 
-// One "step" = 8 columns of k: each lane holds four consecutive k of its row for both row blocks of
-// either operand (4 x ds_read_b128) and feeds 16 MFMAs.
+// One "step" = 8 columns of k: each lane holds four consecutive k of its row for the wave's column
+// block and its two row blocks (3 x ds_read_b128) and feeds 8 MFMAs.
 struct Frag {
-    f32x4 a[2], b[2];
-};
-
-struct DdCtx {       // per-thread constants of the down-date kernel
-    float* P;
-    const float* X;
-    const float* Y;
-    int ld, pitch, kp, nchunks, dbg;
-    int wr, wc, l31, lh, q, cl, srow, sc4;
-    unsigned long long t_head, t_wait, t_epi, t_total;     // PROF instantiation only (shader clocks, summed over tiles)
+    f32x4 a, b[2];
 };
 
 typedef float smem_t[2][2][TILE][LDSP];
 
-__device__ __forceinline__ void request_chunk(const DdCtx& c, int2 t, int chunk, f32x4 (&gx)[4], f32x4 (&gy)[4]) {
-    const float* xs = c.X + (size_t)(t.x * TILE + c.srow) * c.pitch + 4 * c.sc4 + chunk * KC;
-    const float* ys = c.Y + (size_t)(t.y * TILE + c.srow) * c.pitch + 4 * c.sc4 + chunk * KC;
+// panel staging: 128 x 32 floats per panel and chunk = 1024 float4, two per thread per panel
+__device__ __forceinline__ void request_chunk(const DdCtx& c, int2 t, int chunk, f32x4 (&gx)[2], f32x4 (&gy)[2]) {
+    // descriptor of the whole panel + one per-lane offset + wave-uniform offsets: no 64-bit per-lane pointers
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.X), (short)0, c.ld * c.pitch * 4, 0x00020000);
+    const auto ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.Y), (short)0, c.ld * c.pitch * 4, 0x00020000);
+    const int voff = (c.srow * c.pitch + 4 * c.sc4) * 4;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        gx[s] = *reinterpret_cast<const f32x4*>(xs + (size_t)(32 * s) * c.pitch);
-        gy[s] = *reinterpret_cast<const f32x4*>(ys + (size_t)(32 * s) * c.pitch);
+    for (int s = 0; s < 2; ++s) {
+        const int sx = ((t.x * TILE + 64 * s) * c.pitch + chunk * KC) * 4;
+        const int sy = ((t.y * TILE + 64 * s) * c.pitch + chunk * KC) * 4;
+        gx[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, sx, 0));
+        gy[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, voff, sy, 0));
     }
 }
 
-__device__ __forceinline__ void fill_lds(const DdCtx& c, smem_t& smem, int buf, const f32x4 (&gx)[4], const f32x4 (&gy)[4]) {
+__device__ __forceinline__ void fill_lds(const DdCtx& c, smem_t& smem, int buf, const f32x4 (&gx)[2], const f32x4 (&gy)[2]) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        *reinterpret_cast<f32x4*>(&smem[buf][0][c.srow + 32 * s][4 * c.sc4]) = gx[s];
-        *reinterpret_cast<f32x4*>(&smem[buf][1][c.srow + 32 * s][4 * c.sc4]) = gy[s];
+    for (int s = 0; s < 2; ++s) {
+        *reinterpret_cast<f32x4*>(&smem[buf][0][c.srow + 64 * s][4 * c.sc4]) = gx[s];
+        *reinterpret_cast<f32x4*>(&smem[buf][1][c.srow + 64 * s][4 * c.sc4]) = gy[s];
     }
 }
 
 __device__ __forceinline__ void read_frag(const DdCtx& c, const smem_t& sm, int buf, int kk, Frag& f) {
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-        f.a[cb] = *reinterpret_cast<const f32x4*>(&sm[buf][1][64 * c.wc + 32 * cb + c.l31][kk + 4 * c.lh]);
+    f.a = *reinterpret_cast<const f32x4*>(&sm[buf][1][32 * c.wc + c.l31][kk + 4 * c.lh]);
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
         f.b[rb] = *reinterpret_cast<const f32x4*>(&sm[buf][0][64 * c.wr + 32 * rb + c.l31][kk + 4 * c.lh]);
 }
 
 template <bool DBG>
-__device__ __forceinline__ void mfma_step(const DdCtx& c, const Frag& f, f32x16 (&acc)[2][2]) {
+__device__ __forceinline__ void mfma_step(const DdCtx& c, const Frag& f, f32x16 (&acc)[2]) {
     if (DBG && (c.dbg & 2)) return;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-                acc[cb][rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[cb][t], f.b[rb][t], acc[cb][rb], 0, 0, 0);
+        for (int rb = 0; rb < 2; ++rb)
+            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t], f.b[rb][t], acc[rb], 0, 0, 0);
 }
 
 // One tile, start to finish.  On entry gx/gy hold (or are about to receive) the first panel chunk of
 // `tile`; on exit they hold the request for the first chunk of `next` (if valid), issued BEFORE this
 // tile's stores.
 //
-// The k-loop is a software pipeline over steps: the LDS reads of step s+1 are issued before the MFMAs
-// of step s (two register sets), also across the chunk barrier.  Vector-memory results return in issue
+// Four waves per SIMD cover each other's LDS and barrier latencies, so the k-loop is kept simple (one
+// fragment set: the 128-VGPR budget of that occupancy has no room for two).  Vector-memory results return in issue
 // order, so anything waited for after the 64 KiB P tile has been requested also waits for the P tile:
-// the P loads are therefore issued right after the LAST panel request of the tile (WHEN = the chunk
-// iteration that does it) and nothing but the epilogue ever waits behind them.
+// the P loads are therefore issued right after the LAST panel request of the tile and nothing but the
+// epilogue ever waits behind them.
 template <bool DIAG, bool DBG>
 __device__ __forceinline__ void dd_tile(DdCtx& c, int2 tile, int2 next, smem_t& smem, float* sD, float* sV,
-                                        f32x4 (&gx)[4], f32x4 (&gy)[4]) {
+                                        f32x4 (&gx)[2], f32x4 (&gy)[2]) {
     const int R0 = tile.x * TILE;     // rows  (I)
     const int C0 = tile.y * TILE;     // cols  (J <= I)
     const int nch = c.nchunks;
-    f32x16 acc[2][2];
+    f32x16 acc[2];
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[cb][rb][r] = 0.0f;
-    f32x4 pold[4][4];                 // P tile -> registers
-    Frag f0, f1;
+        for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
+    f32x4 pold[2][4];                 // the wave's 64 x 32 part of the P tile
+    Frag f0;
 
     constexpr bool PROF = DBG;
     unsigned long long tp0 = 0, tp1 = 0;
@@ -246,27 +238,24 @@ __device__ __forceinline__ void dd_tile(DdCtx& c, int2 tile, int2 next, smem_t& 
     __syncthreads();
     if (PROF) { tp1 = __builtin_amdgcn_s_memtime(); c.t_head += tp1 - tp0; }
     if (nch > 1) request_chunk(c, tile, 1, gx, gy);
-    if (nch <= 2 && !(DBG && (c.dbg & 4))) load_p_tile(c.P, c.ld, R0, C0, c.wr, c.wc, c.q, c.cl, pold);
-    read_frag(c, smem, 0, 0, f0);
+    if (nch <= 2 && !(DBG && (c.dbg & 4))) load_p_tile(c, R0, C0, pold);
     int ch = 0;
-    // chunk ch is followed by chunk ch+1: three steps, hand-over, the fourth step behind the barrier
+    // chunk ch is followed by chunk ch+1: four steps, then the hand-over of the other LDS buffer
+#define DD_STEPS(BUF, N)                                   \
+    _Pragma("unroll") for (int st = 0; st < (N); ++st) {   \
+        read_frag(c, smem, BUF, 8 * st, f0);               \
+        mfma_step<DBG>(c, f0, acc);                        \
+    }
 #define DD_CHUNK(REQUEST, LOADP)                                                                   \
     {                                                                                              \
         const int buf = ch & 1;                                                                    \
-        read_frag(c, smem, buf, 8, f1);                                                            \
-        mfma_step<DBG>(c, f0, acc);                                                                \
-        read_frag(c, smem, buf, 16, f0);                                                           \
-        mfma_step<DBG>(c, f1, acc);                                                                \
-        read_frag(c, smem, buf, 24, f1);                                                           \
-        mfma_step<DBG>(c, f0, acc);                                                                \
+        DD_STEPS(buf, 4)                                                                           \
         if (PROF) tp1 = __builtin_amdgcn_s_memtime();                                              \
         fill_lds(c, smem, buf ^ 1, gx, gy);                                                        \
         __syncthreads();                                                                           \
         if (PROF) c.t_wait += __builtin_amdgcn_s_memtime() - tp1;                                  \
         if (REQUEST) request_chunk(c, tile, ch + 2, gx, gy);                                       \
-        if ((LOADP) && !(DBG && (c.dbg & 4))) load_p_tile(c.P, c.ld, R0, C0, c.wr, c.wc, c.q, c.cl, pold); \
-        read_frag(c, smem, buf ^ 1, 0, f0);                                                        \
-        mfma_step<DBG>(c, f1, acc);                                                                \
+        if ((LOADP) && !(DBG && (c.dbg & 4))) load_p_tile(c, R0, C0, pold);                        \
         ++ch;                                                                                      \
     }
     while (ch + 3 < nch) DD_CHUNK(true, false)
@@ -275,20 +264,19 @@ __device__ __forceinline__ void dd_tile(DdCtx& c, int2 tile, int2 next, smem_t& 
 #undef DD_CHUNK
     {   // last chunk: two or four steps (kp is a multiple of 16)
         const int buf = ch & 1;
-        read_frag(c, smem, buf, 8, f1);
-        mfma_step<DBG>(c, f0, acc);
+        DD_STEPS(buf, 2)
         if (c.kp - ch * KC > 16) {
             read_frag(c, smem, buf, 16, f0);
-            mfma_step<DBG>(c, f1, acc);
-            read_frag(c, smem, buf, 24, f1);
+            mfma_step<DBG>(c, f0, acc);
+            read_frag(c, smem, buf, 24, f0);
             mfma_step<DBG>(c, f0, acc);
         }
-        mfma_step<DBG>(c, f1, acc);
     }
+#undef DD_STEPS
     if (PROF) tp1 = __builtin_amdgcn_s_memtime();
     __syncthreads();                  // every wave is done with the panels: LDS becomes epilogue scratch
     if (next.x >= 0) request_chunk(c, next, 0, gx, gy);
-    store_p_tile<DIAG>(c.P, c.ld, R0, C0, c.wr, c.wc, c.l31, c.lh, c.q, c.cl, pold, acc, sD, sV, DBG ? c.dbg : 0);
+    store_p_tile<DIAG>(c, R0, C0, pold, acc, sD, sV, DBG ? c.dbg : 0);
     __syncthreads();                  // scratch free again before the next tile's LDS fill
     if (PROF) {
         const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -297,18 +285,24 @@ __device__ __forceinline__ void dd_tile(DdCtx& c, int2 tile, int2 next, smem_t& 
     }
 }
 
-// PERSISTENT kernel: gridDim.x = 8 * nper workgroups (two per CU); workgroup b walks the tile list
-// of XCD b % 8 with stride nper.  Memory operations of a wave are asynchronous: a wave that moves on
-// to the next tile's MFMAs lets its 32 stores drain behind them.  The first tile is peeled so that
-// the loop header sees the same "8 loads, then 32 stores" history on both of its incoming edges and
-// the compiler can emit the counted wait vmcnt(32) for the panel chunk instead of vmcnt(0).
+// PERSISTENT kernel: gridDim.x = 8 * nper workgroups (two per CU: four waves per SIMD); workgroup b
+// walks the tile list of XCD b % 8 with stride nper.  Memory operations of a wave are asynchronous: a
+// wave that moves on to the next tile's MFMAs lets its stores drain behind them.  The first tile is
+// peeled so that the loop header sees the same load/store history on both of its incoming edges and the
+// compiler can emit counted vmcnt waits for the panel chunk instead of vmcnt(0).
 template <bool DBG>
-__global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ P, int ld, int n,
-                                                            const float* __restrict__ X, const float* __restrict__ Y,
-                                                            int pitch, int kp, const int2* __restrict__ tiles, int L,
-                                                            const int32_t* __restrict__ status, int dbg,
-                                                            unsigned long long* __restrict__ prof) {
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void downdate_f32_mfma(float* __restrict__ P, int ld, int n,
+                                                                 const float* __restrict__ X, const float* __restrict__ Y,
+                                                                 int pitch, int kp, const int2* __restrict__ tiles, int L,
+                                                                 const int32_t* __restrict__ status, int dbg,
+                                                                 unsigned long long* __restrict__ prof,
+                                                                 const int32_t* __restrict__ dcount, int joseph) {
     if (status[0] != 0) return;
+    if (dcount) {                     // observe(): the host's kp is an upper bound
+        const int k = 2 * dcount[0];
+        kp = joseph ? 2 * ((k + SLAM_KPAD - 1) / SLAM_KPAD * SLAM_KPAD) : (k + 15) / 16 * 16;
+        if (kp == 0) return;
+    }
     __shared__ __attribute__((aligned(16))) float smem[2][2][TILE][LDSP];   // [buffer][X|Y][row][k]  73,728 B
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -317,12 +311,12 @@ __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ 
     c.P = P; c.X = X; c.Y = Y; c.ld = ld; c.pitch = pitch; c.kp = kp; c.dbg = dbg;
     c.nchunks = (kp + KC - 1) / KC;                           // kp is a multiple of 16: the last chunk may be half
     c.wr = wave & 1;                  // row half of the tile
-    c.wc = wave >> 1;                 // column half
+    c.wc = wave >> 1;                 // column quarter
     c.l31 = lane & 31;
     c.lh = lane >> 5;
     c.q = lane & 7;
     c.cl = lane >> 3;
-    c.srow = tid >> 3;                // staging: 128 x 32 floats per panel = 1024 float4, 4 per thread per panel
+    c.srow = tid >> 3;                // staging rows srow, srow + 64
     c.sc4 = tid & 7;
     c.t_head = c.t_wait = c.t_epi = c.t_total = 0;
     const unsigned long long rt0 = DBG ? __builtin_amdgcn_s_memrealtime() : 0, mt0 = DBG ? __builtin_amdgcn_s_memtime() : 0;
@@ -338,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ 
     int slot = rk;
     int2 tile = slot < L ? list[slot] : make_int2(-1, -1);
     if (tile.x < 0) return;
-    f32x4 gx[4], gy[4];
+    f32x4 gx[2], gy[2];
     request_chunk(c, tile, 0, gx, gy);
     slot += nper;
     int2 next = slot < L ? list[slot] : make_int2(-1, -1);
@@ -362,8 +356,8 @@ __global__ __launch_bounds__(256, 2) void downdate_f32_mfma(float* __restrict__ 
         slot += nper;
         next = slot < L ? list[slot] : make_int2(-1, -1);
     }
-    if (DBG && prof && lane == 0) {                   // per wave: head wait, chunk hand-over wait, epilogue, total
-        unsigned long long* o = prof + ((size_t)blockIdx.x * 4 + wave) * 4;
+    if (DBG && prof && lane == 0) {                   // per wave: panel waits, lifetime (10 ns), epilogue, lifetime (clocks)
+        unsigned long long* o = prof + ((size_t)blockIdx.x * NWAVE + wave) * 4;
         o[0] = c.t_head + c.t_wait; o[1] = __builtin_amdgcn_s_memrealtime() - rt0; o[2] = c.t_epi;
         o[3] = __builtin_amdgcn_s_memtime() - mt0;
     }
@@ -377,8 +371,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void downdate_valu(T* __restrict__ P, int ld, int n, const T* __restrict__ X,
                                                      const T* __restrict__ Y, int pitch, int kp,
                                                      const int2* __restrict__ tiles, int L,
-                                                     const int32_t* __restrict__ status) {
+                                                     const int32_t* __restrict__ status,
+                                                     const int32_t* __restrict__ dcount, int joseph) {
     if (status[0] != 0) return;
+    if (dcount) {                     // observe(): the host's kp is an upper bound
+        const int k = 2 * dcount[0];
+        kp = joseph ? 2 * ((k + SLAM_KPAD - 1) / SLAM_KPAD * SLAM_KPAD) : (k + 15) / 16 * 16;
+        if (kp == 0) return;
+    }
     const int2 tile = tiles[(size_t)(blockIdx.x & 7) * L + (blockIdx.x >> 3)];     // workgroup b -> list b % 8, slot b / 8
     if (tile.x < 0) return;
     __shared__ T sX[DT][DK + 1];
@@ -512,7 +512,7 @@ int ensure_tile_order(slam_ekf* h, int T) {
 
 }  // namespace
 
-int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int pitch) {
+int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int pitch, const int32_t* dcount, int joseph) {
     const int n = 3 + 2 * h->N;
     const int edge = h->dtype == SLAM_F32 ? TILE : DT;
     const int rc = ensure_tile_order(h, (n + edge - 1) / edge);
@@ -524,17 +524,17 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
         if (per_xcd > h->tiles_len) per_xcd = h->tiles_len;
         if (per_xcd < 1) per_xcd = 1;
         if (h->debug_flags)      // timing experiments only (SLAMHIP_DEBUG): parts of the kernel switched off
-            hipLaunchKernelGGL(downdate_f32_mfma<true>, dim3(8 * per_xcd), dim3(256), 0, h->stream, (float*)h->P, h->ld, n,
+            hipLaunchKernelGGL(downdate_f32_mfma<true>, dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,
                                (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
-                               h->d_status, h->debug_flags, (unsigned long long*)h->dd_prof);
+                               h->d_status, h->debug_flags, (unsigned long long*)h->dd_prof, dcount, joseph);
         else
-            hipLaunchKernelGGL(downdate_f32_mfma<false>, dim3(8 * per_xcd), dim3(256), 0, h->stream, (float*)h->P, h->ld, n,
+            hipLaunchKernelGGL(downdate_f32_mfma<false>, dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,
                                (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
-                               h->d_status, 0, (unsigned long long*)nullptr);
+                               h->d_status, 0, (unsigned long long*)nullptr, dcount, joseph);
     } else {
         hipLaunchKernelGGL(downdate_valu<double>, dim3(8 * h->tiles_len), dim3(256), 0, h->stream, (double*)h->P, h->ld, n,
                            (const double*)X, (const double*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
-                           h->d_status);
+                           h->d_status, dcount, joseph);
     }
     HIP_TRY(hipGetLastError());
     return SLAM_OK;

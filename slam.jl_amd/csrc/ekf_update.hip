@@ -20,9 +20,17 @@
 #include "common.h"
 #include "device_math.h"
 
-int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int pitch);   // ekf_syrk.hip
+int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int pitch, const int32_t* dcount, int joseph);   // ekf_syrk.hip
 
 namespace {
+
+// observe(): the host launches with an upper bound of the matched count; the kernels read the real one.
+#define SLAM_DEVICE_COUNT(dcount, m, k, kp)          \
+    if (dcount) {                                    \
+        m = dcount[0];                               \
+        k = 2 * m;                                   \
+        kp = (k + SLAM_KPAD - 1) / SLAM_KPAD * SLAM_KPAD; \
+    }
 
 // ---------------------------------------------------------------------------
 // K2/K3: PHt[r, 2i:2i+2] = P[r,0:3]*Hv_i' + P[r,f_i:f_i+2]*Hf_i'
@@ -33,11 +41,14 @@ constexpr int PHT_OBS = 16;
 template <typename T>
 __global__ __launch_bounds__(256) void pht_kernel(const T* __restrict__ x, const T* __restrict__ P, int ld, int n,
                                                    const int32_t* __restrict__ idf, int m, int k, int kp,
-                                                   double* __restrict__ PHt, int pitch, int tile_log2) {
+                                                   double* __restrict__ PHt, int pitch, int tile_log2,
+                                                   const int32_t* __restrict__ dcount) {
     __shared__ double sh[PHT_OBS][10];
     __shared__ int sf[PHT_OBS];
+    SLAM_DEVICE_COUNT(dcount, m, k, kp)
     const int tid = threadIdx.x;
     const int i0 = blockIdx.y * PHT_OBS;
+    if (2 * i0 >= kp) return;                                   // (device count: a chunk beyond the padded width)
     const int mc = (m - i0 < PHT_OBS) ? m - i0 : PHT_OBS;       // observations in this chunk (may be <= 0 for pure padding)
     if (tid < mc) {
         const double xv = (double)x[0], yv = (double)x[1], phi = (double)x[2];
@@ -203,13 +214,19 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
     const T* __restrict__ x, const double* __restrict__ PHt, int pht_pitch, const double* __restrict__ z,
     const int32_t* __restrict__ idf, int m, int k, int kp, double R0, double R1, double R2, double R3,
     double* __restrict__ Cout, int c_pitch, double* __restrict__ gvec, double* __restrict__ Sout, int want_sinv,
-    double* __restrict__ Mglobal, int32_t* __restrict__ status, unsigned long long* __restrict__ stamps) {
+    double* __restrict__ Mglobal, int32_t* __restrict__ status, unsigned long long* __restrict__ stamps,
+    const int32_t* __restrict__ dcount) {
 #define STAMP(i)                                                  \
     do {                                                          \
         if (stamps && threadIdx.x == 0) stamps[i] = wall_clock64(); \
     } while (0)
     extern __shared__ double lds[];
     STAMP(0);
+    SLAM_DEVICE_COUNT(dcount, m, k, kp)
+    if (m == 0) {                                            // (device count) nothing matched: the update is the identity
+        if (threadIdx.x == 0) status[0] = 0;
+        return;
+    }
     const int tid = threadIdx.x;
     const int nt = blockDim.x;
     const int mp = kp + 1;                                   // odd pitch: conflict-free column walks
@@ -413,8 +430,17 @@ __global__ __launch_bounds__(256) void panel_gemm_kernel(const double* __restric
                                                           double beta, TO* __restrict__ OUT1, int out1_pitch, int out1_col,
                                                           TO* __restrict__ OUT2, int out2_pitch, int out2_col,
                                                           double* __restrict__ OUTD, int outd_pitch,
-                                                          const int32_t* __restrict__ status) {
+                                                          const int32_t* __restrict__ status,
+                                                          const int32_t* __restrict__ dcount) {
     if (status[0] != 0) return;
+    if (dcount) {                                            // out*_col is 0 or the (host upper bound of) kp
+        const int kp_host = kp;
+        int m = 0, k = 0;
+        SLAM_DEVICE_COUNT(dcount, m, k, kp)
+        if (out1_col == kp_host) out1_col = kp;
+        if (out2_col == kp_host) out2_col = kp;
+        if ((int)(blockIdx.y * PG_COLS) >= kp) return;
+    }
     __shared__ double sIn[PG_ROWS][PG_KC + 1];
     __shared__ __attribute__((aligned(16))) double sMat[PG_KC][PG_COLS];
     const int tid = threadIdx.x;
@@ -487,8 +513,10 @@ __global__ __launch_bounds__(256) void panel_gemm_kernel(const double* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void x_update_kernel(T* __restrict__ x, const double* __restrict__ PHt, int pitch, int n,
                                                         int k, const double* __restrict__ g,
-                                                        const int32_t* __restrict__ status) {
+                                                        const int32_t* __restrict__ status,
+                                                        const int32_t* __restrict__ dcount) {
     if (status[0] != 0) return;
+    if (dcount) k = 2 * dcount[0];
     const int r = blockIdx.x * 32 + (threadIdx.x >> 3);
     const int part = threadIdx.x & 7;
     double s = 0.0;
@@ -503,7 +531,7 @@ __global__ __launch_bounds__(256) void x_update_kernel(T* __restrict__ x, const 
 }
 
 template <typename T>
-int update_typed(slam_ekf* h, int m, const double R[4], int form) {
+int update_typed(slam_ekf* h, int m, const double R[4], int form, const int32_t* dcount) {
     const int n = 3 + 2 * h->N;
     const int k = 2 * m;
     const int kp = round_up(k, SLAM_KPAD);
@@ -519,7 +547,7 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form) {
         KTimer t(h, SLAM_K_PHT);
         const dim3 grid((n + 255) / 256, kp / (2 * PHT_OBS));
         hipLaunchKernelGGL(pht_kernel<T>, grid, dim3(256), 0, h->stream, x, P, h->ld, n, h->idfbuf, m, k, kp, h->PHt, pitchA,
-                           h->dtype == SLAM_F32 ? 7 : 6);
+                           h->dtype == SLAM_F32 ? 7 : 6, dcount);
     }
     HIP_TRY(hipGetLastError());
     {   // K4
@@ -531,11 +559,11 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form) {
         if (in_lds)
             hipLaunchKernelGGL((factor_kernel<T, true>), dim3(1), dim3(FACTOR_THREADS), shm, h->stream, x, h->PHt, pitchA,
                                h->obsbuf, h->idfbuf, m, k, kp, R[0], R[1], R[2], R[3], h->Cmat, pitchA, h->gvec,
-                               joseph ? h->Smat : (double*)nullptr, joseph ? 1 : 0, (double*)nullptr, h->d_status, stamps);
+                               joseph ? h->Smat : (double*)nullptr, joseph ? 1 : 0, (double*)nullptr, h->d_status, stamps, dcount);
         else
             hipLaunchKernelGGL((factor_kernel<T, false>), dim3(1), dim3(FACTOR_THREADS), shm, h->stream, x, h->PHt, pitchA,
                                h->obsbuf, h->idfbuf, m, k, kp, R[0], R[1], R[2], R[3], h->Cmat, pitchA, h->gvec,
-                               joseph ? h->Smat : (double*)nullptr, joseph ? 1 : 0, h->Mwork, h->d_status, stamps);
+                               joseph ? h->Smat : (double*)nullptr, joseph ? 1 : 0, h->Mwork, h->d_status, stamps, dcount);
     }
     HIP_TRY(hipGetLastError());
     const dim3 pg_grid(h->npad / PG_ROWS, (kp + PG_COLS - 1) / PG_COLS);
@@ -546,30 +574,31 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form) {
             // W1 = PHt*C
             hipLaunchKernelGGL(panel_gemm_kernel<T>, pg_grid, dim3(256), 0, h->stream, h->PHt, pitchA, h->Cmat, pitchA, kp, 1,
                                1.0, (const double*)nullptr, 0, 0.0, W1, pitchW, 0, (T*)nullptr, 0, 0, (double*)nullptr, 0,
-                               h->d_status);
+                               h->d_status, dcount);
             kp_total = round_up(k, 16);      // W1 is zero in columns k..kp-1: the down-date stops at the next multiple of 16
         } else {
             // K = PHt*inv(S)            -> W1[:, 0:kp], W2[:, kp:2kp], Kd (double)
             hipLaunchKernelGGL(panel_gemm_kernel<T>, pg_grid, dim3(256), 0, h->stream, h->PHt, pitchA, h->Cmat, pitchA, kp, 0,
                                1.0, (const double*)nullptr, 0, 0.0, W1, pitchW, 0, W2, pitchW, kp, h->Kd, pitchA,
-                               h->d_status);
+                               h->d_status, dcount);
             // T = PHt - 0.5 * K * S     -> W1[:, kp:2kp], W2[:, 0:kp]
             hipLaunchKernelGGL(panel_gemm_kernel<T>, pg_grid, dim3(256), 0, h->stream, (const double*)h->Kd, pitchA,
                                (const double*)h->Smat, pitchA, kp, 0, -0.5, (const double*)h->PHt, pitchA, 1.0, W1, pitchW,
-                               kp, W2, pitchW, 0, (double*)nullptr, 0, h->d_status);
+                               kp, W2, pitchW, 0, (double*)nullptr, 0, h->d_status, dcount);
             kp_total = 2 * kp;
         }
         hipLaunchKernelGGL(x_update_kernel<T>, dim3((n + 31) / 32), dim3(256), 0, h->stream, x, h->PHt, pitchA, n, k, h->gvec,
-                           h->d_status);
+                           h->d_status, dcount);
     }
     HIP_TRY(hipGetLastError());
-    return launch_downdate(h, kp_total, W1, joseph ? (const void*)W2 : (const void*)W1, pitchW);
+    return launch_downdate(h, kp_total, W1, joseph ? (const void*)W2 : (const void*)W1, pitchW, dcount, joseph ? 1 : 0);
 }
 
 }  // namespace
 
-int launch_update(slam_ekf* h, int m, const double R[4], int form) {
-    return h->dtype == SLAM_F32 ? update_typed<float>(h, m, R, form) : update_typed<double>(h, m, R, form);
+int launch_update(slam_ekf* h, int m, const double R[4], int form, bool device_count) {
+    const int32_t* dcount = device_count ? h->d_count : (const int32_t*)nullptr;
+    return h->dtype == SLAM_F32 ? update_typed<float>(h, m, R, form, dcount) : update_typed<double>(h, m, R, form, dcount);
 }
 
 int update_kernels_init() {

@@ -30,6 +30,7 @@ from . import _lib
 from ._lib import SLAM_F32, SLAM_F64, SLAM_FORM_CHOLESKY, SLAM_FORM_JOSEPH, check, lib
 
 __all__ = [
+    "observe",
     "SlamState", "EKFSlamState", "DeviceRef", "predict", "update", "add_features", "associate",
     "compute_association", "predict_observation", "mpi_to_pi", "ekf_predict_", "ekf_update_", "augment_",
 ]
@@ -283,6 +284,20 @@ class EKFSlamState(SlamState):
         r = _small(R)
         check(lib.slam_ekf_augment(self._h, _ptr(zp), zp.shape[0], _ptr(r)))
 
+    def observe(self, z, R, gate1, gate2, form="cholesky"):
+        """associate -> update -> add_features (src/sim.jl:114-120) in one library call with no host
+        round trip between the gating and the update.  Returns the association vector
+        (see associate_vector); the state afterwards equals the three calls in sequence."""
+        zp = _obs(z)
+        nz = zp.shape[0]
+        assoc = np.zeros(nz, dtype=np.int32)
+        if nz:
+            r = _small(R)
+            code = SLAM_FORM_JOSEPH if form == "joseph" else SLAM_FORM_CHOLESKY
+            check(lib.slam_ekf_observe(self._h, _ptr(zp), nz, _ptr(r), float(gate1), float(gate2), code,
+                                       _ptr(assoc, C.c_int32)))
+        return assoc
+
     def compute_association(self, z, R, idf):
         zz = _dbl(z, 2)
         r = _small(R)
@@ -362,6 +377,11 @@ def add_features(state: EKFSlamState, z, R):
 def associate(state: SlamState, z, R, gate1, gate2):
     """associate(state, z, R, gate1, gate2) -> (zf, idf, zn)   src/data-association.jl:1-51."""
     return state.associate(z, R, gate1, gate2)
+
+
+def observe(state: EKFSlamState, z, R, gate1, gate2, form="cholesky"):
+    """associate + update + add_features (sim/ekfslam-sim.jl:114-120) in one call -> association vector."""
+    return _state_of(state).observe(z, R, gate1, gate2, form=form)
 
 
 def _temp_state(x, P=None):

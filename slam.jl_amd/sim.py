@@ -161,10 +161,12 @@ def default_QR():
 
 
 def sim(filt, waypoints: np.ndarray, landmarks: np.ndarray, seed: int, nlaps: int = 2,
-        max_steps: int = 100000, monitor=None) -> SimLog:
+        max_steps: int = 100000, monitor=None, fused: bool = False) -> SimLog:
     """The loop of sim/ekfslam-sim.jl:80-141 without sleep/pause.
 
     ``filt`` must already hold the initial state (x = initial pose, P = 0).
+    ``fused``: use ``filt.observe`` (associate + update + add_features in one library call,
+    same results) instead of the three calls of :114-120.
     """
     rng = np.random.default_rng(seed)
     Q, R = default_QR()
@@ -186,9 +188,14 @@ def sim(filt, waypoints: np.ndarray, landmarks: np.ndarray, seed: int, nlaps: in
         if dtsum > DT_OBS:                                                # :105 (fires every 9th step)
             dtsum = 0.0
             z, _tags = get_observations(vehicle, landmarks, R, rng)       # :108
-            zf, idf, zn = filt.associate(z, R, GATE1, GATE2)              # :114
-            filt.update(zf, R, idf)                                       # :117
-            filt.add_features(zn, R)                                      # :120
+            if fused:
+                assoc = np.asarray(filt.observe(z, R, GATE1, GATE2))      # :114-120 in one call
+                idf = assoc[assoc > 0]
+                zn = np.asarray(z, dtype=float).reshape(2, -1)[:, assoc < 0]
+            else:
+                zf, idf, zn = filt.associate(z, R, GATE1, GATE2)          # :114
+                filt.update(zf, R, idf)                                   # :117
+                filt.add_features(zn, R)                                  # :120
             log.obs_steps.append(nsteps)
             log.observations.append(np.array(z))
             log.assoc.append((np.asarray(idf).reshape(-1).tolist(), int(np.asarray(zn).reshape(2, -1).shape[1])))

@@ -227,6 +227,59 @@ def test_full_cycle_against_oracle(pkg, dtype, N, m, nn):
     st.close()
 
 
+@pytest.mark.parametrize("form", ["cholesky", "joseph"])
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,m,nn,ndrop", [(3, 2, 1, 0), (64, 16, 3, 2), (200, 0, 4, 0), (200, 9, 0, 3), (1000, 70, 2, 1)])
+def test_observe_equals_the_three_calls(pkg, dtype, form, N, m, nn, ndrop):
+    """slam_ekf_observe = associate -> update -> add_features (sim/ekfslam-sim.jl:114-120): BIT-identical
+    state to the three library calls, and within tolerance of the oracle's sequence.  Matched, new and
+    dropped observations are interleaved so the device-side compaction has work to do."""
+    rng = np.random.default_rng(77 * N + m + nn)
+    x, P = random_state(rng, N)
+    a_st = pkg.EKFSlamState(x, P, dtype=dtype, max_landmarks=N + 16)
+    b_st = pkg.EKFSlamState(x, P, dtype=dtype, max_landmarks=N + 16)
+    xo, Po = rounded(a_st)
+    ids = rng.choice(np.arange(1, N + 1), size=m, replace=False)
+    zm = noisy_obs(rng, xo, ids)
+    znew = np.vstack([rng.uniform(300, 400, nn), rng.uniform(-1, 1, nn)])
+    # "dropped": inside the outer gate of a landmark but outside the inner one (4 < nis <= 25)
+    zd = noisy_obs(rng, xo, rng.choice(np.arange(1, N + 1), size=ndrop, replace=False)) + np.array([[0.45], [0.0]])
+    z = np.hstack([zm, znew, zd])[:, rng.permutation(m + nn + ndrop)]
+    a = a_st.observe(z, R, 4.0, 25.0, form=form)
+    nis, nd = O.association_table_sparse(xo, Po, z, R)
+    ao = O.assoc_vector(nis, nd, 4.0, 25.0)
+    assert np.array_equal(a, ao)
+    zf, idf, zn = b_st.associate(z, R, 4.0, 25.0)
+    b_st.update(zf, R, idf, form=form)
+    b_st.add_features(zn, R)
+    xa, Pa = a_st.download()
+    xb, Pb = b_st.download()
+    assert a_st.N == b_st.N == N + int(np.sum(ao < 0))
+    assert np.array_equal(xa, xb) and np.array_equal(Pa, Pb), "fused and unfused paths must agree bit for bit"
+    zfo, idfo, zno = O.split_assoc(z, ao)
+    if form == "cholesky":
+        xo2, Po2 = O.update_sparse(xo, Po, zfo, R, idfo)
+    else:
+        xo2, Po2 = O.update_joseph_sparse(xo, Po, zfo, R, idfo)
+    xo2, Po2 = O.add_features_sparse(xo2, Po2, zno, R)
+    check_state(a_st, xo2, Po2, dtype, "observe", fx=4.0, fP=100.0, prior=Po)
+    a_st.close()
+    b_st.close()
+
+
+def test_observe_edge_cases(pkg):
+    st = pkg.EKFSlamState(np.array([1.0, 2.0, 0.3]), np.zeros((3, 3)), dtype="f64", max_landmarks=4)
+    assert st.observe(np.zeros((2, 0)), R, 4.0, 25.0).shape == (0,)
+    a = st.observe(np.array([[10.0, 12.0], [0.1, -0.4]]), R, 4.0, 25.0)        # empty map: everything is new
+    assert np.array_equal(a, [-1, -1]) and st.N == 2
+    a = st.observe(np.array([[10.0, 12.0], [0.1, -0.4]]), R, 4.0, 25.0)        # now both match
+    assert np.array_equal(a, [1, 2]) and st.N == 2
+    with pytest.raises(pkg.SlamHipError):                                     # capacity: 2 + 3 > 4
+        st.observe(np.array([[50.0, 60.0, 70.0], [1.0, 2.0, 3.0]]), R, 4.0, 25.0)
+    assert st.N == 2
+    st.close()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_reference_call_pattern(pkg, dtype):
     """`state.x, state.cov = f(state, ...)` as in sim/ekfslam-sim.jl:100-120."""
@@ -398,7 +451,15 @@ def test_headless_sim_end_to_end(pkg, golden_dir, config1):
     assert np.allclose(np.array(log.slam_track), config1["slam_track"], rtol=1e-6, atol=1e-6)
     err = np.linalg.norm(np.array(log.true_track)[:, :2] - np.array(log.slam_track)[:, :2], axis=1)
     assert err.max() < 2.0 and st.N == 35
+    # the same run through the fused observation step: identical filter, identical tracks
+    st2 = pkg.EKFSlamState(S.initial_pose(wp), np.zeros((3, 3)), dtype="f64", max_landmarks=40)
+    log2 = S.sim(st2, wp, config1["landmarks"], seed=int(config1["seed"][1]), nlaps=2, fused=True)
+    assert np.array_equal(np.array(log2.slam_track), np.array(log.slam_track)) and st2.N == 35
+    x1, P1 = st.download()
+    x2, P2 = st2.download()
+    assert np.array_equal(x1, x2) and np.array_equal(P1, P2)
     st.close()
+    st2.close()
 
 
 def test_timing_hooks(pkg):

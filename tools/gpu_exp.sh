@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
-for d in 0 8 13 10; do
+for d in 0 0; do
   SLAMHIP_DEBUG=$d timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>>gpurun_out/exp.log | python -c "
 import sys,json
 for l in sys.stdin:
