@@ -147,8 +147,10 @@ int slam_ekf_observe(slam_ekf_t h, const double* z, int nz, const double R[4],
 int slam_ekf_set_async(slam_ekf_t h, int async_updates);
 /* Wait for the handle's stream; returns the first deferred error (and clears it). */
 int slam_ekf_sync(slam_ekf_t h);
-/* When enabled every kernel launch is bracketed by HIP events on the handle's
- * stream.  timing_read synchronises, folds the pending events into per-kernel
+/* enable = 1: every kernel launch is bracketed by HIP events on the handle's
+ * stream; enable = a mask of (2 << SLAM_K_x): only those kernels (an event pair costs
+ * ~10 us of stream time, so a benchmark brackets the dominant kernel only); 0: off.
+ * timing_read synchronises, folds the pending events into per-kernel
  * totals and returns total milliseconds and launch count for kernel id `kid`. */
 int slam_ekf_timing(slam_ekf_t h, int enable);
 int slam_ekf_timing_read(slam_ekf_t h, int kid, double* total_ms, int64_t* launches);

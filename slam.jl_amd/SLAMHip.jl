@@ -14,7 +14,7 @@ module SLAMHip
 
 export SlamState, EKFSlamState, set_state!, predict, update, add_features, associate,
        compute_association, predict_observation, mpi_to_pi,
-       ekf_predict!, ekf_update!, augment!
+       ekf_predict!, ekf_update!, augment!, observe!
 
 const libslamhip = get(ENV, "SLAMHIP_LIB", joinpath(@__DIR__, "libslamhip.so"))
 
@@ -146,6 +146,24 @@ function augment!(s::EKFSlamState, z::AbstractMatrix, R::AbstractMatrix)
     check(ccall((:slam_ekf_augment, libslamhip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Cdouble}),
                 handle(s), pairs64(z), nn, colmajor4(R)))
     s
+end
+
+"""
+observe!(state, z, R, gate1, gate2; form = :cholesky) -> assoc::Vector{Int32}
+
+The observation step of sim! (sim/ekfslam-sim.jl:114-120: associate, update, add_features) as one
+library call with the same results; no host round trip between the gating and the update.
+assoc[i] >= 1: matched landmark, 0: dropped, -1: appended as a new feature.
+"""
+function observe!(s::EKFSlamState, z::AbstractMatrix, R::AbstractMatrix, gate1::Real, gate2::Real;
+                  form::Symbol = :cholesky)
+    nz = size(z, 2)
+    assoc = zeros(Int32, nz)
+    nz == 0 && return assoc
+    check(ccall((:slam_ekf_observe, libslamhip), Cint,
+                (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Cdouble, Cdouble, Cint, Ptr{Int32}),
+                handle(s), pairs64(z), nz, colmajor4(R), gate1, gate2, form == :joseph ? 1 : 0, assoc))
+    assoc
 end
 
 # ---- the reference's function surface ------------------------------------------------------

@@ -33,7 +33,7 @@ extern "C" int slam_device_count(void) {
 }
 
 // ---- timing ------------------------------------------------------------------
-KTimer::KTimer(slam_ekf* h_, int kid) : h(h_), on(h_->timing != 0) {
+KTimer::KTimer(slam_ekf* h_, int kid) : h(h_), on(h_->timing == 1 || ((h_->timing >> (kid + 1)) & 1)) {
     if (!on) return;
     if (!h->free_pairs.empty()) {
         p = h->free_pairs.back();
@@ -105,6 +105,8 @@ int ensure_obs_capacity(slam_ekf* h, int nobs) {
     HIP_TRY(hipHostMalloc((void**)&h->h_obs, sizeof(double) * 2 * cap, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&h->h_idf, sizeof(int32_t) * cap, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&h->h_assoc, sizeof(int32_t) * cap, hipHostMallocDefault));
+    HIP_TRY(hipHostGetDevicePointer((void**)&h->h_obs_dev, h->h_obs, 0));
+    HIP_TRY(hipHostGetDevicePointer((void**)&h->h_assoc_dev, h->h_assoc, 0));
     h->ocap = cap;
     return SLAM_OK;
 }
@@ -383,7 +385,7 @@ extern "C" int slam_ekf_associate(slam_ekf_t h, const double* z, int nz, const d
     }
     HIP_TRY(hipSetDevice(h->device));
     if ((rc = stage_obs(h, z, nullptr, nz))) return rc;
-    if ((rc = launch_gate(h, nz, R, gate1, gate2))) return rc;
+    if ((rc = launch_gate(h, nz, R, gate1, gate2, h->obsbuf))) return rc;
     HIP_TRY(hipMemcpyAsync(h->h_assoc, h->d_assoc, sizeof(int32_t) * (size_t)nz, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     memcpy(assoc, h->h_assoc, sizeof(int32_t) * (size_t)nz);
@@ -490,13 +492,19 @@ extern "C" int slam_ekf_observe(slam_ekf_t h, const double* z, int nz, const dou
         return slam_ekf_augment(h, z, nz, R);
     }
     if ((rc = ensure_update_workspace(h, nz))) return rc;
-    if ((rc = stage_obs(h, z, nullptr, nz))) return rc;
-    if ((rc = launch_gate(h, nz, R, gate1, gate2))) return rc;
-    if ((rc = launch_compact(h, nz))) return rc;
-    HIP_TRY(hipMemcpyAsync(h->h_assoc, h->d_assoc, sizeof(int32_t) * (size_t)nz, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipEventRecord(h->assoc_ev, h->stream));
+    if ((rc = ensure_obs_capacity(h, nz))) return rc;
+    // zero-copy staging: the kernels read z from, and write the decisions to, pinned host memory -- no blit
+    // kernels on the critical path.  The pinned buffers are free again once the compaction kernel has run.
+    if (h->stage_pending) {
+        HIP_TRY(hipEventSynchronize(h->stage_ev));
+        h->stage_pending = 0;
+    }
+    memcpy(h->h_obs, z, sizeof(double) * 2 * (size_t)nz);
+    if ((rc = launch_gate(h, nz, R, gate1, gate2, h->h_obs_dev))) return rc;
+    if ((rc = launch_compact(h, nz, h->h_obs_dev))) return rc;
+    HIP_TRY(hipEventRecord(h->assoc_ev, h->stream));       // (also marks the pinned buffers as consumed)
     if ((rc = launch_update(h, nz, R, form, true))) return rc;
-    HIP_TRY(hipEventSynchronize(h->assoc_ev));          // gating + copy only: the update runs on behind it
+    HIP_TRY(hipEventSynchronize(h->assoc_ev));          // gating only: the update runs on behind it
     int nn = 0;
     for (int i = 0; i < nz; ++i) {
         assoc[i] = h->h_assoc[i];
@@ -547,7 +555,7 @@ extern "C" int slam_ekf_debug_stamps(slam_ekf_t h, int enable, uint64_t* out8) {
 
 extern "C" int slam_ekf_timing(slam_ekf_t h, int enable) {
     ARG_CHECK(h != nullptr, "null handle");
-    h->timing = enable ? 1 : 0;
+    h->timing = enable < 0 ? 0 : enable;
     return SLAM_OK;
 }
 

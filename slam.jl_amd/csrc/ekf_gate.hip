@@ -226,18 +226,20 @@ __global__ void single_pair_kernel(const T* __restrict__ x, const T* __restrict_
 }
 
 // observe(): turn the association vector into the update's and add_features' inputs without leaving the device.
-// One wave walks the observations in order, 64 at a time: matched ones (assoc >= 1) are compacted IN PLACE to the
-// front of zbuf/idf (a write position never passes the read position of a later chunk), new ones (assoc < 0) go
-// to zn.  count = {matched, new}.  Order is the observation order, as in data-association.jl:43-47.
-__global__ __launch_bounds__(64) void compact_kernel(const int32_t* __restrict__ assoc, int nz, double* __restrict__ zbuf,
+// One wave walks the observations in order, 64 at a time: matched ones (assoc >= 1) are compacted to the front
+// of zbuf/idf (zsrc may BE zbuf: a write position never passes the read position of a later chunk), new ones
+// (assoc < 0) go to zn.  count = {matched, new}.  Order is the observation order, as in data-association.jl:43-47.
+__global__ __launch_bounds__(64) void compact_kernel(const int32_t* __restrict__ assoc, int nz,
+                                                     const double* __restrict__ zsrc, double* __restrict__ zbuf,
                                                      int32_t* __restrict__ idf, double* __restrict__ zn,
-                                                     int32_t* __restrict__ count) {
+                                                     int32_t* __restrict__ count, int32_t* __restrict__ assoc_host) {
     const int lane = threadIdx.x;
     int m = 0, nn = 0;
     for (int base = 0; base < nz; base += 64) {
         const int i = base + lane;
         const int a = i < nz ? assoc[i] : 0;
-        const double z0 = i < nz ? zbuf[2 * i] : 0.0, z1 = i < nz ? zbuf[2 * i + 1] : 0.0;
+        const double z0 = i < nz ? zsrc[2 * i] : 0.0, z1 = i < nz ? zsrc[2 * i + 1] : 0.0;
+        if (i < nz) assoc_host[i] = a;           // pinned host memory: the host reads it after the event behind this kernel
         const unsigned long long mm = __ballot(a > 0), mn = __ballot(a < 0);
         const unsigned long long below = (1ull << lane) - 1ull;
         __builtin_amdgcn_s_waitcnt(0);           // every lane holds its z before any lane overwrites the front
@@ -263,14 +265,14 @@ __global__ __launch_bounds__(64) void compact_kernel(const int32_t* __restrict__
 
 }  // namespace
 
-int launch_compact(slam_ekf* h, int nz) {
-    hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(64), 0, h->stream, (const int32_t*)h->d_assoc, nz, h->obsbuf, h->idfbuf,
-                       h->znbuf, h->d_count);
+int launch_compact(slam_ekf* h, int nz, const double* z_src) {
+    hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(64), 0, h->stream, (const int32_t*)h->d_assoc, nz, z_src, h->obsbuf,
+                       h->idfbuf, h->znbuf, h->d_count, h->h_assoc_dev);
     HIP_TRY(hipGetLastError());
     return SLAM_OK;
 }
 
-int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gate2) {
+int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gate2, const double* z_src) {
     const int nblocks = (h->N + GATE_BLOCK - 1) / GATE_BLOCK;
     if (nblocks > h->gate_blocks_cap) {
         slam_set_error("internal: gate partial buffer too small");
@@ -281,7 +283,7 @@ int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gat
     for (int o = 0; o < nz; o += CHUNK) {
         const int cz = nz - o < CHUNK ? nz - o : CHUNK;
         const size_t shmem = (size_t)(2 * cz + 3 * GATE_WAVES * cz) * sizeof(double);
-        const double* zc = h->obsbuf + 2 * (size_t)o;
+        const double* zc = z_src + 2 * (size_t)o;
         {
             KTimer t(h, SLAM_K_GATE);
             if (h->dtype == SLAM_F32)

@@ -509,6 +509,100 @@ __global__ __launch_bounds__(256) void panel_gemm_kernel(const double* __restric
     }
 }
 
+// ---------------------------------------------------------------------------
+// K5 (reference form), kp <= 128:  W1 = PHt*C and x += PHt*g in ONE kernel on the fp64 matrix cores.
+//
+// v_mfma_f64_16x16x4_f64 (exact fp64 FMAs; layout probed with tools/mfma_f64_layout.hip):
+//   A[i][kk]: lane = i + 16*kk      B[kk][j]: lane = j + 16*kk      D[4r + lane/16][lane%16] in register r.
+// A wave owns 16 rows of PHt, held in registers for the whole product (and for x += PHt*g); C sits in LDS.
+// The k index inside one MFMA is only a label: lane group kk takes k = 8s + 2kk + t (t = 0, 1) so that a lane
+// loads PAIRS of consecutive doubles (16-byte loads).  C is upper triangular: column block cb needs k < 16(cb+1)
+// only -- 144 instead of 256 MFMAs per wave at kp = 128.  A workgroup = 8 waves = 128 rows.
+// ---------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+constexpr int W1_THREADS = 512;
+
+template <typename TO, int NCB>      // NCB = kp / 16
+__device__ __forceinline__ void w1_mfma_body(const double* __restrict__ PHt, int pitchA, const double* sC, int kp,
+                                             TO* __restrict__ W1, int pitchW, TO* __restrict__ x, int n,
+                                             const double* __restrict__ g) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kk = lane >> 4;
+    const int r0 = (blockIdx.x * (W1_THREADS / 64) + wave) * 16;
+    // the wave's 16 x kp block of PHt: all loads in flight at once
+    f64x2 a[NCB * 2];
+    const double* arow = PHt + (size_t)(r0 + i) * pitchA + 2 * kk;
+#pragma unroll
+    for (int s = 0; s < NCB * 2; ++s) a[s] = *reinterpret_cast<const f64x2*>(arow + 8 * s);
+    f64x4 acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) acc[cb] = f64x4{0.0, 0.0, 0.0, 0.0};
+    __syncthreads();                 // C is in LDS
+#pragma unroll
+    for (int s = 0; s < NCB * 2; ++s) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const double* brow = sC + (size_t)(8 * s + 2 * kk + t) * kp + i;     // B[kk][j = i]
+#pragma unroll
+            for (int cb = s / 2; cb < NCB; ++cb)                                 // C[k][c] = 0 for k > c
+                acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][t], brow[16 * cb], acc[cb], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            W1[(size_t)(r0 + 4 * r + kk) * pitchW + 16 * cb + i] = (TO)acc[cb][r];
+    // x += PHt*g  (ekf.jl:74 with W*v = PHt*(C*C'*v)): lane (i, kk) holds a quarter of row i
+    double sx = 0.0;
+#pragma unroll
+    for (int s = 0; s < NCB * 2; ++s) {
+        const f64x2 gg = *reinterpret_cast<const f64x2*>(g + 8 * s + 2 * kk);
+        sx = __builtin_fma(a[s][0], gg[0], sx);
+        sx = __builtin_fma(a[s][1], gg[1], sx);
+    }
+    sx += __shfl_xor(sx, 16);
+    sx += __shfl_xor(sx, 32);
+    if (kk == 0 && r0 + i < n) x[r0 + i] = (TO)((double)x[r0 + i] + sx);
+}
+
+template <typename TO>
+__global__ __launch_bounds__(W1_THREADS) void w1_mfma_kernel(const double* __restrict__ PHt, int pitchA,
+                                                             const double* __restrict__ Cmat, int pitchC, int kp,
+                                                             TO* __restrict__ W1, int pitchW, TO* __restrict__ x, int n,
+                                                             const double* __restrict__ g,
+                                                             const int32_t* __restrict__ status,
+                                                             const int32_t* __restrict__ dcount) {
+    if (status[0] != 0) return;
+    if (dcount) {
+        int m = 0, k = 0;
+        SLAM_DEVICE_COUNT(dcount, m, k, kp)
+        if (m == 0) return;
+    }
+    extern __shared__ double sC[];                    // [kp][kp]
+    // stage C: eight loads in flight per thread (a plain copy loop serialises one L2 latency per element)
+    for (int base = 0; base < kp * kp; base += 8 * W1_THREADS) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * W1_THREADS + threadIdx.x;
+            const int a = idx / kp, c = idx - a * kp;
+            v[u] = (idx < kp * kp && a <= c) ? Cmat[(size_t)a * pitchC + c] : 0.0;      // upper triangular
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * W1_THREADS + threadIdx.x;
+            if (idx < kp * kp) sC[idx] = v[u];
+        }
+    }
+    // (the barrier is inside the body, after the wave's PHt loads have been issued)
+    if (kp == 32) w1_mfma_body<TO, 2>(PHt, pitchA, sC, kp, W1, pitchW, x, n, g);
+    else if (kp == 64) w1_mfma_body<TO, 4>(PHt, pitchA, sC, kp, W1, pitchW, x, n, g);
+    else if (kp == 96) w1_mfma_body<TO, 6>(PHt, pitchA, sC, kp, W1, pitchW, x, n, g);
+    else w1_mfma_body<TO, 8>(PHt, pitchA, sC, kp, W1, pitchW, x, n, g);
+}
+
 // x += PHt * g      (ekf.jl:74 with W*v = PHt*(C*C'*v)); 8 lanes per row
 template <typename T>
 __global__ __launch_bounds__(256) void x_update_kernel(T* __restrict__ x, const double* __restrict__ PHt, int pitch, int n,
@@ -570,7 +664,13 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form, const int32_t*
     int kp_total;
     {   // K5
         KTimer t(h, SLAM_K_W1);
-        if (!joseph) {
+        if (!joseph && kp <= 128) {
+            // W1 = PHt*C and x += PHt*g on the fp64 matrix cores
+            hipLaunchKernelGGL(w1_mfma_kernel<T>, dim3(h->npad / 128), dim3(W1_THREADS), (size_t)kp * kp * sizeof(double),
+                               h->stream, (const double*)h->PHt, pitchA, (const double*)h->Cmat, pitchA, kp, W1, pitchW, x, n,
+                               (const double*)h->gvec, h->d_status, dcount);
+            kp_total = round_up(k, 16);
+        } else if (!joseph) {
             // W1 = PHt*C
             hipLaunchKernelGGL(panel_gemm_kernel<T>, pg_grid, dim3(256), 0, h->stream, h->PHt, pitchA, h->Cmat, pitchA, kp, 1,
                                1.0, (const double*)nullptr, 0, 0.0, W1, pitchW, 0, (T*)nullptr, 0, 0, (double*)nullptr, 0,
@@ -587,8 +687,9 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form, const int32_t*
                                kp, W2, pitchW, 0, (double*)nullptr, 0, h->d_status, dcount);
             kp_total = 2 * kp;
         }
-        hipLaunchKernelGGL(x_update_kernel<T>, dim3((n + 31) / 32), dim3(256), 0, h->stream, x, h->PHt, pitchA, n, k, h->gvec,
-                           h->d_status, dcount);
+        if (joseph || kp > 128)
+            hipLaunchKernelGGL(x_update_kernel<T>, dim3((n + 31) / 32), dim3(256), 0, h->stream, x, h->PHt, pitchA, n, k,
+                               h->gvec, h->d_status, dcount);
     }
     HIP_TRY(hipGetLastError());
     return launch_downdate(h, kp_total, W1, joseph ? (const void*)W2 : (const void*)W1, pitchW, dcount, joseph ? 1 : 0);
@@ -604,6 +705,10 @@ int launch_update(slam_ekf* h, int m, const double R[4], int form, bool device_c
 int update_kernels_init() {
     // the factor kernel keeps a 128 x 129 double matrix in LDS: raise the dynamic-LDS cap
     const int big = 160 * 1024;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&w1_mfma_kernel<float>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&w1_mfma_kernel<double>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_kernel<float, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_kernel<double, true>),

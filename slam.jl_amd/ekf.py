@@ -323,8 +323,15 @@ class EKFSlamState(SlamState):
     def sync(self):
         check(lib.slam_ekf_sync(self._h))
 
-    def timing(self, enable=True):
-        check(lib.slam_ekf_timing(self._h, 1 if enable else 0))
+    def timing(self, enable=True, kernels=None):
+        """Bracket kernel launches with HIP events; ``kernels``: names from ``_lib.KERNEL_IDS`` to restrict
+        it to (each event pair costs ~10 us of stream time)."""
+        mask = 1 if enable else 0
+        if enable and kernels:
+            mask = 0
+            for name in kernels:
+                mask |= 2 << _lib.KERNEL_IDS[name]
+        check(lib.slam_ekf_timing(self._h, mask))
 
     def debug_stamps(self, enable=True):
         """Diagnostics: 100 MHz wall-clock stamps of the factorisation kernel's phases (last update)."""
