@@ -189,6 +189,10 @@ int slam_pf_predict(slam_pf_t h, double V, double G, double wheelbase, const dou
  * logw += log N(v; 0, S).  First sighting: initialisation like add_features
  * (src/ekf.jl:94-103,112) without the vehicle-covariance term.  Enqueued. */
 int slam_pf_update_known(slam_pf_t h, const double* z, const int32_t* ids, int m, const double R[4]);
+/* F1 + F2/F3 + the local part of F4 as ONE sweep over the particles: slam_pf_predict, slam_pf_update_known
+ * and slam_pf_weight_stats in one kernel (same particles bit for bit; out as slam_pf_weight_stats).  Synchronises. */
+int slam_pf_step(slam_pf_t h, double V, double G, double wheelbase, const double Q[4], double dt,
+                 const double* z, const int32_t* ids, int m, const double R[4], double out[3]);
 /* F4, local part: out = {max logw, sum exp(logw - max), sum exp(2 (logw - max))}.  Synchronises. */
 int slam_pf_weight_stats(slam_pf_t h, double out[3]);
 /* logw -= gmax + log(gsum) with the GLOBAL max / sum (after the all-reduce). */

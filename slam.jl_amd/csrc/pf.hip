@@ -27,6 +27,11 @@
 
 #define PF_PI 3.14159265358979323846
 
+// No FMA contraction in this file: the particle arithmetic is specified operation by operation (the oracle is
+// NumPy, which rounds every operation), and the fused step kernel must reproduce the separate kernels bit for
+// bit whatever the compiler would otherwise fuse across the predict/update boundary.  The kernels are HBM-bound.
+#pragma clang fp contract(off)
+
 struct slam_pf {
     int dtype, device;
     size_t esz;
@@ -40,10 +45,12 @@ struct slam_pf {
     void* logw;          // [n]
     int cur;             // which of the two state buffers is live
     std::vector<char> seen;
-    int32_t* d_ids;      // [ocap] observation landmark ids (0-based) ; bit 30 marks "new landmark"
-    double* d_obs;       // [ocap][2]
-    int32_t* h_ids;
+    int32_t* d_ids;      // [2][ocap] observation landmark ids (0-based) ; bit 30 marks "new landmark"
+    double* d_obs;       // [2][ocap][2]
+    int32_t* h_ids;      // pinned, [2][ocap]: two staging slots used alternately, each guarded by an event
     double* h_obs;
+    hipEvent_t stage_ev[2];
+    int stage_used[2], stage_slot;
     int ocap;
     double* d_part;      // [blocks][4] reduction partials
     double* d_out;       // [8]
@@ -144,32 +151,104 @@ __global__ __launch_bounds__(256) void pf_init_lm_kernel(T* __restrict__ lm, int
 // ---- F2 / F3 -------------------------------------------------------------------------------------
 constexpr int32_t NEW_FLAG = 1 << 30;
 
+// One landmark record of one particle (5 strided values).
 template <typename T>
-__global__ __launch_bounds__(256) void pf_update_kernel(const T* __restrict__ pose, T* __restrict__ lm, T* __restrict__ logw,
-                                                         int64_t n, const double* __restrict__ z, const int32_t* __restrict__ ids,
-                                                         int m, T R00, T R10, T R01, T R11) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const T x = pose[p], y = pose[n + p], phi = pose[2 * n + p];
+struct LmRow {
+    T lx, ly, pxx, pxy, pyy;
+};
+template <typename T>
+__device__ __forceinline__ LmRow<T> load_row(const T* __restrict__ row, int64_t n) {
+    LmRow<T> r;
+    r.lx = row[0]; r.ly = row[n]; r.pxx = row[2 * n]; r.pxy = row[3 * n]; r.pyy = row[4 * n];
+    return r;
+}
+
+__device__ inline double block_reduce(double v, double* sh, bool is_max);
+
+// Per-block weight statistics with the block's OWN maximum as the shift (one pass; pf_fold_kernel rescales):
+// part[b] = {m_b, sum e, sum e^2, sum e x, sum e y, sum e sin(phi), sum e cos(phi)},  e = exp(logw - shift_b),
+// shift_b = m_b if `relative` else 0.
+template <typename T>
+__device__ __forceinline__ void block_weight_stats(T lw, T x, T y, T phi, bool valid, int relative, double* __restrict__ part) {
+    __shared__ double sh[4];
+    const double m = block_reduce(valid ? (double)lw : -__builtin_inf(), sh, true);
+    const double shift = relative ? m : 0.0;
+    const double e = valid ? exp((double)lw - shift) : 0.0;
+    const double ph = (double)phi;
+    const double s1 = block_reduce(e, sh, false), s2 = block_reduce(e * e, sh, false);
+    const double sx = block_reduce(e * (double)x, sh, false), sy = block_reduce(e * (double)y, sh, false);
+    const double ss = block_reduce(e * sin(ph), sh, false), sc = block_reduce(e * cos(ph), sh, false);
+    if (threadIdx.x == 0) {
+        double* o = part + (size_t)blockIdx.x * 8;
+        o[0] = m; o[1] = s1; o[2] = s2; o[3] = sx; o[4] = sy; o[5] = ss; o[6] = sc;
+    }
+}
+
+// F1 + F2/F3 (+ F4 partials): one pass over the particle -- predict (PREDICT), the m known-id updates, and
+// (STATS) the block's weight statistics, so that a filter step is ONE sweep of HBM instead of five launches.
+// The record of observation i+1 is requested before observation i is processed (two records in flight per
+// particle); a repeat of the same landmark in consecutive observations is re-read after the store instead.
+template <typename T, bool PREDICT, bool STATS>
+__global__ __launch_bounds__(256) void pf_step_kernel(T* __restrict__ pose, T* __restrict__ lm, T* __restrict__ logw,
+                                                       int64_t n, int64_t first, uint32_t step, uint64_t seed, T V, T G,
+                                                       T wheelbase, T sigV, T sigG, T dt, const double* __restrict__ z,
+                                                       const int32_t* __restrict__ ids, int m, T R00, T R10, T R01, T R11,
+                                                       double* __restrict__ part) {
+    const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = pi < n;
+    if (!STATS && !valid) return;
+    const int64_t p = valid ? pi : n - 1;          // (STATS: idle lanes shadow the last particle, stores are masked)
+    T x = pose[p], y = pose[n + p], phi = pose[2 * n + p];
+    if (PREDICT) {
+        T e1, e2;
+        normals2<T>((uint64_t)(first + p), step, STREAM_PREDICT, seed, e1, e2);
+        const T Vn = V + sigV * e1;                       // sim/sim-utils.jl:36
+        const T Gn = G + sigG * e2;                       // :37
+        const T xn = x + Vn * dt * cos(Gn + phi);         // src/ekf.jl:39-41
+        const T yn = y + Vn * dt * sin(Gn + phi);
+        const T pn = wrap_pi<T>(phi + Vn * dt * sin(Gn) / wheelbase);
+        x = xn; y = yn; phi = pn;
+        if (valid) { pose[p] = x; pose[n + p] = y; pose[2 * n + p] = phi; }
+    }
     T lw = logw[p];
+    LmRow<T> pre = {0, 0, 0, 0, 0};
+    bool have = false;
+    if (m > 0 && !(ids[0] & NEW_FLAG)) {
+        pre = load_row<T>(lm + (size_t)(ids[0] & (NEW_FLAG - 1)) * 5 * n + p, n);
+        have = true;
+    }
     for (int i = 0; i < m; ++i) {
         const int32_t code = ids[i];
         const int l = code & (NEW_FLAG - 1);
         const T r = (T)z[2 * i], b = (T)z[2 * i + 1];
         T* row = lm + (size_t)l * 5 * n + p;
+        LmRow<T> cur = pre;
+        const bool have_cur = have;
+        have = false;
+        if (i + 1 < m) {
+            const int32_t nc = ids[i + 1];
+            const int nl = nc & (NEW_FLAG - 1);
+            if (!(nc & NEW_FLAG) && nl != l) {            // uniform
+                pre = load_row<T>(lm + (size_t)nl * 5 * n + p, n);
+                have = true;
+            }
+        }
         if (code & NEW_FLAG) {                         // F3: src/ekf.jl:94-103,112 without the pose term
             const T s = sin(phi + b), c = cos(phi + b);
             const T g00 = c, g01 = -r * s, g10 = s, g11 = r * c;
             const T a00 = g00 * R00 + g01 * R10, a01 = g00 * R01 + g01 * R11;
             const T a10 = g10 * R00 + g11 * R10, a11 = g10 * R01 + g11 * R11;
-            row[0] = x + r * c;
-            row[n] = y + r * s;
-            row[2 * n] = a00 * g00 + a01 * g01;
-            row[3 * n] = a00 * g10 + a01 * g11;
-            row[4 * n] = a10 * g10 + a11 * g11;
+            if (valid) {
+                row[0] = x + r * c;
+                row[n] = y + r * s;
+                row[2 * n] = a00 * g00 + a01 * g01;
+                row[3 * n] = a00 * g10 + a01 * g11;
+                row[4 * n] = a10 * g10 + a11 * g11;
+            }
             continue;
         }
-        const T lx = row[0], ly = row[n], pxx = row[2 * n], pxy = row[3 * n], pyy = row[4 * n];
+        if (!have_cur) cur = load_row<T>(row, n);
+        const T lx = cur.lx, ly = cur.ly, pxx = cur.pxx, pxy = cur.pxy, pyy = cur.pyy;
         const T dx = lx - x, dy = ly - y;
         const T d2 = dx * dx + dy * dy;
         const T d = sqrt(d2);
@@ -189,14 +268,17 @@ __global__ __launch_bounds__(256) void pf_update_kernel(const T* __restrict__ po
         const T w00 = t00 * c00, w01 = t00 * c01 + t01 * c11;             // W1 = PHt C (:71)
         const T w10 = t10 * c00, w11 = t10 * c01 + t11 * c11;
         const T y0 = c00 * v0, y1 = c01 * v0 + c11 * v1;                  // C' v
-        row[0] = lx + w00 * y0 + w01 * y1;                                // x += W v (:72,:74)
-        row[n] = ly + w10 * y0 + w11 * y1;
-        row[2 * n] = pxx - (w00 * w00 + w01 * w01);                       // P -= W1 W1' (:75)
-        row[3 * n] = pxy - (w00 * w10 + w01 * w11);
-        row[4 * n] = pyy - (w10 * w10 + w11 * w11);
+        if (valid) {
+            row[0] = lx + w00 * y0 + w01 * y1;                            // x += W v (:72,:74)
+            row[n] = ly + w10 * y0 + w11 * y1;
+            row[2 * n] = pxx - (w00 * w00 + w01 * w01);                   // P -= W1 W1' (:75)
+            row[3 * n] = pxy - (w00 * w10 + w01 * w11);
+            row[4 * n] = pyy - (w10 * w10 + w11 * w11);
+        }
         lw += (T)-0.5 * (y0 * y0 + y1 * y1) - log(u00 * u11) - (T)1.8378770664093453;   // log(2 pi)
     }
-    logw[p] = lw;
+    if (valid) logw[p] = lw;
+    if (STATS) block_weight_stats<T>(lw, x, y, phi, valid, 1, part);
 }
 
 // ---- F4: reductions ------------------------------------------------------------------------------
@@ -216,50 +298,36 @@ __device__ inline double block_reduce(double v, double* sh, bool is_max) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void pf_max_kernel(const T* __restrict__ logw, int64_t n, double* __restrict__ part) {
+__global__ __launch_bounds__(256) void pf_stats_kernel(const T* __restrict__ logw, const T* __restrict__ pose, int64_t n,
+                                                        int relative, double* __restrict__ part) {
+    const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = pi < n;
+    const int64_t p = valid ? pi : n - 1;
+    block_weight_stats<T>(logw[p], pose[p], pose[n + p], pose[2 * n + p], valid, relative, part);
+}
+
+// out = {M, sum, sum2, sx, sy, ss, sc} over all blocks: M = max_b m_b, block sums rescaled by exp(m_b - M)
+// (its square for the second moment).  One workgroup.
+__global__ __launch_bounds__(256) void pf_fold_kernel(const double* __restrict__ part, int nblocks, int relative,
+                                                      double* __restrict__ out) {
     __shared__ double sh[4];
     double m = -__builtin_inf();
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x)
-        m = fmax(m, (double)logw[p]);
-    m = block_reduce(m, sh, true);
-    if (threadIdx.x == 0) part[blockIdx.x] = m;
-}
-
-// pass 2: with the local max known: sums of exp(logw - max), exp(2(logw - max)) and the weighted pose sums
-template <typename T>
-__global__ __launch_bounds__(256) void pf_sums_kernel(const T* __restrict__ logw, const T* __restrict__ pose, int64_t n,
-                                                       const double* __restrict__ maxpart, int nmax, double shift_is_max,
-                                                       double* __restrict__ part) {
-    __shared__ double sh[4];
-    double mx = -__builtin_inf();
-    for (int i = 0; i < nmax; ++i) mx = fmax(mx, maxpart[i]);
-    const double shift = shift_is_max != 0.0 ? mx : 0.0;
-    double s1 = 0, s2 = 0, sx = 0, sy = 0, ss = 0, sc = 0;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
-        const double e = exp((double)logw[p] - shift);
-        s1 += e;
-        s2 += e * e;
-        const double ph = (double)pose[2 * n + p];
-        sx += e * (double)pose[p];
-        sy += e * (double)pose[n + p];
-        ss += e * sin(ph);
-        sc += e * cos(ph);
+    for (int b = threadIdx.x; b < nblocks; b += 256) m = fmax(m, part[(size_t)b * 8]);
+    const double M = block_reduce(m, sh, true);
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
+        const double* q = part + (size_t)b * 8;
+        const double f = relative ? exp(q[0] - M) : 1.0;
+        acc[0] += q[1] * f;
+        acc[1] += q[2] * f * f;
+        acc[2] += q[3] * f; acc[3] += q[4] * f; acc[4] += q[5] * f; acc[5] += q[6] * f;
     }
-    s1 = block_reduce(s1, sh, false); s2 = block_reduce(s2, sh, false);
-    sx = block_reduce(sx, sh, false); sy = block_reduce(sy, sh, false);
-    ss = block_reduce(ss, sh, false); sc = block_reduce(sc, sh, false);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[i] = block_reduce(acc[i], sh, false);
     if (threadIdx.x == 0) {
-        double* o = part + (size_t)blockIdx.x * 8;
-        o[0] = mx; o[1] = s1; o[2] = s2; o[3] = sx; o[4] = sy; o[5] = ss; o[6] = sc;
+        out[0] = M;
+        for (int i = 0; i < 6; ++i) out[1 + i] = acc[i];
     }
-}
-
-__global__ void pf_fold_kernel(const double* __restrict__ part, int nblocks, double* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double acc[7] = {part[0], 0, 0, 0, 0, 0, 0};
-    for (int b = 0; b < nblocks; ++b)
-        for (int q = 1; q < 7; ++q) acc[q] += part[(size_t)b * 8 + q];
-    for (int q = 0; q < 7; ++q) out[q] = acc[q];
 }
 
 template <typename T>
@@ -295,16 +363,32 @@ __global__ __launch_bounds__(SCAN_BLOCK) void pf_scan1_kernel(const T* __restric
     if (threadIdx.x == SCAN_BLOCK - 1) bsum[blockIdx.x] = sh[threadIdx.x];
 }
 
-// exclusive scan of the block totals, in place, one thread (<= a few hundred blocks)
-__global__ void pf_scan2_kernel(double* __restrict__ bsum, int nb) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double run = 0;
-    for (int b = 0; b < nb; ++b) {
-        const double v = bsum[b];
-        bsum[b] = run;
-        run += v;
+// exclusive scan of the block totals, in place.  The additions run in index order on ONE thread (the oracle's
+// order: the ancestor table must be exact), but out of LDS: loads and stores are done by the whole workgroup, so
+// the serial part is ~10 cycles per block total instead of one L2 round trip.
+constexpr int SCAN2_CHUNK = 4096;
+__global__ __launch_bounds__(256) void pf_scan2_kernel(double* __restrict__ bsum, int nb) {
+    __shared__ double sh[SCAN2_CHUNK];
+    __shared__ double carry;
+    if (threadIdx.x == 0) carry = 0.0;
+    for (int base = 0; base < nb; base += SCAN2_CHUNK) {
+        const int cnt = nb - base < SCAN2_CHUNK ? nb - base : SCAN2_CHUNK;
+        for (int i = threadIdx.x; i < cnt; i += 256) sh[i] = bsum[base + i];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double run = carry;
+            for (int i = 0; i < cnt; ++i) {
+                const double v = sh[i];
+                sh[i] = run;
+                run += v;
+            }
+            carry = run;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += 256) bsum[base + i] = sh[i];
+        __syncthreads();
     }
-    bsum[nb] = run;                      // grand total
+    if (threadIdx.x == 0) bsum[nb] = carry;                      // grand total
 }
 
 // ancestor of global slot g = first j with cdf[j] >= (g + u0)/N * total   (binary search)
@@ -340,19 +424,45 @@ __global__ __launch_bounds__(256) void pf_src_kernel(const int32_t* __restrict__
     src[p] = -(lo + 1);
 }
 
-// new[row][p] = old[row][src] or remote[row][pos];  grid.y = row (3 pose rows, then landmark rows)
+// new[row][p] = old[row][src] or remote[row][pos].  A thread owns one particle and GATHER_ROWS consecutive rows
+// (grid.y = row chunks): the source index is read once and the row loop keeps eight independent loads in flight.
+constexpr int GATHER_ROWS = 64;
 template <typename T>
 __global__ __launch_bounds__(256) void pf_gather_kernel(const T* __restrict__ pose_old, const T* __restrict__ lm_old,
                                                          T* __restrict__ pose_new, T* __restrict__ lm_new, int64_t n,
-                                                         const int32_t* __restrict__ src, const T* __restrict__ remote,
-                                                         int nremote) {
+                                                         int nrows, const int32_t* __restrict__ src,
+                                                         const T* __restrict__ remote, int nremote) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    const int row = blockIdx.y;
     const int32_t s = src[p];
-    const T* old_row = row < 3 ? pose_old + (size_t)row * n : lm_old + (size_t)(row - 3) * n;
-    T* new_row = row < 3 ? pose_new + (size_t)row * n : lm_new + (size_t)(row - 3) * n;
-    new_row[p] = s >= 0 ? old_row[s] : remote[(size_t)row * nremote + (-s - 1)];
+    const int row0 = blockIdx.y * GATHER_ROWS;
+    const int row1 = row0 + GATHER_ROWS < nrows ? row0 + GATHER_ROWS : nrows;
+    if (s >= 0) {
+        int row = row0;
+        for (; row < 3 && row < row1; ++row) pose_new[(size_t)row * n + p] = pose_old[(size_t)row * n + s];
+        const T* o = lm_old + (size_t)(row - 3) * n + s;
+        T* d = lm_new + (size_t)(row - 3) * n + p;
+        for (; row + 8 <= row1; row += 8) {
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = o[(size_t)u * n];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) d[(size_t)u * n] = v[u];
+            o += (size_t)8 * n;
+            d += (size_t)8 * n;
+        }
+        for (; row < row1; ++row) {
+            *d = *o;
+            o += n;
+            d += n;
+        }
+    } else {
+        const T* rr = remote + (size_t)(-s - 1);
+        for (int row = row0; row < row1; ++row) {
+            T* new_row = row < 3 ? pose_new + (size_t)row * n : lm_new + (size_t)(row - 3) * n;
+            new_row[p] = rr[(size_t)row * nremote];
+        }
+    }
 }
 
 // records[row][c] = state[row][idx[c]]
@@ -404,6 +514,8 @@ extern "C" int slam_pf_destroy(slam_pf_t h) {
     if (h->h_ids) (void)hipHostFree(h->h_ids);
     if (h->h_obs) (void)hipHostFree(h->h_obs);
     if (h->h_out) (void)hipHostFree(h->h_out);
+    for (int b = 0; b < 2; ++b)
+        if (h->stage_ev[b]) (void)hipEventDestroy(h->stage_ev[b]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return SLAM_OK;
@@ -420,17 +532,18 @@ static int pf_create_impl(slam_pf* h) {
     }
     if ((rc = pf_alloc(&h->logw, h->esz * n, h->stream))) return rc;
     h->ocap = 1024;
-    if ((rc = pf_alloc(&h->d_ids, sizeof(int32_t) * h->ocap, h->stream))) return rc;
-    if ((rc = pf_alloc(&h->d_obs, sizeof(double) * 2 * h->ocap, h->stream))) return rc;
-    h->red_blocks = 256;
-    if ((rc = pf_alloc(&h->d_part, sizeof(double) * 9 * h->red_blocks, h->stream))) return rc;
+    if ((rc = pf_alloc(&h->d_ids, sizeof(int32_t) * 2 * h->ocap, h->stream))) return rc;
+    if ((rc = pf_alloc(&h->d_obs, sizeof(double) * 4 * h->ocap, h->stream))) return rc;
+    h->red_blocks = grid_for(h->n);                  // one partial record per 256 particles
+    if ((rc = pf_alloc(&h->d_part, sizeof(double) * 8 * h->red_blocks, h->stream))) return rc;
     if ((rc = pf_alloc(&h->d_out, sizeof(double) * 8, h->stream))) return rc;
     if ((rc = pf_alloc(&h->d_cdf, sizeof(double) * (size_t)h->n_global, h->stream))) return rc;
     const size_t nb = ((size_t)h->n_global + SCAN_BLOCK - 1) / SCAN_BLOCK;
     if ((rc = pf_alloc(&h->d_bsum, sizeof(double) * (nb + 1), h->stream))) return rc;
     if ((rc = pf_alloc(&h->d_src, sizeof(int32_t) * n, h->stream))) return rc;
-    HIP_TRY(hipHostMalloc((void**)&h->h_ids, sizeof(int32_t) * h->ocap, hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void**)&h->h_obs, sizeof(double) * 2 * h->ocap, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&h->h_ids, sizeof(int32_t) * 2 * h->ocap, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&h->h_obs, sizeof(double) * 4 * h->ocap, hipHostMallocDefault));
+    for (int b = 0; b < 2; ++b) HIP_TRY(hipEventCreateWithFlags(&h->stage_ev[b], hipEventDisableTiming));
     HIP_TRY(hipHostMalloc((void**)&h->h_out, sizeof(double) * 8, hipHostMallocDefault));
     // uniform weights over the GLOBAL particle set
     const double lw = -log((double)h->n_global);
@@ -465,6 +578,7 @@ extern "C" int slam_pf_create(slam_pf_t* out, int dtype, int64_t n_local, int64_
     h->seed = seed; h->step = 0; h->cur = 0; h->stream = nullptr;
     h->pose[0] = h->pose[1] = h->lm[0] = h->lm[1] = h->logw = nullptr;
     h->d_ids = nullptr; h->d_obs = nullptr; h->h_ids = nullptr; h->h_obs = nullptr; h->ocap = 0;
+    h->stage_ev[0] = h->stage_ev[1] = nullptr; h->stage_used[0] = h->stage_used[1] = 0; h->stage_slot = 0;
     h->d_part = h->d_out = h->h_out = h->d_cdf = h->d_bsum = nullptr; h->d_src = nullptr;
     h->seen.assign(max_landmarks, 0);
     const int rc = pf_create_impl(h);
@@ -520,32 +634,101 @@ extern "C" int slam_pf_predict(slam_pf_t h, double V, double G, double wheelbase
     return SLAM_OK;
 }
 
-extern "C" int slam_pf_update_known(slam_pf_t h, const double* z, const int32_t* ids, int m, const double R[4]) {
-    ARG_CHECK(h != nullptr, "null handle");
+// Stage m observations (ids recoded 0-based with the first-sighting flag) into the next staging slot and queue
+// the copies; returns the slot's device addresses.  No stream synchronisation: a slot is reused only after the
+// event behind its previous copies has fired.
+static int pf_stage(slam_pf* h, const double* z, const int32_t* ids, int m, const double** d_z, const int32_t** d_i) {
+    const int slot = h->stage_slot;
+    h->stage_slot ^= 1;
+    if (h->stage_used[slot]) HIP_TRY(hipEventSynchronize(h->stage_ev[slot]));
+    int32_t* hi = h->h_ids + (size_t)slot * h->ocap;
+    double* hz = h->h_obs + (size_t)slot * 2 * h->ocap;
+    for (int i = 0; i < m; ++i) {
+        const int l = ids[i] - 1;
+        hi[i] = l | (h->seen[l] ? 0 : NEW_FLAG);
+        h->seen[l] = 1;
+        hz[2 * i] = z[2 * i];
+        hz[2 * i + 1] = z[2 * i + 1];
+    }
+    int32_t* di = h->d_ids + (size_t)slot * h->ocap;
+    double* dz = h->d_obs + (size_t)slot * 2 * h->ocap;
+    HIP_TRY(hipMemcpyAsync(di, hi, sizeof(int32_t) * m, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(dz, hz, sizeof(double) * 2 * m, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipEventRecord(h->stage_ev[slot], h->stream));
+    h->stage_used[slot] = 1;
+    *d_z = dz;
+    *d_i = di;
+    return SLAM_OK;
+}
+
+static int pf_check_obs(slam_pf* h, const double* z, const int32_t* ids, int m, const double* R) {
     ARG_CHECK(m >= 0, "m < 0");
     if (m == 0) return SLAM_OK;
     ARG_CHECK(z != nullptr && ids != nullptr && R != nullptr, "null argument");
     ARG_CHECK(m <= h->ocap, "too many observations in one call (max 1024)");
     for (int i = 0; i < m; ++i) ARG_CHECK(ids[i] >= 1 && ids[i] <= h->nl, "landmark id out of range");
+    return SLAM_OK;
+}
+
+extern "C" int slam_pf_update_known(slam_pf_t h, const double* z, const int32_t* ids, int m, const double R[4]) {
+    ARG_CHECK(h != nullptr, "null handle");
+    int rc = pf_check_obs(h, z, ids, m, R);
+    if (rc || m == 0) return rc;
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->stream));          // pinned staging may still be in flight
-    for (int i = 0; i < m; ++i) {
-        const int l = ids[i] - 1;
-        h->h_ids[i] = l | (h->seen[l] ? 0 : NEW_FLAG);
-        h->seen[l] = 1;
-        h->h_obs[2 * i] = z[2 * i];
-        h->h_obs[2 * i + 1] = z[2 * i + 1];
-    }
-    HIP_TRY(hipMemcpyAsync(h->d_ids, h->h_ids, sizeof(int32_t) * m, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->d_obs, h->h_obs, sizeof(double) * 2 * m, hipMemcpyHostToDevice, h->stream));
+    const double* dz;
+    const int32_t* di;
+    if ((rc = pf_stage(h, z, ids, m, &dz, &di))) return rc;
     PF_DISPATCH(h,
-                hipLaunchKernelGGL(pf_update_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream,
-                                   (const T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->d_obs, h->d_ids, m,
-                                   (T)R[0], (T)R[1], (T)R[2], (T)R[3]),
-                hipLaunchKernelGGL(pf_update_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream,
-                                   (const T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->d_obs, h->d_ids, m,
-                                   (T)R[0], (T)R[1], (T)R[2], (T)R[3]));
+                hipLaunchKernelGGL((pf_step_kernel<T, false, false>), dim3(grid_for(h->n)), dim3(256), 0, h->stream,
+                                   (T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->first, 0u, h->seed, (T)0, (T)0,
+                                   (T)1, (T)0, (T)0, (T)0, dz, di, m, (T)R[0], (T)R[1], (T)R[2], (T)R[3], (double*)nullptr),
+                hipLaunchKernelGGL((pf_step_kernel<T, false, false>), dim3(grid_for(h->n)), dim3(256), 0, h->stream,
+                                   (T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->first, 0u, h->seed, (T)0, (T)0,
+                                   (T)1, (T)0, (T)0, (T)0, dz, di, m, (T)R[0], (T)R[1], (T)R[2], (T)R[3], (double*)nullptr));
     HIP_TRY(hipGetLastError());
+    return SLAM_OK;
+}
+
+// fold the per-block partials in d_part and bring the seven numbers to the host
+static int pf_fold_and_read(slam_pf* h, int relative_to_max, double out[7]) {
+    hipLaunchKernelGGL(pf_fold_kernel, dim3(1), dim3(256), 0, h->stream, (const double*)h->d_part, h->red_blocks,
+                       relative_to_max, h->d_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h->h_out, h->d_out, sizeof(double) * 7, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 7; ++i) out[i] = h->h_out[i];
+    return SLAM_OK;
+}
+
+/* F1 + F2/F3 + the local part of F4 as ONE sweep over the particles: predict, the m known-id updates and the weight
+ * statistics {max logw, sum exp(logw - max), sum exp(2 (logw - max))}.  Same particles as slam_pf_predict +
+ * slam_pf_update_known (bit for bit), same statistics as slam_pf_weight_stats.  Synchronises (the caller needs Neff). */
+extern "C" int slam_pf_step(slam_pf_t h, double V, double G, double wheelbase, const double Q[4], double dt, const double* z,
+                            const int32_t* ids, int m, const double R[4], double out[3]) {
+    ARG_CHECK(h != nullptr && Q != nullptr && out != nullptr, "null argument");
+    double Rz[4] = {0, 0, 0, 0};
+    int rc = pf_check_obs(h, z, ids, m, m ? R : Rz);
+    if (rc) return rc;
+    if (m) for (int i = 0; i < 4; ++i) Rz[i] = R[i];
+    HIP_TRY(hipSetDevice(h->device));
+    const double* dz = h->d_obs;
+    const int32_t* di = h->d_ids;
+    if (m && (rc = pf_stage(h, z, ids, m, &dz, &di))) return rc;
+    const double sV = sqrt(Q[0]), sG = sqrt(Q[3]);
+    PF_DISPATCH(h,
+                hipLaunchKernelGGL((pf_step_kernel<T, true, true>), dim3(grid_for(h->n)), dim3(256), 0, h->stream,
+                                   (T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
+                                   (T)G, (T)wheelbase, (T)sV, (T)sG, (T)dt, dz, di, m, (T)Rz[0], (T)Rz[1], (T)Rz[2], (T)Rz[3],
+                                   h->d_part),
+                hipLaunchKernelGGL((pf_step_kernel<T, true, true>), dim3(grid_for(h->n)), dim3(256), 0, h->stream,
+                                   (T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
+                                   (T)G, (T)wheelbase, (T)sV, (T)sG, (T)dt, dz, di, m, (T)Rz[0], (T)Rz[1], (T)Rz[2], (T)Rz[3],
+                                   h->d_part));
+    HIP_TRY(hipGetLastError());
+    h->step += 1;
+    double s[7];
+    if ((rc = pf_fold_and_read(h, 1, s))) return rc;
+    out[0] = s[0]; out[1] = s[1]; out[2] = s[2];
     return SLAM_OK;
 }
 
@@ -553,23 +736,13 @@ extern "C" int slam_pf_update_known(slam_pf_t h, const double* z, const int32_t*
 // with w = exp(logw - shift), shift = local max if relative_to_max else 0.
 static int pf_stats(slam_pf* h, int relative_to_max, double out[7]) {
     HIP_TRY(hipSetDevice(h->device));
-    const int nb = h->red_blocks;
-    double* maxpart = h->d_part;                 // [nb]
-    double* sums = h->d_part + nb;               // [nb][8]
     PF_DISPATCH(h,
-                hipLaunchKernelGGL(pf_max_kernel<T>, dim3(nb), dim3(256), 0, h->stream, (const T*)h->logw, h->n, maxpart),
-                hipLaunchKernelGGL(pf_max_kernel<T>, dim3(nb), dim3(256), 0, h->stream, (const T*)h->logw, h->n, maxpart));
-    PF_DISPATCH(h,
-                hipLaunchKernelGGL(pf_sums_kernel<T>, dim3(nb), dim3(256), 0, h->stream, (const T*)h->logw,
-                                   (const T*)h->pose[h->cur], h->n, maxpart, nb, relative_to_max ? 1.0 : 0.0, sums),
-                hipLaunchKernelGGL(pf_sums_kernel<T>, dim3(nb), dim3(256), 0, h->stream, (const T*)h->logw,
-                                   (const T*)h->pose[h->cur], h->n, maxpart, nb, relative_to_max ? 1.0 : 0.0, sums));
-    hipLaunchKernelGGL(pf_fold_kernel, dim3(1), dim3(64), 0, h->stream, sums, nb, h->d_out);
+                hipLaunchKernelGGL(pf_stats_kernel<T>, dim3(h->red_blocks), dim3(256), 0, h->stream, (const T*)h->logw,
+                                   (const T*)h->pose[h->cur], h->n, relative_to_max, h->d_part),
+                hipLaunchKernelGGL(pf_stats_kernel<T>, dim3(h->red_blocks), dim3(256), 0, h->stream, (const T*)h->logw,
+                                   (const T*)h->pose[h->cur], h->n, relative_to_max, h->d_part));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h->h_out, h->d_out, sizeof(double) * 7, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    for (int i = 0; i < 7; ++i) out[i] = h->h_out[i];
-    return SLAM_OK;
+    return pf_fold_and_read(h, relative_to_max, out);
 }
 
 extern "C" int slam_pf_weight_stats(slam_pf_t h, double out[3]) {
@@ -620,7 +793,7 @@ extern "C" int slam_pf_ancestors(slam_pf_t h, const void* d_logw_all, double gma
                                    h->n_global, gmax, h->d_cdf, h->d_bsum),
                 hipLaunchKernelGGL(pf_scan1_kernel<T>, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, (const T*)d_logw_all,
                                    h->n_global, gmax, h->d_cdf, h->d_bsum));
-    hipLaunchKernelGGL(pf_scan2_kernel, dim3(1), dim3(64), 0, h->stream, h->d_bsum, nb);
+    hipLaunchKernelGGL(pf_scan2_kernel, dim3(1), dim3(256), 0, h->stream, h->d_bsum, nb);
     hipLaunchKernelGGL(pf_ancestor_kernel, dim3(grid_for(h->n)), dim3(256), 0, h->stream, h->d_cdf, h->d_bsum, nb, h->n_global,
                        h->first, h->n, u0, d_anc);
     HIP_TRY(hipGetLastError());
@@ -660,13 +833,14 @@ extern "C" int slam_pf_resample_apply(slam_pf_t h, const int32_t* d_anc, const i
     hipLaunchKernelGGL(pf_src_kernel, dim3(grid_for(h->n)), dim3(256), 0, h->stream, d_anc, h->n, h->first, d_remote_ids,
                        nremote, h->d_src);
     const int nxt = h->cur ^ 1;
-    const dim3 grid(grid_for(h->n), 3 + 5 * h->nl);
+    const int nrows = 3 + 5 * h->nl;
+    const dim3 grid(grid_for(h->n), (nrows + GATHER_ROWS - 1) / GATHER_ROWS);
     PF_DISPATCH(h,
                 hipLaunchKernelGGL(pf_gather_kernel<T>, grid, dim3(256), 0, h->stream, (const T*)h->pose[h->cur],
-                                   (const T*)h->lm[h->cur], (T*)h->pose[nxt], (T*)h->lm[nxt], h->n, h->d_src,
+                                   (const T*)h->lm[h->cur], (T*)h->pose[nxt], (T*)h->lm[nxt], h->n, nrows, h->d_src,
                                    (const T*)d_remote_records, nremote),
                 hipLaunchKernelGGL(pf_gather_kernel<T>, grid, dim3(256), 0, h->stream, (const T*)h->pose[h->cur],
-                                   (const T*)h->lm[h->cur], (T*)h->pose[nxt], (T*)h->lm[nxt], h->n, h->d_src,
+                                   (const T*)h->lm[h->cur], (T*)h->pose[nxt], (T*)h->lm[nxt], h->n, nrows, h->d_src,
                                    (const T*)d_remote_records, nremote));
     const double lw = -log((double)h->n_global);      // uniform weights again
     PF_DISPATCH(h,

@@ -106,6 +106,19 @@ class PFShard:
         check(lib.slam_pf_weight_stats(self._h, _ptr(out)))
         return float(out[0]), float(out[1]), float(out[2])
 
+    def step_fused(self, V, G, wheelbase, Q, dt, z, ids, R):
+        """predict + update_known + weight_stats as ONE sweep over the particles (slam_pf_step): the same
+        particles bit for bit, the same three statistics."""
+        zp = _obs(z)
+        idv = np.ascontiguousarray(np.asarray(ids, dtype=np.int32).reshape(-1))
+        if idv.shape[0] != zp.shape[0]:
+            raise ValueError("ids and z disagree on the number of observations")
+        q, r = _small(Q), _small(R)
+        out = np.empty(3)
+        check(lib.slam_pf_step(self._h, float(V), float(G), float(wheelbase), _ptr(q), float(dt), _ptr(zp),
+                               _ptr(idv, C.c_int32), zp.shape[0], _ptr(r), _ptr(out)))
+        return float(out[0]), float(out[1]), float(out[2])
+
     def normalize(self, gmax, gsum):
         check(lib.slam_pf_normalize(self._h, float(gmax), float(gsum)))
 
@@ -228,6 +241,7 @@ class FastSLAM:
         self.shard = shard
         self.comm = comm if comm is not None else _SingleProcess()
         self.neff_frac = float(neff_frac)
+        self.fused = True                           # use shard.step_fused when the shard offers it
         self.resamples = 0
         self.last_neff = float(shard.n_global)
         assert shard.n * self.comm.world == shard.n_global and shard.first == self.comm.rank * shard.n, (
@@ -239,17 +253,18 @@ class FastSLAM:
     def update_known(self, z, ids, R):
         self.shard.update_known(z, ids, R)
 
-    def global_stats(self):
-        """(gmax, sum w, sum w^2) with w = exp(logw - gmax): one MAX and one SUM all-reduce of scalars."""
-        lmax, s1, s2 = self.shard.weight_stats()
+    def global_stats(self, local=None):
+        """(gmax, sum w, sum w^2) with w = exp(logw - gmax): one MAX and one SUM all-reduce of scalars.
+        ``local``: this shard's (max, sum, sum2) if a fused step has already produced them."""
+        lmax, s1, s2 = self.shard.weight_stats() if local is None else local
         gmax = self.comm.allreduce_max(lmax)
         f = math.exp(lmax - gmax)
         gs1, gs2 = self.comm.allreduce_sum([s1 * f, s2 * f * f])
         return gmax, gs1, gs2
 
-    def normalize(self):
+    def normalize(self, local=None):
         """Normalise the weights, return Neff = 1 / sum(w_normalised^2)."""
-        gmax, gs1, gs2 = self.global_stats()
+        gmax, gs1, gs2 = self.global_stats(local)
         self.shard.normalize(gmax, gs1)
         self.last_neff = gs1 * gs1 / gs2
         return self.last_neff
@@ -262,6 +277,10 @@ class FastSLAM:
         logw_all = comm.all_gather(sh.logw_tensor(), sh.n_global)      # the all-gather of log-weights
         gmax = float(logw_all.max().item())
         anc = sh.ancestors(logw_all, gmax, u0)                          # global ancestor id per local slot, ascending
+        if comm.world == 1:                                             # every ancestor is local: nothing to exchange
+            sh.resample_apply(anc, None, None)
+            self.resamples += 1
+            return 0
         anc64 = anc.to(torch.int64)
         owner = torch.div(anc64, sh.n, rounding_mode="floor")
         remote = owner != comm.rank
@@ -282,9 +301,13 @@ class FastSLAM:
 
     def step(self, V, G, wheelbase, Q, dt, z, ids, R, force_resample=None):
         """predict + known-id updates + normalise + (Neff-triggered) resample.  Returns (Neff, resampled?)."""
-        self.predict(V, G, wheelbase, Q, dt)
-        self.update_known(z, ids, R)
-        neff = self.normalize()
+        fused = getattr(self.shard, "step_fused", None) if self.fused else None
+        if fused is not None:                       # one sweep over the particles instead of five launches
+            neff = self.normalize(fused(V, G, wheelbase, Q, dt, z, ids, R))
+        else:
+            self.predict(V, G, wheelbase, Q, dt)
+            self.update_known(z, ids, R)
+            neff = self.normalize()
         do = force_resample if force_resample is not None else (neff < self.neff_frac * self.shard.n_global)
         if do:
             self.resample()

@@ -76,6 +76,44 @@ def test_predict_update_weights_against_oracle(pkg, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_fused_step_equals_the_separate_calls(pkg, dtype):
+    """slam_pf_step = predict + update_known + weight_stats in one sweep: the particles must be BIT-identical
+    to the three calls (same Philox words, same arithmetic), the statistics equal up to summation order.
+    n is not a multiple of the block size and the id list has adjacent repeats, first sightings and a
+    repeat two apart (the record prefetch must not read a stale row)."""
+    n, nl, seed = 3000 + 37, 12, 5
+    lm = scene(nl, 3)
+    a = pkg.PFShard(n, nl, seed, dtype=dtype)
+    b = pkg.PFShard(n, nl, seed, dtype=dtype)
+    for f in (a, b):
+        f.set_pose([0.5, 1.5, -0.2])
+        f.init_landmarks(lm[:8], 0.01, 0.1)
+    rng = np.random.default_rng(4)
+    pose = np.array([0.5, 1.5, -0.2])
+    for t in range(5):
+        pose = np.array([pose[0] + 0.6 * math.cos(pose[2]), pose[1] + 0.6 * math.sin(pose[2]), pose[2]])
+        ids = np.array([1 + t % 8, 1 + t % 8, 2 + t % 6, 1 + t % 8, 9 + t % 4, 3, 9 + t % 4])
+        z = observe(lm, pose, ids, rng)
+        sa = a.step_fused(6.0, 0.01 * t, 4.0, Q, 0.1, z, ids, R)
+        b.predict(6.0, 0.01 * t, 4.0, Q, 0.1)
+        b.update_known(z, ids, R)
+        sb = b.weight_stats()
+        pa, wa, la = a.download()
+        pb, wb, lb = b.download()
+        assert np.array_equal(pa, pb) and np.array_equal(wa, wb) and np.array_equal(la, lb), f"step {t}"
+        assert sa[0] == sb[0] and abs(sa[1] - sb[1]) <= 1e-12 * sb[1] and abs(sa[2] - sb[2]) <= 1e-12 * sb[2]
+        # and against a plain NumPy evaluation of the same statistics
+        w = np.exp(wa.astype(np.float64) - float(wa.max()))
+        assert sa[0] == float(wa.max()) and close(sa[1], w.sum(), 1e-12) and close(sa[2], (w * w).sum(), 1e-12)
+        if t == 2:                                    # an empty observation list is a pure predict + statistics
+            sa = a.step_fused(6.0, 0.0, 4.0, Q, 0.1, np.zeros((2, 0)), np.zeros(0, dtype=np.int32), R)
+            b.predict(6.0, 0.0, 4.0, Q, 0.1)
+            assert np.array_equal(a.download()[0], b.download()[0]) and sa[0] == b.weight_stats()[0]
+    a.close()
+    b.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_ancestors_and_resampling_are_exact(pkg, dtype):
     import torch
     n, nl, seed = 5000, 4, 5
