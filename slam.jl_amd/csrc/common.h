@@ -103,6 +103,7 @@ struct slam_ekf {
 
     int debug_flags;     // SLAMHIP_DEBUG env bits: 1 = no P stores, 2 = no MFMAs, 4 = no P loads (timing experiments, WRONG results)
     void* dd_prof;       // SLAMHIP_DEBUG & 8: per-wave phase clocks of the fp32 down-date (printed at destroy)
+    int factor_blocked;  // K4: blocked MFMA elimination (default) or the scalar one (SLAMHIP_FACTOR=scalar)
     int debug_stamps;    // factor kernel writes 100 MHz wall-clock stamps into d_small[40..47]
     int async_updates;
     int deferred;        // first deferred error

@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 #include "common.h"
@@ -248,6 +249,7 @@ extern "C" int slam_ekf_create(slam_ekf_t* out, int dtype, int max_landmarks, in
     h->async_updates = 0; h->deferred = 0; h->pending_status = 0; h->debug_stamps = 0;
     h->debug_flags = getenv("SLAMHIP_DEBUG") ? atoi(getenv("SLAMHIP_DEBUG")) : 0;
     h->dd_prof = nullptr;
+    h->factor_blocked = !(getenv("SLAMHIP_FACTOR") && !strcmp(getenv("SLAMHIP_FACTOR"), "scalar"));
     h->timing = 0;
     for (int i = 0; i < SLAM_K_COUNT; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
     const int rc = create_impl(h);

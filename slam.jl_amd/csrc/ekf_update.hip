@@ -185,6 +185,219 @@ __device__ __forceinline__ bool eliminate_in_registers(double* M, int mp, int k,
     return !bad;
 }
 
+// ---------------------------------------------------------------------------
+// Blocked elimination for kp <= 128 (same result contract as eliminate_in_registers: afterwards the strictly lower
+// part of M holds inv(L), unit lower, and the diagonal holds D of S = L D L').
+//
+// 16 x 16 blocks, right-looking LDL' with the inverse carried along; everything but the diagonal blocks runs on
+// the fp64 matrix cores (v_mfma_f64_16x16x4_f64: A[i][kk] on lane i + 16 kk, B[kk][j] on lane j + 16 kk,
+// D[4r + lane/16][lane%16] in register r -- so an MFMA RESULT is, register by register, already the B operand of
+// the next product).  Per block step J, TWO barriers instead of 16:
+//   A. wave 0 applies step J-1's trailing update to block (J, J) and factors it in registers (one MFMA per pivot,
+//      no LDS traffic, no barrier inside); meanwhile waves 1.. do the rest of step J-1's trailing update
+//      A_IK -= (L_I,J-1 D_J-1) L_K,J-1' and form T_JC = sum_{K=C}^{J-1} L_JK X_KC for the inverse.
+//   B. panel: L_IJ = A_IJ Linv_JJ' D_J^-1 (I > J), and the inverse's row block X_JC = -Linv_JJ T_JC (C < J).
+// X_JC (J > C) is kept transposed in the unused upper block (C, J) and moved below the diagonal at the end.
+// ---------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// 1/p: hardware estimate + two Newton steps
+__device__ __forceinline__ double pivot_rcp(double piv) {
+    double rp = __builtin_amdgcn_rcp(piv);
+    rp = __builtin_fma(rp, __builtin_fma(-piv, rp, 1.0), rp);
+    rp = __builtin_fma(rp, __builtin_fma(-piv, rp, 1.0), rp);
+    return rp;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int srclane) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), srclane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), srclane);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+__device__ __forceinline__ double bpermute_f64(double v, int srclane) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_ds_bpermute(4 * srclane, (int)(b & 0xffffffffll));
+    const int hi = __builtin_amdgcn_ds_bpermute(4 * srclane, (int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Diagonal block J: Gauss-Jordan of a 16 x 16 SPD block held by ONE wave in the MFMA result layout (element
+// (4r + q, c) in register r of lane c + 16 q), one v_mfma_f64_16x16x4_f64 per pivot: the rank-1 update
+// a_ic -= mu_i a_jc of all 256 elements is the product of the column (-mu_i) and the row (a_jc) in the k = 0 slice.
+// Row j reaches every lane with one bpermute; the multipliers use a_ji for a_ij (the active part is symmetric);
+// column j gets -mu_i exactly (its C entries are zeroed and its row entry is 1).  Leaves the CLEAN unit-lower
+// inv(L_JJ) in M (ones on the diagonal, zeros above), D in dvec, 1/D in dinv.  False on a non-positive pivot.
+__device__ __forceinline__ bool factor_diag_block(double* M, int mp, int J, double* dvec, double* dinv) {
+    const int lane = threadIdx.x & 63;
+    const int c = lane & 15, q = lane >> 4;
+    double* blk = M + (16 * J) * mp + 16 * J;
+    f64x4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = blk[(4 * r + q) * mp + c];
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int rj = j >> 2, qj = j & 3;
+        const double rowv = bpermute_f64(acc[rj], c + 16 * qj);           // a_{j,c} on every lane
+        const double piv = readlane_f64(acc[rj], j + 16 * qj);
+        bad = bad || !(piv > 0.0) || piv == __builtin_inf();
+        const double rp = pivot_rcp(piv);
+        const double aval = (q == 0 && c > j) ? -(rowv * rp) : 0.0;       // A[i = c][kk = 0] = -mu_i (a_ji for a_ij)
+        const double bval = (q == 0) ? (c == j ? 1.0 : rowv) : 0.0;       // B[kk = 0][c]
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * r + 3 > j) acc[r] = (c == j && 4 * r + q > j) ? 0.0 : acc[r];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aval, bval, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * r + q;
+        blk[row * mp + c] = (c < row) ? acc[r] : (c == row ? 1.0 : 0.0);
+        if (c == row) {
+            dvec[16 * J + row] = acc[r];
+            dinv[16 * J + row] = pivot_rcp(acc[r]);
+        }
+    }
+    return !bad;
+}
+
+__device__ __forceinline__ bool eliminate_blocked(double* M, int mp, int k, int kp, double* dvec, double* dinv, double* flag) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    const int nbk = (k + 15) >> 4;                    // blocks that hold real rows; the rest is identity padding
+    // S = (S + S')/2 (ekf.jl:69), in place; D = 1 on the padding
+    // thread (tr, tc) of a (nt/32) x 32 grid walks rows tr + (nt/32) i and columns tc + 32 u: no integer division,
+    // and the (at most four) column visits of a row are requested together
+    const int tc = tid & 31, tr = tid >> 5, trs = nt >> 5;
+    for (int r = tr; r < kp; r += trs) {
+        double v1[4], v2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = tc + 32 * u;
+            const bool on = c < r;                    // (c < r < kp)
+            v1[u] = on ? M[r * mp + c] : 0.0;
+            v2[u] = on ? M[c * mp + r] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = tc + 32 * u;
+            if (c < r) {
+                const double v = (v1[u] + v2[u]) * 0.5;
+                M[r * mp + c] = v;
+                M[c * mp + r] = v;
+            }
+        }
+    }
+    for (int j = tid; j < kp; j += nt) { dvec[j] = 1.0; dinv[j] = 1.0; }
+    if (tid == 0) flag[0] = 0.0;
+    __syncthreads();
+    // trailing update of step Jp on the lower blocks e = e0, e0 + stride, ... (linear index into the lower triangle
+    // of the (nbk-1-Jp)^2 trailing blocks, row by row): A_IK -= (L_IJp D_Jp) L_KJp'.  Up to four blocks at a time with
+    // all their LDS operands requested before the first MFMA.
+    auto trailing = [&](int Jp, int e0, int stride, int e_end) {
+        for (int first = e0; first < e_end; first += 4 * stride) {
+            f64x4 acc[4];
+            double av[4][4], bv[4][4];
+            int bi[4], bk[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = first + q * stride;
+                int I = 0;
+                while ((I + 1) * (I + 2) / 2 <= e) ++I;
+                const int K = e - I * (I + 1) / 2;
+                bi[q] = e < e_end ? Jp + 1 + I : -1;
+                bk[q] = Jp + 1 + K;
+                if (bi[q] < 0) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[q][r] = M[(16 * bi[q] + 4 * r + kk) * mp + 16 * bk[q] + li];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int kx = 4 * s + kk;
+                    av[q][s] = -M[(16 * bi[q] + li) * mp + 16 * Jp + kx] * dvec[16 * Jp + kx];
+                    bv[q][s] = M[(16 * bk[q] + li) * mp + 16 * Jp + kx];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (bi[q] < 0) continue;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][s], bv[q][s], acc[q], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) M[(16 * bi[q] + 4 * r + kk) * mp + 16 * bk[q] + li] = acc[q][r];
+            }
+        }
+    };
+    for (int J = 0; J < nbk; ++J) {
+        // ---- [A] wave 0: the trailing update of block (J, J) from step J-1, then its factorisation.
+        //      waves 1..: the rest of step J-1's trailing update, then T_JC = sum_{K=C}^{J-1} L_JK X_KC.
+        f64x4 T = {0.0, 0.0, 0.0, 0.0};
+        const int C = wave - 1;                       // this wave's block column of the inverse (waves 1..J)
+        const int tp = nbk - J;                       // trailing block rows of step J-1
+        if (wave == 0) {
+            if (J > 0) trailing(J - 1, 0, 1, 1);
+            if (!factor_diag_block(M, mp, J, dvec, dinv) && lane == 0) flag[0] = 1.0;
+        } else {
+            if (J > 0) trailing(J - 1, wave, nwaves - 1, tp * (tp + 1) / 2);
+            if (C < J) {
+                for (int K = C; K < J; ++K) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int kx = 4 * s + kk;
+                        const double av = M[(16 * J + li) * mp + 16 * K + kx];                       // L_JK[li][kx]
+                        const double bv = (K == C) ? M[(16 * C + kx) * mp + 16 * C + li]             // Linv_CC[kx][li]
+                                                   : M[(16 * C + li) * mp + 16 * K + kx];            // X_KC[kx][li]
+                        T = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, T, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- [B] (waves 1..nbk-1: at most 7 tasks, nbk <= 8)
+        if (wave >= 1 && C < J) {                     // X_JC = -Linv_JJ * T_JC, stored transposed in block (C, J)
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(M[(16 * J + li) * mp + 16 * J + 4 * s + kk], T[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) M[(16 * C + li) * mp + 16 * J + 4 * r + kk] = -acc[r];
+        } else if (wave > J && wave < nbk) {          // L_IJ = A_IJ * Linv_JJ' * D_J^-1, I = wave
+            const int I = wave;
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int kx = 4 * s + kk;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(M[(16 * I + li) * mp + 16 * J + kx],
+                                                           M[(16 * J + li) * mp + 16 * J + kx], acc, 0, 0, 0);
+            }
+            const double di = dinv[16 * J + li];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) M[(16 * I + 4 * r + kk) * mp + 16 * J + li] = acc[r] * di;
+        }
+        __syncthreads();
+    }
+    // the inverse's off-diagonal blocks move below the diagonal (over L, no longer needed); D goes on the diagonal
+    for (int b = tr; b < kp; b += trs) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int a = tc + 32 * u;
+            const bool low = a < kp && (b >> 4) > (a >> 4);
+            v[u] = (low && (b >> 4) < nbk) ? M[(size_t)a * mp + b] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int a = tc + 32 * u;
+            if (a < kp && (b >> 4) > (a >> 4)) M[(size_t)b * mp + a] = v[u];
+        }
+    }
+    for (int j = tid; j < kp; j += nt) M[(size_t)j * mp + j] = dvec[j];
+    __syncthreads();
+    return flag[0] == 0.0;
+}
+
 __device__ inline bool eliminate_in_memory(double* M, int mp, int k, double* mvec) {
     const int tid = threadIdx.x, nt = blockDim.x;
     for (int j = 0; j < k; ++j) {
@@ -215,7 +428,7 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
     const int32_t* __restrict__ idf, int m, int k, int kp, double R0, double R1, double R2, double R3,
     double* __restrict__ Cout, int c_pitch, double* __restrict__ gvec, double* __restrict__ Sout, int want_sinv,
     double* __restrict__ Mglobal, int32_t* __restrict__ status, unsigned long long* __restrict__ stamps,
-    const int32_t* __restrict__ dcount) {
+    const int32_t* __restrict__ dcount, int blocked) {
 #define STAMP(i)                                                  \
     do {                                                          \
         if (stamps && threadIdx.x == 0) stamps[i] = wall_clock64(); \
@@ -343,6 +556,7 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
     STAMP(3);
     bool ok;
     if constexpr (!INLDS) ok = eliminate_in_memory(M, mp, k, mvec);
+    else if (blocked) ok = eliminate_blocked(M, mp, k, kp, rowbuf, rowbuf + kp, colbuf);
     else if (kp == 32) ok = eliminate_in_registers<2>(M, mp, k, kp, rowbuf, colbuf);
     else if (kp == 64) ok = eliminate_in_registers<4>(M, mp, k, kp, rowbuf, colbuf);
     else if (kp == 96) ok = eliminate_in_registers<6>(M, mp, k, kp, rowbuf, colbuf);
@@ -519,7 +733,6 @@ __global__ __launch_bounds__(256) void panel_gemm_kernel(const double* __restric
 // loads PAIRS of consecutive doubles (16-byte loads).  C is upper triangular: column block cb needs k < 16(cb+1)
 // only -- 144 instead of 256 MFMAs per wave at kp = 128.  A workgroup = 8 waves = 128 rows.
 // ---------------------------------------------------------------------------
-typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 constexpr int W1_THREADS = 512;
 
@@ -653,11 +866,11 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form, const int32_t*
         if (in_lds)
             hipLaunchKernelGGL((factor_kernel<T, true>), dim3(1), dim3(FACTOR_THREADS), shm, h->stream, x, h->PHt, pitchA,
                                h->obsbuf, h->idfbuf, m, k, kp, R[0], R[1], R[2], R[3], h->Cmat, pitchA, h->gvec,
-                               joseph ? h->Smat : (double*)nullptr, joseph ? 1 : 0, (double*)nullptr, h->d_status, stamps, dcount);
+                               joseph ? h->Smat : (double*)nullptr, joseph ? 1 : 0, (double*)nullptr, h->d_status, stamps, dcount, h->factor_blocked);
         else
             hipLaunchKernelGGL((factor_kernel<T, false>), dim3(1), dim3(FACTOR_THREADS), shm, h->stream, x, h->PHt, pitchA,
                                h->obsbuf, h->idfbuf, m, k, kp, R[0], R[1], R[2], R[3], h->Cmat, pitchA, h->gvec,
-                               joseph ? h->Smat : (double*)nullptr, joseph ? 1 : 0, h->Mwork, h->d_status, stamps, dcount);
+                               joseph ? h->Smat : (double*)nullptr, joseph ? 1 : 0, h->Mwork, h->d_status, stamps, dcount, 0);
     }
     HIP_TRY(hipGetLastError());
     const dim3 pg_grid(h->npad / PG_ROWS, (kp + PG_COLS - 1) / PG_COLS);
