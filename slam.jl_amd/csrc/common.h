@@ -130,8 +130,9 @@ struct KTimer {
 int launch_mirror(slam_ekf* h);     // make the tiles above the diagonal valid (before a download)
 int launch_predict(slam_ekf* h, double v, double g, double w, const double Q[4], double dt);
 int launch_augment(slam_ekf* h, int nn, const double R[4], const double* zn_dev);   // zn already on the device (obsbuf or znbuf)
-int launch_compact(slam_ekf* h, int nz, const double* z_src);   // d_assoc -> idfbuf/obsbuf (matched, in order), znbuf (new), d_count = {m, nn}
-int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gate2, const double* z_src);   // z_src: device-readable (obsbuf or pinned host)
+int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gate2, const double* z_src, bool compact);
+// z_src: device-readable (obsbuf or pinned host); compact (observe()): d_assoc -> idfbuf/obsbuf (matched, in order),
+// znbuf (new), d_count = {m, nn}, h_assoc (pinned) -- done by the last gate_final launch
 int launch_nis(slam_ekf* h, const double z1[2], int j, const double R[4]);
 int launch_obs_model(slam_ekf* h, int j);
 int launch_update(slam_ekf* h, int m, const double R[4], int form, bool device_count);   // device_count: m is an upper bound, kernels read d_count[0]

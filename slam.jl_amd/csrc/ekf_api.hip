@@ -387,7 +387,7 @@ extern "C" int slam_ekf_associate(slam_ekf_t h, const double* z, int nz, const d
     }
     HIP_TRY(hipSetDevice(h->device));
     if ((rc = stage_obs(h, z, nullptr, nz))) return rc;
-    if ((rc = launch_gate(h, nz, R, gate1, gate2, h->obsbuf))) return rc;
+    if ((rc = launch_gate(h, nz, R, gate1, gate2, h->obsbuf, false))) return rc;
     HIP_TRY(hipMemcpyAsync(h->h_assoc, h->d_assoc, sizeof(int32_t) * (size_t)nz, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     memcpy(assoc, h->h_assoc, sizeof(int32_t) * (size_t)nz);
@@ -502,8 +502,7 @@ extern "C" int slam_ekf_observe(slam_ekf_t h, const double* z, int nz, const dou
         h->stage_pending = 0;
     }
     memcpy(h->h_obs, z, sizeof(double) * 2 * (size_t)nz);
-    if ((rc = launch_gate(h, nz, R, gate1, gate2, h->h_obs_dev))) return rc;
-    if ((rc = launch_compact(h, nz, h->h_obs_dev))) return rc;
+    if ((rc = launch_gate(h, nz, R, gate1, gate2, h->h_obs_dev, true))) return rc;      // gating + compaction
     HIP_TRY(hipEventRecord(h->assoc_ev, h->stream));       // (also marks the pinned buffers as consumed)
     if ((rc = launch_update(h, nz, R, form, true))) return rc;
     HIP_TRY(hipEventSynchronize(h->assoc_ev));          // gating only: the update runs on behind it

@@ -15,14 +15,17 @@
 // (SURVEY.md 3.2):  jbest = argmin_{j : nis_j < gate1, nd_j < Inf} nd_j, lowest j
 // on ties; if none: new feature iff no j has nis_j <= gate2 (outer > gate2).
 // Only waves that contain an in-gate landmark pay for a shuffle reduction; the
-// rest contribute two ballots per observation.
+// rest contribute two ballots per observation.  A workgroup is eight waves over the SAME
+// 64 landmarks, each taking every eighth observation: N/64 one-wave workgroups left
+// most SIMDs idle while each wave ground through all nz observations alone.
 #include "common.h"
 #include "device_math.h"
 
 namespace {
 
-constexpr int GATE_BLOCK = 64;      // one wave per workgroup: N/64 workgroups spread the sweep over the CUs
-constexpr int GATE_WAVES = 1;
+constexpr int GATE_BLOCK = 64;      // landmarks per workgroup (one per lane): N/64 workgroups spread the sweep over the CUs
+constexpr int GATE_WAVES = 1;       // (partials per workgroup and observation)
+constexpr int OBS_WAVES = 8;        // waves per workgroup: all own the same 64 landmarks, wave w the observations w, w+8, ...
 
 struct PairConst {        // per-landmark, observation-independent
     double zp0, zp1;
@@ -106,7 +109,7 @@ __device__ inline PairConst landmark_const(const T* __restrict__ x, const T* __r
 }
 
 template <typename T>
-__global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(const T* __restrict__ x, const T* __restrict__ P, int ld,
+__global__ __launch_bounds__(GATE_BLOCK * OBS_WAVES) void gate_kernel(const T* __restrict__ x, const T* __restrict__ P, int ld,
                                                            int N, const double* __restrict__ z, int nz, double R0,
                                                            double R1, double R2, double R3, double gate1, double gate2,
                                                            double* __restrict__ part) {
@@ -115,7 +118,9 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(const T* __restrict__ 
     double* red = smem + 2 * nz;       // [nz][3]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    for (int i = tid; i < 2 * nz; i += GATE_BLOCK) zs[i] = z[i];
+    const int wave = tid >> 6;
+    constexpr int NT = GATE_BLOCK * OBS_WAVES;
+    for (int i = tid; i < 2 * nz; i += NT) zs[i] = z[i];
 
     const double R[4] = {R0, R1, R2, R3};
     double pose[3] = {(double)x[0], (double)x[1], (double)x[2]};
@@ -125,13 +130,14 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(const T* __restrict__ 
 #pragma unroll
         for (int c = 0; c < 3; ++c) pvv[r * 3 + c] = (double)P[(size_t)c * ld + r];
 
-    const int j0 = blockIdx.x * GATE_BLOCK + tid;
+    // the landmark constants are evaluated by every wave (cheaper than a hand-over through LDS: ~200 flops)
+    const int j0 = blockIdx.x * GATE_BLOCK + lane;
     const bool valid = j0 < N;
     PairConst pc;
     if (valid) pc = landmark_const(x, P, ld, j0, pose, pvv, R);
     const double INF = __builtin_inf();
     // per-observation result of this wave, default "nothing in either gate"
-    for (int i = tid; i < nz; i += GATE_BLOCK) {
+    for (int i = tid; i < nz; i += NT) {
         red[3 * i] = INF;
         red[3 * i + 1] = (double)0x7fffffff;
         red[3 * i + 2] = 0.0;
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(const T* __restrict__ 
 
     // Almost every (observation, landmark) pair is far outside both gates: the common path is a
     // 2-vector innovation, a 2x2 quadratic form and two ballots, with no LDS traffic at all.
-    for (int i = 0; i < nz; ++i) {
+    for (int i = wave; i < nz; i += OBS_WAVES) {
         double nis = INF, nd = INF;
         if (valid) pair_eval(pc, zs[2 * i], zs[2 * i + 1], nis, nd);
         const bool cand = valid && (nis < gate1) && (nd < INF);
@@ -167,73 +173,17 @@ __global__ __launch_bounds__(GATE_BLOCK) void gate_kernel(const T* __restrict__ 
         }
     }
     __syncthreads();
-    for (int i = tid; i < 3 * nz; i += GATE_BLOCK) part[(size_t)blockIdx.x * 3 * nz + i] = red[i];
-}
-
-// One wave per observation folds the per-workgroup partials into assoc[i].
-__global__ __launch_bounds__(64) void gate_final_kernel(const double* __restrict__ part, int nblocks, int nz,
-                                                        int32_t* __restrict__ assoc) {
-    const int i = blockIdx.x;
-    const int lane = threadIdx.x;
-    const double INF = __builtin_inf();
-    double nd_c = INF, j_c = (double)0x7fffffff;
-    bool near = false;
-    for (int b = lane; b < nblocks; b += 64) {
-        const double* r = part + ((size_t)b * nz + i) * 3;
-        const double r0 = r[0], r1 = r[1], r2 = r[2];
-        if (r0 < nd_c || (r0 == nd_c && r1 < j_c)) { nd_c = r0; j_c = r1; }
-        near = near || (r2 != 0.0);
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double o_nd = __shfl_xor(nd_c, off);
-        const double o_j = __shfl_xor(j_c, off);
-        if (o_nd < nd_c || (o_nd == nd_c && o_j < j_c)) { nd_c = o_nd; j_c = o_j; }
-    }
-    const bool any_near = __ballot(near) != 0ull;
-    if (lane == 0) {
-        int32_t a;
-        if (nd_c < INF) a = (int32_t)j_c;            // jbest != 0          (:43)
-        else if (!any_near) a = -1;                  // outer > gate2       (:46)
-        else a = 0;                                  // dropped
-        assoc[i] = a;
-    }
-}
-
-// compute_association for ONE pair and predict_observation for ONE landmark.
-template <typename T>
-__global__ void single_pair_kernel(const T* __restrict__ x, const T* __restrict__ P, int ld, int j0, double z0, double z1,
-                                   double R0, double R1, double R2, double R3, int mode, double* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const double R[4] = {R0, R1, R2, R3};
-    double pose[3] = {(double)x[0], (double)x[1], (double)x[2]};
-    if (mode == 1) {   // predict_observation: zp[2], Hv (col-major 2x3), Hf (col-major 2x2)
-        const int f = 3 + 2 * j0;
-        const ObsModel om = obs_model(pose[0], pose[1], pose[2], (double)x[f], (double)x[f + 1]);
-        out[0] = om.zp[0]; out[1] = om.zp[1];
-        for (int c = 0; c < 3; ++c) { out[2 + 2 * c] = om.Hv[c]; out[2 + 2 * c + 1] = om.Hv[3 + c]; }
-        for (int c = 0; c < 2; ++c) { out[8 + 2 * c] = om.Hf[c]; out[8 + 2 * c + 1] = om.Hf[2 + c]; }
-        return;
-    }
-    double pvv[9];
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) pvv[r * 3 + c] = (double)P[(size_t)c * ld + r];
-    const PairConst pc = landmark_const(x, P, ld, j0, pose, pvv, R);
-    double nis, nd;
-    pair_eval(pc, z0, z1, nis, nd);
-    out[0] = nis;
-    out[1] = nd;
+    for (int i = tid; i < 3 * nz; i += NT) part[(size_t)blockIdx.x * 3 * nz + i] = red[i];
 }
 
 // observe(): turn the association vector into the update's and add_features' inputs without leaving the device.
 // One wave walks the observations in order, 64 at a time: matched ones (assoc >= 1) are compacted to the front
 // of zbuf/idf (zsrc may BE zbuf: a write position never passes the read position of a later chunk), new ones
 // (assoc < 0) go to zn.  count = {matched, new}.  Order is the observation order, as in data-association.jl:43-47.
-__global__ __launch_bounds__(64) void compact_kernel(const int32_t* __restrict__ assoc, int nz,
-                                                     const double* __restrict__ zsrc, double* __restrict__ zbuf,
-                                                     int32_t* __restrict__ idf, double* __restrict__ zn,
-                                                     int32_t* __restrict__ count, int32_t* __restrict__ assoc_host) {
-    const int lane = threadIdx.x;
+__device__ __forceinline__ void compact_wave(const int32_t* assoc, int nz, const double* __restrict__ zsrc,
+                                             double* __restrict__ zbuf, int32_t* __restrict__ idf,
+                                             double* __restrict__ zn, int32_t* __restrict__ count,
+                                             int32_t* __restrict__ assoc_host, int lane) {
     int m = 0, nn = 0;
     for (int base = 0; base < nz; base += 64) {
         const int i = base + lane;
@@ -263,16 +213,78 @@ __global__ __launch_bounds__(64) void compact_kernel(const int32_t* __restrict__
     }
 }
 
-}  // namespace
-
-int launch_compact(slam_ekf* h, int nz, const double* z_src) {
-    hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(64), 0, h->stream, (const int32_t*)h->d_assoc, nz, z_src, h->obsbuf,
-                       h->idfbuf, h->znbuf, h->d_count, h->h_assoc_dev);
-    HIP_TRY(hipGetLastError());
-    return SLAM_OK;
+// One wave per observation folds the per-workgroup partials into assoc[i].  With `compact_total` > 0 (observe(),
+// last chunk) the LAST workgroup to finish -- an arrival counter in device memory -- then turns
+// assoc[0 .. compact_total) into the update's inputs: no extra launch, and the fold stays nz-way parallel.
+__global__ __launch_bounds__(64) void gate_final_kernel(
+    const double* __restrict__ part, int nblocks, int nz, int32_t* assoc, int32_t* assoc_all,     // (the two alias)
+    int compact_total, const double* __restrict__ zsrc, double* __restrict__ zbuf, int32_t* __restrict__ idf,
+    double* __restrict__ zn, int32_t* __restrict__ count, int32_t* __restrict__ assoc_host, int32_t* arrive) {
+    const int i = blockIdx.x;
+    const int lane = threadIdx.x;
+    const double INF = __builtin_inf();
+    double nd_c = INF, j_c = (double)0x7fffffff;
+    bool near = false;
+    for (int b = lane; b < nblocks; b += 64) {
+        const double* r = part + ((size_t)b * nz + i) * 3;
+        const double r0 = r[0], r1 = r[1], r2 = r[2];
+        if (r0 < nd_c || (r0 == nd_c && r1 < j_c)) { nd_c = r0; j_c = r1; }
+        near = near || (r2 != 0.0);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double o_nd = __shfl_xor(nd_c, off);
+        const double o_j = __shfl_xor(j_c, off);
+        if (o_nd < nd_c || (o_nd == nd_c && o_j < j_c)) { nd_c = o_nd; j_c = o_j; }
+    }
+    const bool any_near = __ballot(near) != 0ull;
+    int last = 0;
+    if (lane == 0) {
+        int32_t a;
+        if (nd_c < INF) a = (int32_t)j_c;            // jbest != 0          (:43)
+        else if (!any_near) a = -1;                  // outer > gate2       (:46)
+        else a = 0;                                  // dropped
+        assoc[i] = a;
+        if (compact_total > 0) {
+            __threadfence();                         // assoc[i] before the arrival
+            last = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+        }
+    }
+    if (compact_total > 0 && __shfl(last, 0)) {
+        __threadfence();
+        compact_wave(assoc_all, compact_total, zsrc, zbuf, idf, zn, count, assoc_host, lane);
+        if (lane == 0) __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed
+    }
 }
 
-int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gate2, const double* z_src) {
+// compute_association for ONE pair and predict_observation for ONE landmark.
+template <typename T>
+__global__ void single_pair_kernel(const T* __restrict__ x, const T* __restrict__ P, int ld, int j0, double z0, double z1,
+                                   double R0, double R1, double R2, double R3, int mode, double* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double R[4] = {R0, R1, R2, R3};
+    double pose[3] = {(double)x[0], (double)x[1], (double)x[2]};
+    if (mode == 1) {   // predict_observation: zp[2], Hv (col-major 2x3), Hf (col-major 2x2)
+        const int f = 3 + 2 * j0;
+        const ObsModel om = obs_model(pose[0], pose[1], pose[2], (double)x[f], (double)x[f + 1]);
+        out[0] = om.zp[0]; out[1] = om.zp[1];
+        for (int c = 0; c < 3; ++c) { out[2 + 2 * c] = om.Hv[c]; out[2 + 2 * c + 1] = om.Hv[3 + c]; }
+        for (int c = 0; c < 2; ++c) { out[8 + 2 * c] = om.Hf[c]; out[8 + 2 * c + 1] = om.Hf[2 + c]; }
+        return;
+    }
+    double pvv[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) pvv[r * 3 + c] = (double)P[(size_t)c * ld + r];
+    const PairConst pc = landmark_const(x, P, ld, j0, pose, pvv, R);
+    double nis, nd;
+    pair_eval(pc, z0, z1, nis, nd);
+    out[0] = nis;
+    out[1] = nd;
+}
+
+}  // namespace
+
+int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gate2, const double* z_src, bool compact) {
     const int nblocks = (h->N + GATE_BLOCK - 1) / GATE_BLOCK;
     if (nblocks > h->gate_blocks_cap) {
         slam_set_error("internal: gate partial buffer too small");
@@ -287,19 +299,21 @@ int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gat
         {
             KTimer t(h, SLAM_K_GATE);
             if (h->dtype == SLAM_F32)
-                hipLaunchKernelGGL(gate_kernel<float>, dim3(nblocks), dim3(GATE_BLOCK), shmem, h->stream,
+                hipLaunchKernelGGL(gate_kernel<float>, dim3(nblocks), dim3(GATE_BLOCK * OBS_WAVES), shmem, h->stream,
                                    (const float*)h->x, (const float*)h->P, h->ld, h->N, zc, cz, R[0], R[1], R[2], R[3],
                                    gate1, gate2, h->gate_part);
             else
-                hipLaunchKernelGGL(gate_kernel<double>, dim3(nblocks), dim3(GATE_BLOCK), shmem, h->stream,
+                hipLaunchKernelGGL(gate_kernel<double>, dim3(nblocks), dim3(GATE_BLOCK * OBS_WAVES), shmem, h->stream,
                                    (const double*)h->x, (const double*)h->P, h->ld, h->N, zc, cz, R[0], R[1], R[2], R[3],
                                    gate1, gate2, h->gate_part);
         }
         HIP_TRY(hipGetLastError());
         {
             KTimer t(h, SLAM_K_GATE_FIN);
-            hipLaunchKernelGGL(gate_final_kernel, dim3(cz), dim3(64), 0, h->stream, h->gate_part, nblocks, cz,
-                               h->d_assoc + o);
+            const bool last = o + CHUNK >= nz;
+            hipLaunchKernelGGL(gate_final_kernel, dim3(cz), dim3(64), 0, h->stream, (const double*)h->gate_part, nblocks, cz,
+                               h->d_assoc + o, h->d_assoc, (compact && last) ? nz : 0, z_src, h->obsbuf, h->idfbuf, h->znbuf,
+                               h->d_count, h->h_assoc_dev, h->d_count + 2);
         }
         HIP_TRY(hipGetLastError());
     }
