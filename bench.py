@@ -147,13 +147,39 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
             el = float(tt.item())
         res[regime] = {"particle_steps_per_s": NP * steps / el, "ms_per_step": el / steps * 1e3, "resamples": nres}
     pf.close()
+    weak = None
+    if world > 1:
+        # the same filter with the per-GPU particle count held at 262144 (weak scaling): the strong-scaling figure
+        # above divides 52 us of sweep per step by N and leaves the per-step collective latency
+        pfw = pkg.PFSlamState(NP * world, NL, seed=20240602, dtype="f32", device=local_rank, distributed=True)
+        pfw.shard.set_pose([0.0, 0.0, 0.3])
+        pfw.shard.init_landmarks(lm, 0.01, 0.1)
+        itw = iter(obs)
+        for _ in range(warmup):
+            z, ids = next(itw)
+            pfw.step(8.0, 0.0, 4.0, Q, 0.025, z, ids, R, force_resample=False)
+        pfw.shard.sync()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            z, ids = next(itw)
+            pfw.step(8.0, 0.0, 4.0, Q, 0.025, z, ids, R, force_resample=False)
+        pfw.shard.sync()
+        fence()
+        el = time.perf_counter() - t0
+        tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+        weak = {"particles": NP * world, "particle_steps_per_s": NP * world * steps / el, "ms_per_step": el / steps * 1e3,
+                "regime": "no_resample, 262144 particles per GPU"}
+        pfw.close()
     bytes_per = 24 + 8 + M * 40             # pose r/w + log-weight r/w + 5 floats read and written per observed landmark
     t_step = res["no_resample"]["ms_per_step"] * 1e-3
     return {"metric": "FastSLAM particle-steps/sec", "value": res["neff_triggered"]["particle_steps_per_s"],
             "unit": "particle-steps/s", "n_gpus": world, "scaling": "strong",
             "config": {"workload": f"FastSLAM-1.0 known correspondences, {NP} particles x {NL} landmarks, {M} obs/step, fp32, "
                                    f"predict + {M} 2x2 EKF updates + weights + Neff all-reduce (+ resample when Neff < 0.75 Np)"},
-            "regimes": res,
+            "regimes": res, "weak_scaling": weak,
             "roofline": {"bound": "hbm", "achieved": NP * bytes_per / t_step / 1e9, "peak": HBM_PEAK_GBPS * world,
                          "unit": "GB/s", "frac": NP * bytes_per / t_step / 1e9 / (HBM_PEAK_GBPS * world), "traffic": None,
                          "algorithmic_bytes_per_particle_step": bytes_per, "regime": "no_resample (one fused sweep "

@@ -191,6 +191,9 @@ class _SingleProcess:
     def all_gather(self, t, n_global):
         return t
 
+    def all_gather_scalars(self, vec):
+        return [list(vec)]
+
     def all_to_all_v(self, send, send_counts, recv_counts):
         return send
 
@@ -215,6 +218,14 @@ class TorchComm:
         t = torch.tensor(list(vec), dtype=torch.float64, device=self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return [float(x) for x in t.tolist()]
+
+    def all_gather_scalars(self, vec):
+        """[world][len(vec)] float64 table, rows in rank order."""
+        import torch
+        t = torch.tensor(list(vec), dtype=torch.float64, device=self.device)
+        out = torch.empty(self.world * t.numel(), dtype=torch.float64, device=self.device)
+        self.dist.all_gather_into_tensor(out, t)
+        return out.reshape(self.world, -1).tolist()
 
     def all_gather(self, t, n_global):
         import torch
@@ -254,12 +265,18 @@ class FastSLAM:
         self.shard.update_known(z, ids, R)
 
     def global_stats(self, local=None):
-        """(gmax, sum w, sum w^2) with w = exp(logw - gmax): one MAX and one SUM all-reduce of scalars.
+        """(gmax, sum w, sum w^2) with w = exp(logw - gmax): one all-gather of three scalars per rank.
         ``local``: this shard's (max, sum, sum2) if a fused step has already produced them."""
         lmax, s1, s2 = self.shard.weight_stats() if local is None else local
-        gmax = self.comm.allreduce_max(lmax)
-        f = math.exp(lmax - gmax)
-        gs1, gs2 = self.comm.allreduce_sum([s1 * f, s2 * f * f])
+        # ONE small all-gather of (max, sum, sum2) per rank; every rank then folds the same table in rank order
+        # (two dependent all-reduces -- MAX, then SUM of the rescaled sums -- cost two collective latencies per step)
+        table = self.comm.all_gather_scalars([lmax, s1, s2])
+        gmax = max(row[0] for row in table)
+        gs1 = gs2 = 0.0
+        for m_r, s1_r, s2_r in table:
+            f = math.exp(m_r - gmax)
+            gs1 += s1_r * f
+            gs2 += s2_r * f * f
         return gmax, gs1, gs2
 
     def normalize(self, local=None):
