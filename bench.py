@@ -37,6 +37,7 @@ R = np.array([[0.1 ** 2, 0.0], [0.0, (math.pi / 180) ** 2]])
 GATE1, GATE2 = 4.0, 25.0
 SEED = 20240601
 MFMA_F32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md, Peak FP32 (matrix)
+RED_DEVICE = "cpu" if os.environ.get("SLAM_BENCH_REHEARSE") == "1" else "cuda"     # where timing scalars are reduced
 HBM_PEAK_GBPS = 8000.0                # MI355X_MICROARCH.md, HBM3E peak (6290 measured copy rate)
 
 
@@ -142,7 +143,7 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
         fence()
         el = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([el], dtype=torch.float64, device=RED_DEVICE)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         res[regime] = {"particle_steps_per_s": NP * steps / el, "ms_per_step": el / steps * 1e3, "resamples": nres}
@@ -167,7 +168,7 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
         pfw.shard.sync()
         fence()
         el = time.perf_counter() - t0
-        tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([el], dtype=torch.float64, device=RED_DEVICE)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
         weak = {"particles": NP * world, "particle_steps_per_s": NP * world * steps / el, "ms_per_step": el / steps * 1e3,
@@ -207,9 +208,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rehearse = os.environ.get("SLAM_BENCH_REHEARSE") == "1"    # several ranks on ONE card over gloo: plumbing check only
+    if rehearse:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
 
     from __graft_entry__ import load_package
@@ -271,10 +278,10 @@ def main():
     stamps = st.debug_stamps(False)
     phases = [(b - a) / 100.0 for a, b in zip(stamps[:6], stamps[1:7])]     # 100 MHz ticks -> us
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=RED_DEVICE)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        mt = torch.tensor([matched], dtype=torch.float64, device="cuda")
+        mt = torch.tensor([matched], dtype=torch.float64, device=RED_DEVICE)
         dist.all_reduce(mt, op=dist.ReduceOp.SUM)
         matched_all = float(mt.item())
     else:

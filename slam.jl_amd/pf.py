@@ -199,46 +199,58 @@ class _SingleProcess:
 
 
 class TorchComm:
-    """torch.distributed (nccl = RCCL over xGMI on the GPUs, gloo in the CPU tests)."""
+    """torch.distributed (nccl = RCCL over xGMI on the GPUs, gloo in the CPU tests).
+
+    With the gloo backend device tensors are staged through the host (gloo's CUDA support is partial): that
+    is how several ranks can rehearse the real GPU shards on ONE card; RCCL runs never take that path."""
 
     def __init__(self, device):
         import torch.distributed as dist
         self.dist = dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.device = device
+        self.stage = dist.get_backend() == "gloo"
+
+    def _in(self, t):
+        return t.cpu() if self.stage and t.is_cuda else t
+
+    def _out(self, t, like):
+        return t.to(like.device) if self.stage and like.is_cuda else t
 
     def allreduce_max(self, v):
         import torch
-        t = torch.tensor([v], dtype=torch.float64, device=self.device)
+        t = torch.tensor([v], dtype=torch.float64, device="cpu" if self.stage else self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
     def allreduce_sum(self, vec):
         import torch
-        t = torch.tensor(list(vec), dtype=torch.float64, device=self.device)
+        t = torch.tensor(list(vec), dtype=torch.float64, device="cpu" if self.stage else self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return [float(x) for x in t.tolist()]
 
     def all_gather_scalars(self, vec):
         """[world][len(vec)] float64 table, rows in rank order."""
         import torch
-        t = torch.tensor(list(vec), dtype=torch.float64, device=self.device)
-        out = torch.empty(self.world * t.numel(), dtype=torch.float64, device=self.device)
+        t = torch.tensor(list(vec), dtype=torch.float64, device="cpu" if self.stage else self.device)
+        out = torch.empty(self.world * t.numel(), dtype=torch.float64, device=t.device)
         self.dist.all_gather_into_tensor(out, t)
         return out.reshape(self.world, -1).tolist()
 
     def all_gather(self, t, n_global):
         import torch
-        out = torch.empty(n_global, dtype=t.dtype, device=t.device)
-        self.dist.all_gather_into_tensor(out, t.contiguous())       # equal slices: rank r owns [r*n, (r+1)*n)
-        return out
+        src = self._in(t.contiguous())
+        out = torch.empty(n_global, dtype=src.dtype, device=src.device)
+        self.dist.all_gather_into_tensor(out, src)       # equal slices: rank r owns [r*n, (r+1)*n)
+        return self._out(out, t)
 
     def all_to_all_v(self, send, send_counts, recv_counts):
         """Rows of `send` (dim 0) are grouped by destination rank; returns the rows received, grouped by source."""
         import torch
-        out = torch.empty((int(sum(recv_counts)),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
-        self.dist.all_to_all_single(out, send.contiguous(), [int(c) for c in recv_counts], [int(c) for c in send_counts])
-        return out
+        src = self._in(send.contiguous())
+        out = torch.empty((int(sum(recv_counts)),) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        self.dist.all_to_all_single(out, src, [int(c) for c in recv_counts], [int(c) for c in send_counts])
+        return self._out(out, send)
 
 
 class FastSLAM:
