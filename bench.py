@@ -61,6 +61,40 @@ def make_workload(N, nz, nsteps, seed):
     return x, P, zs
 
 
+def make_workload_on_device(pkg, N, nz, nsteps, seed, dtype, device):
+    """The same kind of workload for maps whose covariance does not fit the host comfortably (N = 50k, fp64:
+    80 GB): x and the observations come from NumPy, P = A A' + 0.01 I is formed on the GPU by torch and handed to
+    the library device-to-device (slam_ekf_set_state_device)."""
+    import torch
+    rng = np.random.default_rng(seed)
+    n = 3 + 2 * N
+    L = 100.0 * math.sqrt(N / 35.0)
+    lm = rng.uniform(0, L, (2, N))
+    pose = np.array([L / 2, L / 2, 0.3])
+    npdt = np.float32 if dtype == "f32" else np.float64
+    x = np.concatenate([pose, (lm + rng.normal(0, 0.1, lm.shape)).T.reshape(-1)]).astype(npdt)
+    tdt = torch.float32 if dtype == "f32" else torch.float64
+    dev = torch.device("cuda", device)
+    A = torch.from_numpy(rng.normal(0, 0.05, (n, 16)).astype(npdt)).to(dev)
+    Pd = torch.empty((n, n), dtype=tdt, device=dev)
+    torch.mm(A, A.t(), out=Pd)                     # symmetric by construction (same products both ways)
+    Pd.diagonal().add_(0.01)
+    Pd = torch.maximum(Pd, Pd.t()) if n <= 30000 else Pd
+    xd = torch.from_numpy(x).to(dev)
+    st = pkg.EKFSlamState(np.asarray(x[:3]), np.zeros((3, 3), dtype=npdt), dtype=dtype, max_landmarks=N, device=device)
+    torch.cuda.synchronize(dev)
+    st.set_state_device(xd.data_ptr(), Pd.data_ptr(), n, n)     # row-major == column-major for a symmetric matrix
+    st.sync()
+    del Pd, A
+    torch.cuda.empty_cache()
+    dx, dy = lm[0] - pose[0], lm[1] - pose[1]
+    fwd = np.flatnonzero(dx * math.cos(pose[2]) + dy * math.sin(pose[2]) > 0)
+    ids = fwd[np.argsort(dx[fwd] ** 2 + dy[fwd] ** 2)[:nz]]
+    ztrue = np.vstack([np.hypot(dx[ids], dy[ids]), np.arctan2(dy[ids], dx[ids]) - pose[2]])
+    zs = [ztrue + rng.normal(0, 1, ztrue.shape) * np.array([[0.1], [math.pi / 180]]) for _ in range(nsteps)]
+    return st, zs
+
+
 def gpu_step(st, z):
     """associate -> (host splits the decisions, as sim! does) -> update.  Returns matched count."""
     a = st.associate_vector(z, R, GATE1, GATE2)
@@ -225,8 +259,14 @@ def main():
     N, nz = args.landmarks, args.obs
     n = 3 + 2 * N
     total_steps = args.warmup + args.steps
-    x, P, zs = make_workload(N, nz, total_steps, SEED + rank)      # every replica gets its own noise
-    st = pkg.EKFSlamState(x, P, dtype=args.dtype, max_landmarks=N, device=local_rank)
+    big = n > 30000                                                # covariance built on the device (see above)
+    if big:
+        st, zs = make_workload_on_device(pkg, N, nz, total_steps, SEED + rank, args.dtype, local_rank)
+        x = P = None
+        args.no_cpu_baseline = True
+    else:
+        x, P, zs = make_workload(N, nz, total_steps, SEED + rank)  # every replica gets its own noise
+        st = pkg.EKFSlamState(x, P, dtype=args.dtype, max_landmarks=N, device=local_rank)
 
     def step(z):
         if args.unfused:                   # the reference's three calls, decisions split on the host (sim! :114-120)

@@ -39,9 +39,8 @@
 // column by column, so the four row panels stay L2-resident and every column
 // panel fetched is used four times.
 //
-// fp64: the same triangular / mirrored scheme with an LDS-tiled VALU kernel
-// (64 x 64 tile, 4 x 4 per thread); at the k of BASELINE.json's fp64
-// configuration the down-date is HBM-bound.
+// fp64: the same triangular scheme on v_mfma_f64_16x16x4_f64 (64 x 64 tiles); at the k of
+// BASELINE.json's fp64 configuration the down-date is HBM-bound.
 #include <algorithm>
 
 #include "common.h"
@@ -363,16 +362,22 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
     }
 }
 
-// ---- fp64 VALU down-date -----------------------------------------------------
+// ---- fp64 down-date on the fp64 matrix cores ------------------------------------------
+// 64 x 64 tile per 256-thread workgroup, wave (wr, wc) owns rows 32 wr.., columns 32 wc.. as 2 x 2 blocks of
+// v_mfma_f64_16x16x4_f64 (exact fp64 FMAs).  Orientation as in the fp32 kernel: D[i][j] with i = COLUMN of P and
+// j = ROW of P, so the 16 lanes of a quarter-wave hold 16 consecutive rows of one column = one 128-byte line.
+// The P tile is requested before the k-loop; at the k of BASELINE.json's fp64 configuration (Joseph form, k_total =
+// 64) a tile needs 2 us of matrix-core time against 13 us of its HBM share, so several resident workgroups per CU
+// are all the overlap this kernel needs.  (The VALU version this replaces was LDS-bound: 12.5 TFLOP/s, 1.7 TB/s.)
 constexpr int DT = 64;     // tile edge
 constexpr int DK = 16;     // k-chunk
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-template <typename T>
-__global__ __launch_bounds__(256) void downdate_valu(T* __restrict__ P, int ld, int n, const T* __restrict__ X,
-                                                     const T* __restrict__ Y, int pitch, int kp,
-                                                     const int2* __restrict__ tiles, int L,
-                                                     const int32_t* __restrict__ status,
-                                                     const int32_t* __restrict__ dcount, int joseph) {
+__global__ __launch_bounds__(256) void downdate_f64_mfma(double* __restrict__ P, int ld, int n, const double* __restrict__ X,
+                                                         const double* __restrict__ Y, int pitch, int kp,
+                                                         const int2* __restrict__ tiles, int L,
+                                                         const int32_t* __restrict__ status,
+                                                         const int32_t* __restrict__ dcount, int joseph) {
     if (status[0] != 0) return;
     if (dcount) {                     // observe(): the host's kp is an upper bound
         const int k = 2 * dcount[0];
@@ -381,20 +386,29 @@ __global__ __launch_bounds__(256) void downdate_valu(T* __restrict__ P, int ld, 
     }
     const int2 tile = tiles[(size_t)(blockIdx.x & 7) * L + (blockIdx.x >> 3)];     // workgroup b -> list b % 8, slot b / 8
     if (tile.x < 0) return;
-    __shared__ T sX[DT][DK + 1];
-    __shared__ T sY[DT][DK + 1];
-    __shared__ T sT[DT][DT + 1];
+    __shared__ double sX[DT][DK + 1];
+    __shared__ double sY[DT][DK + 1];
+    __shared__ double sT[DT][DT + 1];
     const int tid = threadIdx.x;
-    const int tx = tid & 15;          // rows  tx + 16u
-    const int ty = tid >> 4;          // cols  ty + 16v
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    const int wr = wave & 1, wc = wave >> 1;
     const int R0 = tile.x * DT;
     const int C0 = tile.y * DT;
     const bool diag = tile.x == tile.y;
-    T acc[4][4];
+    // P tile -> registers (rows/columns >= n are padding inside the allocation: P is allocated in whole tiles)
+    f64x4 pold[2][2], acc[2][2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[u][v] = (T)0;
+        for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = C0 + 32 * wc + 16 * cb + 4 * r + kk, row = R0 + 32 * wr + 16 * rb + li;
+                pold[cb][rb][r] = P[(size_t)col * ld + row];
+                acc[cb][rb][r] = 0.0;
+            }
+        }
     for (int kc = 0; kc < kp; kc += DK) {
         // 64 x 16 elements per panel, 4 per thread, coalesced along k
 #pragma unroll
@@ -407,39 +421,37 @@ __global__ __launch_bounds__(256) void downdate_valu(T* __restrict__ P, int ld, 
         }
         __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < DK; ++kk) {
-            T xr[4], yc[4];
+        for (int s = 0; s < 4; ++s) {
+            double ay[2], bx[2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) xr[u] = sX[tx + 16 * u][kk];
+            for (int cb = 0; cb < 2; ++cb) ay[cb] = sY[32 * wc + 16 * cb + li][4 * s + kk];     // A[i = column][k]
 #pragma unroll
-            for (int v = 0; v < 4; ++v) yc[v] = sY[ty + 16 * v][kk];
+            for (int rb = 0; rb < 2; ++rb) bx[rb] = sX[32 * wr + 16 * rb + li][4 * s + kk];     // B[k][j = row]
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) acc[u][v] += xr[u] * yc[v];
+                for (int rb = 0; rb < 2; ++rb)
+                    acc[cb][rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ay[cb], bx[rb], acc[cb][rb], 0, 0, 0);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const int cl = ty + 16 * v;
-        const int col = C0 + cl;
+    for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int rl = tx + 16 * u;
-            const int row = R0 + rl;
-            T val = (T)0;
-            if (row < n && col < n) {
-                T* p = P + (size_t)col * ld + row;
-                val = *p - acc[u][v];
-                if (!diag || row >= col) *p = val;
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cl = 32 * wc + 16 * cb + 4 * r + kk, rl = 32 * wr + 16 * rb + li;
+                const int col = C0 + cl, row = R0 + rl;
+                const double val = pold[cb][rb][r] - acc[cb][rb][r];
+                if (!diag || row >= col) P[(size_t)col * ld + row] = val;
+                if (diag) sT[rl][cl] = val;
             }
-            sT[rl][cl] = val;
-        }
-    }
-    __syncthreads();
     if (!diag) return;          // tiles above the diagonal are not maintained (see the header comment)
-    // in-tile mirror: thread (tx, ty) stores element (row = ty+16v, col = tx+16u) to P[col, row]; col on tx
+    __syncthreads();
+    // in-tile mirror: element (row = rl, col = cl) of the lower triangle goes to P[row = cl', col = rl'] ...
+    // thread (tx, ty) stores the value of element (ty + 16v, tx + 16u) at its mirror position; tx runs along rows
+    const int tx = tid & 15, ty = tid >> 4;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const int rl = ty + 16 * v;
@@ -448,9 +460,10 @@ __global__ __launch_bounds__(256) void downdate_valu(T* __restrict__ P, int ld, 
         for (int u = 0; u < 4; ++u) {
             const int cl = tx + 16 * u;
             const int colJ = C0 + cl;
-            if (rowI < n && colJ < n && rowI > colJ) P[(size_t)rowI * ld + colJ] = sT[rl][cl];
+            if (rowI > colJ) P[(size_t)rowI * ld + colJ] = sT[rl][cl];
         }
     }
+    (void)n;
 }
 
 // Tile lists: eight lists of equal length L (padded with -1), laid out [xcd][slot].  XCD x
@@ -532,7 +545,7 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
                                (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
                                h->d_status, 0, (unsigned long long*)nullptr, dcount, joseph);
     } else {
-        hipLaunchKernelGGL(downdate_valu<double>, dim3(8 * h->tiles_len), dim3(256), 0, h->stream, (double*)h->P, h->ld, n,
+        hipLaunchKernelGGL(downdate_f64_mfma, dim3(8 * h->tiles_len), dim3(256), 0, h->stream, (double*)h->P, h->ld, n,
                            (const double*)X, (const double*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
                            h->d_status, dcount, joseph);
     }
