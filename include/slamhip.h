@@ -142,6 +142,14 @@ int slam_ekf_augment(slam_ekf_t h, const double* zn, int nn, const double R[4]);
 int slam_ekf_observe(slam_ekf_t h, const double* z, int nz, const double R[4],
                      double gate1, double gate2, int form, int32_t* assoc);
 
+/* Telemetry without downloading P: feature_ellipses(x, cov) (sim/browser/wsserver.jl:72-85) into
+ * `features` (5 x N column-major: cx, cy, rx, ry, phi; may be NULL) and the vehicle-position ellipse of
+ * monitor() (:60-65) into `vehicle` = {cx, cy, vehicle_phi, rx, ry, phi} (may be NULL).  rx <= ry are the
+ * square roots of the ascending eigenvalues of the 2 x 2 block, phi the direction of the FIRST eigenvector
+ * with its sign fixed so that phi lies in [-pi/2, pi/2] (LAPACK's sign in the reference is arbitrary).
+ * Synchronises. */
+int slam_ekf_ellipses(slam_ekf_t h, double* features, double vehicle[6]);
+
 /* ---- stream / timing -------------------------------------------------------- */
 
 int slam_ekf_set_async(slam_ekf_t h, int async_updates);

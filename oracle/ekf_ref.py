@@ -470,3 +470,25 @@ class OracleEKF:
 
     def pose(self):
         return self.x[0:3].copy()
+
+
+# ---- telemetry (sim/browser/wsserver.jl:60-65,72-85) -----------------------------------------------
+
+def feature_ellipses(x, cov):
+    """``feature_ellipses`` (sim/browser/wsserver.jl:72-85): per landmark ``[x_j; sqrt(l); atan2(u[2,1], u[1,1])]``
+    with ``l, u = eig(cov[j, j])`` (ascending eigenvalues, LAPACK eigenvectors -- their sign is arbitrary, so phi
+    is defined modulo pi)."""
+    nf = (len(x) - 3) // 2
+    out = np.empty((5, nf))
+    for i in range(nf):
+        j = slice(3 + 2 * i, 5 + 2 * i)
+        l, u = np.linalg.eigh(np.asarray(cov, dtype=np.float64)[j, j])
+        out[:, i] = [x[3 + 2 * i], x[4 + 2 * i], math.sqrt(max(l[0], 0.0)), math.sqrt(max(l[1], 0.0)),
+                     math.atan2(u[1, 0], u[0, 0])]
+    return out
+
+
+def vehicle_ellipse(x, cov):
+    """The ``vehicle-ellipse`` record of ``monitor`` (sim/browser/wsserver.jl:60-65)."""
+    l, u = np.linalg.eigh(np.asarray(cov, dtype=np.float64)[0:2, 0:2])
+    return np.array([x[0], x[1], x[2], math.sqrt(max(l[0], 0.0)), math.sqrt(max(l[1], 0.0)), math.atan2(u[1, 0], u[0, 0])])

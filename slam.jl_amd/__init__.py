@@ -5,13 +5,14 @@ The directory name is not a Python identifier; load it with
 
 Contents: ``csrc/`` (HIP kernels + C ABI -> ``libslamhip.so``), ``_lib`` (ctypes
 binding), ``ekf`` (host mirror of src/SLAM.jl's exports), ``sim`` (headless
-``sim!`` driver), ``SLAMHip.jl`` (the Julia 1.x binding).  Importing this package
+``sim!`` driver), ``telemetry`` (the browser monitor's message schema), ``SLAMHip.jl`` (the Julia 1.x binding).  Importing this package
 fails loudly if the HIP library has not been built: there is no CPU fallback.
 """
 from . import _lib  # noqa: F401  (raises ImportError when libslamhip.so is missing)
 from ._lib import NotPositiveDefinite, SlamHipError, device_count  # noqa: F401
 from .ekf import (DeviceRef, EKFSlamState, SlamState, add_features, associate, augment_,  # noqa: F401
                   compute_association, ekf_predict_, ekf_update_, mpi_to_pi, predict, predict_observation,
-                  update)
+                  observe, update)
 from .pf import FastSLAM, PFShard, PFSlamState, TorchComm, philox_uniform  # noqa: F401
 from . import sim  # noqa: F401
+from . import telemetry  # noqa: F401

@@ -83,6 +83,7 @@ SIGNATURES = {
     "slam_ekf_predict_observation": (C.c_int, [_h, C.c_int, _dp, _dp, _dp]),
     "slam_ekf_update": (C.c_int, [_h, _dp, _ip, C.c_int, _dp, C.c_int]),
     "slam_ekf_augment": (C.c_int, [_h, _dp, C.c_int, _dp]),
+    "slam_ekf_ellipses": (C.c_int, [_h, _dp, _dp]),
     "slam_ekf_observe": (C.c_int, [_h, _dp, C.c_int, _dp, C.c_double, C.c_double, C.c_int, _ip]),
     "slam_ekf_set_async": (C.c_int, [_h, C.c_int]),
     "slam_ekf_sync": (C.c_int, [_h]),

@@ -127,6 +127,7 @@ struct KTimer {
 };
 
 // ---- kernel launchers (one per .hip file) -----------------------------------
+int launch_ellipses(slam_ekf* h, double* d_out);     // [N + 1][5]: vehicle, then the landmarks
 int launch_mirror(slam_ekf* h);     // make the tiles above the diagonal valid (before a download)
 int launch_predict(slam_ekf* h, double v, double g, double w, const double Q[4], double dt);
 int launch_augment(slam_ekf* h, int nn, const double R[4], const double* zn_dev);   // zn already on the device (obsbuf or znbuf)

@@ -320,6 +320,36 @@ extern "C" int slam_ekf_get_pose(slam_ekf_t h, double pose[3]) {
     return SLAM_OK;
 }
 
+/* feature_ellipses(x, cov) and the vehicle ellipse of monitor()  (sim/browser/wsserver.jl:60-65,72-85). */
+extern "C" int slam_ekf_ellipses(slam_ekf_t h, double* features, double vehicle[6]) {
+    ARG_CHECK(h != nullptr, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t cnt = (size_t)h->N + 1;
+    double* d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_out, sizeof(double) * 5 * cnt));
+    std::vector<double> host(5 * cnt);
+    int rc = launch_ellipses(h, d_out);
+    if (rc == SLAM_OK) {
+        const hipError_t e1 = hipMemcpyAsync(host.data(), d_out, sizeof(double) * 5 * cnt, hipMemcpyDeviceToHost, h->stream);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamSynchronize(h->stream) : e1;
+        if (e2 != hipSuccess) {
+            slam_set_error("HIP error in slam_ekf_ellipses: %s", hipGetErrorString(e2));
+            rc = SLAM_E_HIP;
+        }
+    }
+    (void)hipFree(d_out);
+    if (rc) return rc;
+    if (features)
+        for (size_t i = 0; i < 5 * (cnt - 1); ++i) features[i] = host[5 + i];
+    if (vehicle) {
+        double pose[3];
+        if ((rc = slam_ekf_get_pose(h, pose))) return rc;
+        vehicle[0] = pose[0]; vehicle[1] = pose[1]; vehicle[2] = pose[2];      // cx, cy, vehicle_phi
+        vehicle[3] = host[2]; vehicle[4] = host[3]; vehicle[5] = host[4];      // rx, ry, phi
+    }
+    return SLAM_OK;
+}
+
 extern "C" int slam_ekf_num_landmarks(slam_ekf_t h, int* N) {
     ARG_CHECK(h != nullptr && N != nullptr, "null argument");
     *N = h->N;

@@ -175,7 +175,50 @@ __global__ __launch_bounds__(256) void mirror_kernel(T* __restrict__ P, int ld, 
     }
 }
 
+// Telemetry (sim/browser/wsserver.jl:60-65,72-85): the covariance ellipse of the vehicle position (index 0) and of
+// every landmark j >= 1 straight from the 2 x 2 diagonal blocks -- 5 values per landmark instead of shipping P.
+//   l, u = eig(P_jj) (ascending);  out = [cx, cy, sqrt(l1), sqrt(l2), atan2(u[2,1], u[1,1])]
+// The sign of an eigenvector is arbitrary (LAPACK's choice in the reference); here u[1,1] >= 0, so phi lies in
+// [-pi/2, pi/2] -- the same ellipse.  Closed form for the symmetric 2 x 2 block, in double.
+template <typename T>
+__global__ __launch_bounds__(256) void ellipse_kernel(const T* __restrict__ x, const T* __restrict__ P, int ld, int N,
+                                                       double* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;          // 0: vehicle, 1..N: landmarks
+    if (j > N) return;
+    const int f = j == 0 ? 0 : 3 + 2 * (j - 1);
+    const double a = (double)P[(size_t)f * ld + f], b = (double)P[(size_t)f * ld + f + 1],
+                 d = (double)P[(size_t)(f + 1) * ld + f + 1];
+    const double tr = a + d, df = a - d;
+    const double disc = sqrt(df * df + 4.0 * b * b);
+    const double l2 = 0.5 * (tr + disc);
+    const double l1 = l2 > 0.0 ? (a * d - b * b) / l2 : 0.5 * (tr - disc);       // det / l2: no cancellation
+    // eigenvector of l1: (b, l1 - a) or (l1 - d, b), whichever is longer
+    double u0 = b, u1 = l1 - a;
+    const double w0 = l1 - d, w1 = b;
+    if (w0 * w0 + w1 * w1 > u0 * u0 + u1 * u1) { u0 = w0; u1 = w1; }
+    if (u0 == 0.0 && u1 == 0.0) { u0 = a <= d ? 1.0 : 0.0; u1 = a <= d ? 0.0 : 1.0; }     // isotropic / diagonal block
+    if (u0 < 0.0 || (u0 == 0.0 && u1 < 0.0)) { u0 = -u0; u1 = -u1; }
+    double* o = out + (size_t)5 * j;
+    o[0] = (double)x[f];
+    o[1] = (double)x[f + 1];
+    o[2] = sqrt(l1 > 0.0 ? l1 : 0.0);
+    o[3] = sqrt(l2 > 0.0 ? l2 : 0.0);
+    o[4] = atan2(u1, u0);
+}
+
 }  // namespace
+
+int launch_ellipses(slam_ekf* h, double* d_out) {
+    const int cnt = h->N + 1;
+    if (h->dtype == SLAM_F32)
+        hipLaunchKernelGGL(ellipse_kernel<float>, dim3((cnt + 255) / 256), dim3(256), 0, h->stream, (const float*)h->x,
+                           (const float*)h->P, h->ld, h->N, d_out);
+    else
+        hipLaunchKernelGGL(ellipse_kernel<double>, dim3((cnt + 255) / 256), dim3(256), 0, h->stream, (const double*)h->x,
+                           (const double*)h->P, h->ld, h->N, d_out);
+    HIP_TRY(hipGetLastError());
+    return SLAM_OK;
+}
 
 int launch_mirror(slam_ekf* h) {
     const int n = 3 + 2 * h->N;

@@ -240,6 +240,20 @@ class EKFSlamState(SlamState):
         check(lib.slam_ekf_get_pose(self._h, _ptr(out)))
         return out
 
+    def feature_ellipses(self):
+        """feature_ellipses(x, cov) (sim/browser/wsserver.jl:72-85): 5 x N array [cx; cy; rx; ry; phi], computed
+        on the device from the 2 x 2 diagonal blocks -- P is not downloaded."""
+        N = self.N
+        out = np.empty((5, N), dtype=np.float64, order="F")
+        check(lib.slam_ekf_ellipses(self._h, _ptr(out) if N else None, None))
+        return out
+
+    def vehicle_ellipse(self):
+        """[cx, cy, vehicle_phi, rx, ry, phi] of monitor() (sim/browser/wsserver.jl:60-65)."""
+        out = np.empty(6)
+        check(lib.slam_ekf_ellipses(self._h, None, _ptr(out)))
+        return out
+
     # -- in-place operations (ekf_predict!, ekf_update!, augment!) ---------------------
     def predict(self, v, g, wheelbase, Q, dt):
         q = _small(Q)

@@ -101,3 +101,24 @@ def test_sim_driver_pieces(pkg, golden_dir):
     lms = np.array([[60.0, 40.0, 50.0, 79.9, 80.1], [50.0, 50.0, 70.0, 50.0, 50.0]])
     z, tags = S.get_observations(veh, lms, np.zeros((2, 2)), np.random.default_rng(1))
     assert tags.tolist() == [1, 4] and z[0].tolist() == pytest.approx([10.0, 29.9])
+
+
+def test_telemetry_host_helpers():
+    """Row N3, host side (no GPU): laser_lines / local_to_global / dict_array restate src/common.jl:118-132,269-283
+    and sim/browser/wsserver.jl:120-131; checked against hand-computed values."""
+    import importlib.util
+    import json
+    import math
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "slam_telemetry_only", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "slam.jl_amd", "telemetry.py"))
+    T = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(T)
+    import numpy as np
+    pose = [1.0, 2.0, math.pi / 2]
+    lines = T.laser_lines(np.array([[10.0, 5.0], [0.0, math.pi / 2]]), pose)
+    assert np.allclose(lines, [[1.0, 1.0], [2.0, 2.0], [1.0, -4.0], [12.0, 2.0]], atol=1e-12)
+    d = T.dict_array(np.array([[10, 5, 8], [5, 3, 6]]), ["a", "b"])
+    assert d == [{"a": 10.0, "b": 5.0}, {"a": 5.0, "b": 3.0}, {"a": 8.0, "b": 6.0}]      # the docstring example of the reference
+    m = T.message("tracks", {"x": 1}, timestamp=3.0)
+    assert json.loads(T.to_json(m)) == {"type": "tracks", "data": {"x": 1}, "timestamp": 3.0}

@@ -524,3 +524,45 @@ def test_full_size_10k_landmarks_fp32(pkg):
     assert np.array_equal(Pg, Pg.T)
     assert float(np.trace(Pg.astype(np.float64))) < tr0
     st.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_telemetry_ellipses_and_monitor_schema(pkg, dtype):
+    """Row N3: feature / vehicle ellipses computed on the device from the 2 x 2 blocks (no download of P) against
+    the oracle's restatement of feature_ellipses (sim/browser/wsserver.jl:72-85); the eigenvector sign is
+    LAPACK's choice in the reference, so phi is compared modulo pi.  Then the message schema of monitor()."""
+    rng = np.random.default_rng(21)
+    x, P = random_state(rng, 300)
+    # a few special blocks: isotropic, diagonal with a > d, and strongly correlated
+    P[3:5, 3:5] = [[0.25, 0.0], [0.0, 0.25]]
+    P[5:7, 5:7] = [[0.9, 0.0], [0.0, 0.1]]
+    P[7:9, 7:9] = [[1.0, 0.999], [0.999, 1.0]]
+    st = pkg.EKFSlamState(x, P, dtype=dtype, max_landmarks=320)
+    xo, Po = rounded(st)
+    z = noisy_obs(rng, xo, [4, 9, 77])
+    st.observe(z, R, 4.0, 25.0)                      # ellipses must follow the CURRENT (block-lower) device state
+    xo, Po = rounded(st)
+    E = st.feature_ellipses()
+    Eo = O.feature_ellipses(xo, Po)
+    tol = 1e-9 if dtype == "f64" else 1e-5
+    assert E.shape == Eo.shape == (5, 300)
+    assert np.allclose(E[:4], Eo[:4], rtol=tol, atol=tol)
+    assert np.all(E[2] <= E[3] + 1e-15) and np.all(np.abs(E[4]) <= math.pi / 2 + 1e-12)
+    aniso = (Eo[3] - Eo[2]) > 1e-3 * Eo[3]            # the direction is undefined for an isotropic block
+    dphi = np.abs(np.angle(np.exp(2j * (E[4] - Eo[4])))) / 2          # difference modulo pi
+    assert np.all(dphi[aniso] < (1e-7 if dtype == "f64" else 2e-3))
+    V = st.vehicle_ellipse()
+    Vo = O.vehicle_ellipse(xo, Po)
+    assert np.allclose(V[:5], Vo[:5], rtol=tol, atol=tol)
+    msgs = pkg.telemetry.monitor_messages(st, [1.0, 2.0, 0.1], st.pose(), z=z, state_updated=True, timestamp=0.0)
+    assert [m["type"] for m in msgs] == ["tracks", "state", "lidar", "feature-ellipses", "vehicle-ellipse"]
+    assert set(msgs[0]["data"]) == {"ideal", "slam"} and set(msgs[0]["data"]["slam"]) == {"x", "y", "phi"}
+    assert "cov" not in msgs[1]["data"] and len(msgs[1]["data"]["pose"]) == 3
+    assert len(msgs[2]["data"]) == 3 and set(msgs[2]["data"][0]) == {"x1", "y1", "x2", "y2"}
+    assert len(msgs[3]["data"]) == 300 and set(msgs[3]["data"][0]) == {"cx", "cy", "rx", "ry", "phi"}
+    assert set(msgs[4]["data"][0]) == {"cx", "cy", "vehicle_phi", "rx", "ry", "phi"}
+    for m in msgs:
+        pkg.telemetry.to_json(m)
+    quiet = pkg.telemetry.monitor_messages(st, [1.0, 2.0, 0.1], st.pose(), timestamp=0.0)
+    assert [m["type"] for m in quiet] == ["tracks", "state", "vehicle-ellipse"]      # no update: no lidar, no ellipses
+    st.close()
