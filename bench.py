@@ -153,7 +153,7 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
     pf.shard.init_landmarks(lm, 0.01, 0.1)
     pose = np.array([0.0, 0.0, 0.3])
     obs = []
-    for t in range(2 * (steps + warmup)):
+    for t in range(3 * (steps + warmup)):
         pose = np.array([pose[0] + 0.2 * math.cos(pose[2]), pose[1] + 0.2 * math.sin(pose[2]), pose[2]])
         ids = (np.arange(M) + M * t) % NL + 1
         dx, dy = lm[ids - 1, 0] - pose[0], lm[ids - 1, 1] - pose[1]
@@ -161,7 +161,7 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
         obs.append((z, ids))
     res = {}
     it = iter(obs)
-    for regime, force in (("no_resample", False), ("neff_triggered", None)):
+    for regime, force in (("no_resample", False), ("every_step", True), ("neff_triggered", None)):
         for _ in range(warmup):
             z, ids = next(it)
             pf.step(8.0, 0.0, 4.0, Q, 0.025, z, ids, R, force_resample=force)

@@ -83,7 +83,9 @@ struct slam_ekf {
     int32_t* h_assoc_dev;
     double* znbuf;    // [2*ocap] observe(): the new-feature observations, compacted on the device
     int32_t* d_count; // [4]      observe(): {matched m, new nn}
-    hipEvent_t assoc_ev;   // observe(): the association vector has reached h_assoc
+    int32_t* h_flag;       // pinned: observe() polls it for obs_seq (written by the compaction after the decisions)
+    int32_t* h_flag_dev;
+    int32_t obs_seq;
 
     // down-date tile order (ekf_syrk.hip): workgroup b computes tile tiles[b]
     int2* tiles;

@@ -178,7 +178,7 @@ extern "C" int slam_ekf_destroy(slam_ekf_t h) {
     dev_free(h->x); dev_free(h->P); dev_free(h->tiles);
     dev_free(h->obsbuf); dev_free(h->idfbuf); dev_free(h->d_assoc); dev_free(h->gate_part); dev_free(h->znbuf);
     dev_free(h->d_small); dev_free(h->d_status); dev_free(h->d_count);
-    if (h->assoc_ev) (void)hipEventDestroy(h->assoc_ev);
+    if (h->h_flag) (void)hipHostFree(h->h_flag);
     if (h->h_obs) (void)hipHostFree(h->h_obs);
     if (h->h_idf) (void)hipHostFree(h->h_idf);
     if (h->h_assoc) (void)hipHostFree(h->h_assoc);
@@ -203,7 +203,9 @@ static int create_impl(slam_ekf* h) {
     if ((rc = dev_alloc_zero(&h->P, h->esz * (size_t)h->ld * h->npad, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->d_small, sizeof(double) * 64, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->d_count, sizeof(int32_t) * 4, h->stream))) return rc;
-    HIP_TRY(hipEventCreateWithFlags(&h->assoc_ev, hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc((void**)&h->h_flag, sizeof(int32_t) * 16, hipHostMallocDefault));
+    h->h_flag[0] = 0;
+    HIP_TRY(hipHostGetDevicePointer((void**)&h->h_flag_dev, h->h_flag, 0));
     if ((h->debug_flags & 8) && (rc = dev_alloc_zero(&h->dd_prof, (size_t)4096 * 4 * 4 * 8, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->d_status, sizeof(int32_t) * 4, h->stream))) return rc;
     HIP_TRY(hipHostMalloc((void**)&h->h_small, sizeof(double) * 64, hipHostMallocDefault));
@@ -244,7 +246,7 @@ extern "C" int slam_ekf_create(slam_ekf_t* out, int dtype, int max_landmarks, in
     h->h_obs = nullptr; h->h_idf = nullptr; h->h_assoc = nullptr; h->d_assoc = nullptr;
     h->gate_part = nullptr; h->gate_blocks_cap = 0;
     h->d_small = h->h_small = nullptr;
-    h->znbuf = nullptr; h->d_count = nullptr; h->assoc_ev = nullptr;
+    h->znbuf = nullptr; h->d_count = nullptr; h->h_flag = nullptr; h->h_flag_dev = nullptr; h->obs_seq = 0;
     h->d_status = h->h_status = nullptr;
     h->async_updates = 0; h->deferred = 0; h->pending_status = 0; h->debug_stamps = 0;
     h->debug_flags = getenv("SLAMHIP_DEBUG") ? atoi(getenv("SLAMHIP_DEBUG")) : 0;
@@ -532,10 +534,28 @@ extern "C" int slam_ekf_observe(slam_ekf_t h, const double* z, int nz, const dou
         h->stage_pending = 0;
     }
     memcpy(h->h_obs, z, sizeof(double) * 2 * (size_t)nz);
+    h->obs_seq = h->obs_seq == 0x7fffffff ? 1 : h->obs_seq + 1;
     if ((rc = launch_gate(h, nz, R, gate1, gate2, h->h_obs_dev, true))) return rc;      // gating + compaction
-    HIP_TRY(hipEventRecord(h->assoc_ev, h->stream));       // (also marks the pinned buffers as consumed)
     if ((rc = launch_update(h, nz, R, form, true))) return rc;
-    HIP_TRY(hipEventSynchronize(h->assoc_ev));          // gating only: the update runs on behind it
+    // Wait for the decisions only (the update runs on behind them): the compaction publishes this call's sequence
+    // number in pinned memory after the association vector.  The stream is queried now and then so that a failed
+    // kernel cannot leave the host spinning.
+    {
+        volatile int32_t* flag = h->h_flag;
+        unsigned long long spins = 0;
+        while (*flag != h->obs_seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xfffffull) == 0) {
+                const hipError_t q = hipStreamQuery(h->stream);
+                if (q != hipErrorNotReady && *flag != h->obs_seq) {
+                    if (q == hipSuccess) slam_set_error("observe: the gating finished without publishing its decisions");
+                    else slam_set_error("HIP error while waiting for the gating: %s", hipGetErrorString(q));
+                    return SLAM_E_HIP;
+                }
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
     int nn = 0;
     for (int i = 0; i < nz; ++i) {
         assoc[i] = h->h_assoc[i];

@@ -183,7 +183,8 @@ __global__ __launch_bounds__(GATE_BLOCK * OBS_WAVES) void gate_kernel(const T* _
 __device__ __forceinline__ void compact_wave(const int32_t* assoc, int nz, const double* __restrict__ zsrc,
                                              double* __restrict__ zbuf, int32_t* __restrict__ idf,
                                              double* __restrict__ zn, int32_t* __restrict__ count,
-                                             int32_t* __restrict__ assoc_host, int lane) {
+                                             int32_t* __restrict__ assoc_host, int lane, int32_t* __restrict__ flag_host,
+                                             int32_t seq) {
     int m = 0, nn = 0;
     for (int base = 0; base < nz; base += 64) {
         const int i = base + lane;
@@ -211,6 +212,10 @@ __device__ __forceinline__ void compact_wave(const int32_t* assoc, int nz, const
         count[0] = m;
         count[1] = nn;
     }
+    // the host polls this word in pinned memory instead of waiting on an event (an event record costs ~6 us of
+    // stream time): decisions first, system-scope fence, then the sequence number of this call
+    __threadfence_system();
+    if (lane == 0) __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // One wave per observation folds the per-workgroup partials into assoc[i].  With `compact_total` > 0 (observe(),
@@ -219,7 +224,8 @@ __device__ __forceinline__ void compact_wave(const int32_t* assoc, int nz, const
 __global__ __launch_bounds__(64) void gate_final_kernel(
     const double* __restrict__ part, int nblocks, int nz, int32_t* assoc, int32_t* assoc_all,     // (the two alias)
     int compact_total, const double* __restrict__ zsrc, double* __restrict__ zbuf, int32_t* __restrict__ idf,
-    double* __restrict__ zn, int32_t* __restrict__ count, int32_t* __restrict__ assoc_host, int32_t* arrive) {
+    double* __restrict__ zn, int32_t* __restrict__ count, int32_t* __restrict__ assoc_host, int32_t* arrive,
+    int32_t* __restrict__ flag_host, int32_t seq) {
     const int i = blockIdx.x;
     const int lane = threadIdx.x;
     const double INF = __builtin_inf();
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(64) void gate_final_kernel(
     }
     if (compact_total > 0 && __shfl(last, 0)) {
         __threadfence();
-        compact_wave(assoc_all, compact_total, zsrc, zbuf, idf, zn, count, assoc_host, lane);
+        compact_wave(assoc_all, compact_total, zsrc, zbuf, idf, zn, count, assoc_host, lane, flag_host, seq);
         if (lane == 0) __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed
     }
 }
@@ -313,7 +319,7 @@ int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gat
             const bool last = o + CHUNK >= nz;
             hipLaunchKernelGGL(gate_final_kernel, dim3(cz), dim3(64), 0, h->stream, (const double*)h->gate_part, nblocks, cz,
                                h->d_assoc + o, h->d_assoc, (compact && last) ? nz : 0, z_src, h->obsbuf, h->idfbuf, h->znbuf,
-                               h->d_count, h->h_assoc_dev, h->d_count + 2);
+                               h->d_count, h->h_assoc_dev, h->d_count + 2, h->h_flag_dev, h->obs_seq);
         }
         HIP_TRY(hipGetLastError());
     }
