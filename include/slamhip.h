@@ -201,6 +201,10 @@ int slam_pf_update_known(slam_pf_t h, const double* z, const int32_t* ids, int m
  * and slam_pf_weight_stats in one kernel (same particles bit for bit; out as slam_pf_weight_stats).  Synchronises. */
 int slam_pf_step(slam_pf_t h, double V, double G, double wheelbase, const double Q[4], double dt,
                  const double* z, const int32_t* ids, int m, const double R[4], double out[3]);
+/* slam_pf_step + slam_pf_normalize with the shard's own statistics, for a filter on ONE GPU (n == n_global):
+ * one library call per filter step.  out = {max logw, sum, sum2, Neff}. */
+int slam_pf_step_normalized(slam_pf_t h, double V, double G, double wheelbase, const double Q[4], double dt,
+                            const double* z, const int32_t* ids, int m, const double R[4], double out[4]);
 /* F4, local part: out = {max logw, sum exp(logw - max), sum exp(2 (logw - max))}.  Synchronises. */
 int slam_pf_weight_stats(slam_pf_t h, double out[3]);
 /* logw -= gmax + log(gsum) with the GLOBAL max / sum (after the all-reduce). */

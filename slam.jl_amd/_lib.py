@@ -98,6 +98,8 @@ SIGNATURES = {
     "slam_pf_predict": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, _dp, C.c_double]),
     "slam_pf_update_known": (C.c_int, [_h, _dp, _ip, C.c_int, _dp]),
     "slam_pf_step": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, _dp, C.c_double, _dp, _ip, C.c_int, _dp, _dp]),
+    "slam_pf_step_normalized": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, _dp, C.c_double, _dp, _ip, C.c_int, _dp,
+                                          _dp]),
     "slam_pf_weight_stats": (C.c_int, [_h, _dp]),
     "slam_pf_normalize": (C.c_int, [_h, C.c_double, C.c_double]),
     "slam_pf_copy_logw": (C.c_int, [_h, C.c_void_p]),

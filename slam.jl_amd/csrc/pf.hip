@@ -45,16 +45,18 @@ struct slam_pf {
     void* logw;          // [n]
     int cur;             // which of the two state buffers is live
     std::vector<char> seen;
-    int32_t* d_ids;      // [2][ocap] observation landmark ids (0-based) ; bit 30 marks "new landmark"
-    double* d_obs;       // [2][ocap][2]
-    int32_t* h_ids;      // pinned, [2][ocap]: two staging slots used alternately, each guarded by an event
-    double* h_obs;
+    int32_t* h_ids;      // pinned, [2][ocap]: observation landmark ids (0-based; bit 30 marks "new landmark"); two
+    double* h_obs;       // pinned, [2][ocap][2]   staging slots used alternately, each guarded by an event, read by the kernels
     hipEvent_t stage_ev[2];
-    int stage_used[2], stage_slot;
+    int stage_used[2], stage_slot, stage_last;
+    int32_t* h_ids_dev;  // device-side addresses of the pinned slots
+    double* h_obs_dev;
     int ocap;
     double* d_part;      // [blocks][4] reduction partials
     double* d_out;       // [8]
-    double* h_out;       // pinned [8]
+    double* h_out;       // pinned [8]: seven statistics + the sequence word the host polls
+    double* h_out_dev;   // its device-side address
+    long long out_seq;
     double* d_cdf;       // [n_global]
     double* d_bsum;      // [scan blocks]
     int32_t* d_src;      // [n] gather source: >= 0 local index, < 0: -(recv position + 1)
@@ -194,6 +196,12 @@ __global__ __launch_bounds__(256) void pf_step_kernel(T* __restrict__ pose, T* _
                                                        T wheelbase, T sigV, T sigG, T dt, const double* __restrict__ z,
                                                        const int32_t* __restrict__ ids, int m, T R00, T R10, T R01, T R11,
                                                        double* __restrict__ part) {
+    // the observation list may live in pinned HOST memory (zero-copy staging): one read per workgroup into LDS
+    extern __shared__ double s_obs[];              // [m][2] doubles, then [m] ints
+    int32_t* s_ids = reinterpret_cast<int32_t*>(s_obs + 2 * m);
+    for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) s_obs[i] = z[i];
+    for (int i = threadIdx.x; i < m; i += blockDim.x) s_ids[i] = ids[i];
+    __syncthreads();
     const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = pi < n;
     if (!STATS && !valid) return;
@@ -213,20 +221,20 @@ __global__ __launch_bounds__(256) void pf_step_kernel(T* __restrict__ pose, T* _
     T lw = logw[p];
     LmRow<T> pre = {0, 0, 0, 0, 0};
     bool have = false;
-    if (m > 0 && !(ids[0] & NEW_FLAG)) {
-        pre = load_row<T>(lm + (size_t)(ids[0] & (NEW_FLAG - 1)) * 5 * n + p, n);
+    if (m > 0 && !(s_ids[0] & NEW_FLAG)) {
+        pre = load_row<T>(lm + (size_t)(s_ids[0] & (NEW_FLAG - 1)) * 5 * n + p, n);
         have = true;
     }
     for (int i = 0; i < m; ++i) {
-        const int32_t code = ids[i];
+        const int32_t code = s_ids[i];
         const int l = code & (NEW_FLAG - 1);
-        const T r = (T)z[2 * i], b = (T)z[2 * i + 1];
+        const T r = (T)s_obs[2 * i], b = (T)s_obs[2 * i + 1];
         T* row = lm + (size_t)l * 5 * n + p;
         LmRow<T> cur = pre;
         const bool have_cur = have;
         have = false;
         if (i + 1 < m) {
-            const int32_t nc = ids[i + 1];
+            const int32_t nc = s_ids[i + 1];
             const int nl = nc & (NEW_FLAG - 1);
             if (!(nc & NEW_FLAG) && nl != l) {            // uniform
                 pre = load_row<T>(lm + (size_t)nl * 5 * n + p, n);
@@ -309,7 +317,8 @@ __global__ __launch_bounds__(256) void pf_stats_kernel(const T* __restrict__ log
 // out = {M, sum, sum2, sx, sy, ss, sc} over all blocks: M = max_b m_b, block sums rescaled by exp(m_b - M)
 // (its square for the second moment).  One workgroup.
 __global__ __launch_bounds__(256) void pf_fold_kernel(const double* __restrict__ part, int nblocks, int relative,
-                                                      double* __restrict__ out) {
+                                                      double* __restrict__ out, double* __restrict__ host_out,
+                                                      long long seq) {
     __shared__ double sh[4];
     double m = -__builtin_inf();
     for (int b = threadIdx.x; b < nblocks; b += 256) m = fmax(m, part[(size_t)b * 8]);
@@ -327,6 +336,11 @@ __global__ __launch_bounds__(256) void pf_fold_kernel(const double* __restrict__
     if (threadIdx.x == 0) {
         out[0] = M;
         for (int i = 0; i < 6; ++i) out[1 + i] = acc[i];
+        // the host polls pinned memory for `seq` (no copy kernel, no event, no interrupt-driven wake-up)
+        host_out[0] = M;
+        for (int i = 0; i < 6; ++i) host_out[1 + i] = acc[i];
+        __threadfence_system();
+        __hip_atomic_store(reinterpret_cast<long long*>(host_out + 7), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -508,7 +522,7 @@ extern "C" int slam_pf_destroy(slam_pf_t h) {
         if (h->pose[b]) (void)hipFree(h->pose[b]);
         if (h->lm[b]) (void)hipFree(h->lm[b]);
     }
-    void* devs[] = {h->logw, h->d_ids, h->d_obs, h->d_part, h->d_out, h->d_cdf, h->d_bsum, h->d_src};
+    void* devs[] = {h->logw, h->d_part, h->d_out, h->d_cdf, h->d_bsum, h->d_src};
     for (void* p : devs)
         if (p) (void)hipFree(p);
     if (h->h_ids) (void)hipHostFree(h->h_ids);
@@ -532,8 +546,6 @@ static int pf_create_impl(slam_pf* h) {
     }
     if ((rc = pf_alloc(&h->logw, h->esz * n, h->stream))) return rc;
     h->ocap = 1024;
-    if ((rc = pf_alloc(&h->d_ids, sizeof(int32_t) * 2 * h->ocap, h->stream))) return rc;
-    if ((rc = pf_alloc(&h->d_obs, sizeof(double) * 4 * h->ocap, h->stream))) return rc;
     h->red_blocks = grid_for(h->n);                  // one partial record per 256 particles
     if ((rc = pf_alloc(&h->d_part, sizeof(double) * 8 * h->red_blocks, h->stream))) return rc;
     if ((rc = pf_alloc(&h->d_out, sizeof(double) * 8, h->stream))) return rc;
@@ -544,7 +556,12 @@ static int pf_create_impl(slam_pf* h) {
     HIP_TRY(hipHostMalloc((void**)&h->h_ids, sizeof(int32_t) * 2 * h->ocap, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&h->h_obs, sizeof(double) * 4 * h->ocap, hipHostMallocDefault));
     for (int b = 0; b < 2; ++b) HIP_TRY(hipEventCreateWithFlags(&h->stage_ev[b], hipEventDisableTiming));
+    HIP_TRY(hipHostGetDevicePointer((void**)&h->h_ids_dev, h->h_ids, 0));
+    HIP_TRY(hipHostGetDevicePointer((void**)&h->h_obs_dev, h->h_obs, 0));
     HIP_TRY(hipHostMalloc((void**)&h->h_out, sizeof(double) * 8, hipHostMallocDefault));
+    memset(h->h_out, 0, sizeof(double) * 8);
+    HIP_TRY(hipHostGetDevicePointer((void**)&h->h_out_dev, h->h_out, 0));
+    h->out_seq = 0;
     // uniform weights over the GLOBAL particle set
     const double lw = -log((double)h->n_global);
     PF_DISPATCH(h,
@@ -577,7 +594,7 @@ extern "C" int slam_pf_create(slam_pf_t* out, int dtype, int64_t n_local, int64_
     h->n = n_local; h->n_global = n_global; h->first = first_id; h->nl = max_landmarks;
     h->seed = seed; h->step = 0; h->cur = 0; h->stream = nullptr;
     h->pose[0] = h->pose[1] = h->lm[0] = h->lm[1] = h->logw = nullptr;
-    h->d_ids = nullptr; h->d_obs = nullptr; h->h_ids = nullptr; h->h_obs = nullptr; h->ocap = 0;
+    h->h_ids = nullptr; h->h_obs = nullptr; h->ocap = 0;
     h->stage_ev[0] = h->stage_ev[1] = nullptr; h->stage_used[0] = h->stage_used[1] = 0; h->stage_slot = 0;
     h->d_part = h->d_out = h->h_out = h->d_cdf = h->d_bsum = nullptr; h->d_src = nullptr;
     h->seen.assign(max_landmarks, 0);
@@ -650,14 +667,17 @@ static int pf_stage(slam_pf* h, const double* z, const int32_t* ids, int m, cons
         hz[2 * i] = z[2 * i];
         hz[2 * i + 1] = z[2 * i + 1];
     }
-    int32_t* di = h->d_ids + (size_t)slot * h->ocap;
-    double* dz = h->d_obs + (size_t)slot * 2 * h->ocap;
-    HIP_TRY(hipMemcpyAsync(di, hi, sizeof(int32_t) * m, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(dz, hz, sizeof(double) * 2 * m, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipEventRecord(h->stage_ev[slot], h->stream));
-    h->stage_used[slot] = 1;
-    *d_z = dz;
-    *d_i = di;
+    // zero-copy: the kernel reads the pinned slot itself (once per workgroup, into LDS); the caller records the
+    // slot's event behind that kernel (pf_stage_done)
+    *d_z = h->h_obs_dev + (size_t)slot * 2 * h->ocap;
+    *d_i = h->h_ids_dev + (size_t)slot * h->ocap;
+    h->stage_last = slot;
+    return SLAM_OK;
+}
+
+static int pf_stage_done(slam_pf* h) {
+    HIP_TRY(hipEventRecord(h->stage_ev[h->stage_last], h->stream));
+    h->stage_used[h->stage_last] = 1;
     return SLAM_OK;
 }
 
@@ -679,23 +699,35 @@ extern "C" int slam_pf_update_known(slam_pf_t h, const double* z, const int32_t*
     const int32_t* di;
     if ((rc = pf_stage(h, z, ids, m, &dz, &di))) return rc;
     PF_DISPATCH(h,
-                hipLaunchKernelGGL((pf_step_kernel<T, false, false>), dim3(grid_for(h->n)), dim3(256), 0, h->stream,
+                hipLaunchKernelGGL((pf_step_kernel<T, false, false>), dim3(grid_for(h->n)), dim3(256), (size_t)m * 20, h->stream,
                                    (T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->first, 0u, h->seed, (T)0, (T)0,
                                    (T)1, (T)0, (T)0, (T)0, dz, di, m, (T)R[0], (T)R[1], (T)R[2], (T)R[3], (double*)nullptr),
-                hipLaunchKernelGGL((pf_step_kernel<T, false, false>), dim3(grid_for(h->n)), dim3(256), 0, h->stream,
+                hipLaunchKernelGGL((pf_step_kernel<T, false, false>), dim3(grid_for(h->n)), dim3(256), (size_t)m * 20, h->stream,
                                    (T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->first, 0u, h->seed, (T)0, (T)0,
                                    (T)1, (T)0, (T)0, (T)0, dz, di, m, (T)R[0], (T)R[1], (T)R[2], (T)R[3], (double*)nullptr));
     HIP_TRY(hipGetLastError());
-    return SLAM_OK;
+    return pf_stage_done(h);
 }
 
 // fold the per-block partials in d_part and bring the seven numbers to the host
 static int pf_fold_and_read(slam_pf* h, int relative_to_max, double out[7]) {
+    h->out_seq += 1;
     hipLaunchKernelGGL(pf_fold_kernel, dim3(1), dim3(256), 0, h->stream, (const double*)h->d_part, h->red_blocks,
-                       relative_to_max, h->d_out);
+                       relative_to_max, h->d_out, h->h_out_dev, h->out_seq);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h->h_out, h->d_out, sizeof(double) * 7, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    volatile long long* flag = reinterpret_cast<volatile long long*>(h->h_out + 7);
+    unsigned long long spins = 0;
+    while (*flag != h->out_seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xfffffull) == 0) {            // a failed kernel must not leave the host spinning
+            const hipError_t q = hipStreamQuery(h->stream);
+            if (q != hipErrorNotReady && *flag != h->out_seq) {
+                slam_set_error("particle statistics were not published: %s", q == hipSuccess ? "kernel finished" : hipGetErrorString(q));
+                return SLAM_E_HIP;
+            }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
     for (int i = 0; i < 7; ++i) out[i] = h->h_out[i];
     return SLAM_OK;
 }
@@ -711,24 +743,38 @@ extern "C" int slam_pf_step(slam_pf_t h, double V, double G, double wheelbase, c
     if (rc) return rc;
     if (m) for (int i = 0; i < 4; ++i) Rz[i] = R[i];
     HIP_TRY(hipSetDevice(h->device));
-    const double* dz = h->d_obs;
-    const int32_t* di = h->d_ids;
+    const double* dz = h->h_obs_dev;
+    const int32_t* di = h->h_ids_dev;
     if (m && (rc = pf_stage(h, z, ids, m, &dz, &di))) return rc;
     const double sV = sqrt(Q[0]), sG = sqrt(Q[3]);
     PF_DISPATCH(h,
-                hipLaunchKernelGGL((pf_step_kernel<T, true, true>), dim3(grid_for(h->n)), dim3(256), 0, h->stream,
+                hipLaunchKernelGGL((pf_step_kernel<T, true, true>), dim3(grid_for(h->n)), dim3(256), (size_t)m * 20, h->stream,
                                    (T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
                                    (T)G, (T)wheelbase, (T)sV, (T)sG, (T)dt, dz, di, m, (T)Rz[0], (T)Rz[1], (T)Rz[2], (T)Rz[3],
                                    h->d_part),
-                hipLaunchKernelGGL((pf_step_kernel<T, true, true>), dim3(grid_for(h->n)), dim3(256), 0, h->stream,
+                hipLaunchKernelGGL((pf_step_kernel<T, true, true>), dim3(grid_for(h->n)), dim3(256), (size_t)m * 20, h->stream,
                                    (T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
                                    (T)G, (T)wheelbase, (T)sV, (T)sG, (T)dt, dz, di, m, (T)Rz[0], (T)Rz[1], (T)Rz[2], (T)Rz[3],
                                    h->d_part));
     HIP_TRY(hipGetLastError());
+    if (m && (rc = pf_stage_done(h))) return rc;
     h->step += 1;
     double s[7];
     if ((rc = pf_fold_and_read(h, 1, s))) return rc;
     out[0] = s[0]; out[1] = s[1]; out[2] = s[2];
+    return SLAM_OK;
+}
+
+/* slam_pf_step followed by slam_pf_normalize with the shard's OWN statistics, for a filter that lives on one GPU
+ * (n == n_global): one library call per filter step.  out = {max logw, sum, sum2, Neff}. */
+extern "C" int slam_pf_step_normalized(slam_pf_t h, double V, double G, double wheelbase, const double Q[4], double dt,
+                                       const double* z, const int32_t* ids, int m, const double R[4], double out[4]) {
+    ARG_CHECK(h != nullptr && out != nullptr, "null argument");
+    ARG_CHECK(h->n == h->n_global, "slam_pf_step_normalized needs the whole filter on this shard");
+    int rc = slam_pf_step(h, V, G, wheelbase, Q, dt, z, ids, m, R, out);
+    if (rc) return rc;
+    if ((rc = slam_pf_normalize(h, out[0], out[1]))) return rc;
+    out[3] = out[1] * out[1] / out[2];
     return SLAM_OK;
 }
 

@@ -119,6 +119,18 @@ class PFShard:
                                _ptr(idv, C.c_int32), zp.shape[0], _ptr(r), _ptr(out)))
         return float(out[0]), float(out[1]), float(out[2])
 
+    def step_fused_normalized(self, V, G, wheelbase, Q, dt, z, ids, R):
+        """step_fused + normalize with this shard's own statistics (the whole filter lives here): returns Neff."""
+        zp = _obs(z)
+        idv = np.ascontiguousarray(np.asarray(ids, dtype=np.int32).reshape(-1))
+        if idv.shape[0] != zp.shape[0]:
+            raise ValueError("ids and z disagree on the number of observations")
+        q, r = _small(Q), _small(R)
+        out = np.empty(4)
+        check(lib.slam_pf_step_normalized(self._h, float(V), float(G), float(wheelbase), _ptr(q), float(dt), _ptr(zp),
+                                          _ptr(idv, C.c_int32), zp.shape[0], _ptr(r), _ptr(out)))
+        return float(out[3])
+
     def normalize(self, gmax, gsum):
         check(lib.slam_pf_normalize(self._h, float(gmax), float(gsum)))
 
@@ -331,7 +343,10 @@ class FastSLAM:
     def step(self, V, G, wheelbase, Q, dt, z, ids, R, force_resample=None):
         """predict + known-id updates + normalise + (Neff-triggered) resample.  Returns (Neff, resampled?)."""
         fused = getattr(self.shard, "step_fused", None) if self.fused else None
-        if fused is not None:                       # one sweep over the particles instead of five launches
+        local = getattr(self.shard, "step_fused_normalized", None) if (self.fused and self.comm.world == 1) else None
+        if local is not None:                       # the whole filter on one GPU: one library call per step
+            neff = self.last_neff = local(V, G, wheelbase, Q, dt, z, ids, R)
+        elif fused is not None:                     # one sweep over the particles instead of five launches
             neff = self.normalize(fused(V, G, wheelbase, Q, dt, z, ids, R))
         else:
             self.predict(V, G, wheelbase, Q, dt)
