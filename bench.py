@@ -284,7 +284,10 @@ def main():
     for i in range(args.warmup):
         step(zs[i])
     st.sync()
-    st.timing(True, kernels=["syrk"])      # HIP events around the dominant kernel only (a pair costs ~10 us of stream time)
+    # HIP events around the dominant kernel only, and on every TIMING_STRIDE-th step of the timed region only: an
+    # event pair costs ~10 us of stream time (1.5 % of a step); the host toggles it while the GPU is busy with the
+    # previous update, so the toggling itself costs nothing
+    TIMING_STRIDE = 4
     st.timing_reset()
 
     def fence():
@@ -296,8 +299,14 @@ def main():
     fence()
     t0 = time.perf_counter()
     matched = 0
+    matched_timed = 0
     for i in range(args.warmup, total_steps):
-        matched += step(zs[i])
+        timed = (i - args.warmup) % TIMING_STRIDE == 0
+        st.timing(timed, kernels=["syrk"])
+        mi = step(zs[i])
+        matched += mi
+        if timed:
+            matched_timed += mi
     st.sync()
     fence()
     elapsed = time.perf_counter() - t0
@@ -334,7 +343,7 @@ def main():
         esz = 4 if args.dtype == "f32" else 8
         syrk_ms, syrk_n = tim["syrk"]
         syrk_avg_s = (syrk_ms / max(syrk_n, 1)) * 1e-3
-        k_avg = 2.0 * matched / max(syrk_n, 1)                       # actual k = 2m per launch
+        k_avg = 2.0 * matched_timed / max(syrk_n, 1)                 # actual k = 2m per (event-bracketed) launch
         if args.form == "joseph":
             k_avg *= 2.0
         # the down-date updates ONE triangle (the tiles on/below the diagonal), like BLAS syrk:
@@ -352,7 +361,7 @@ def main():
         if args.dtype == "f32":
             roof = {"kernel": "downdate (P -= W1*W1')", "bound": "mfma", "achieved": tflops,
                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_F32_PEAK_TFLOPS,
-                    "traffic": traffic, "avg_launch_ms": syrk_avg_s * 1e3, "launches": syrk_n,
+                    "traffic": traffic, "avg_launch_ms": syrk_avg_s * 1e3, "launches": syrk_n, "launches_note": f"every {TIMING_STRIDE}th step of the timed region is bracketed by HIP events",
                     "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
                     "hbm_achieved_GBps": gbps, "hbm_frac_of_8TBps": gbps / HBM_PEAK_GBPS}
         else:

@@ -59,6 +59,9 @@ struct slam_ekf {
     void* x;          // [ncap]
     void* P;          // [ld * npad] column-major, whole 128 x 128 tiles; rows/cols >= n are zero padding
     hipStream_t stream;
+    hipStream_t stream2;   // update(): the full P*H' panel is formed here while the main stream factors S
+    hipEvent_t ev_fork, ev_join;
+    double* PHtS;          // compact panel [3 + kcap][kcap]: the rows of P*H' the factorisation needs
     hipEvent_t stage_ev;   // marks the last H2D copy out of the pinned staging buffers
     int stage_pending;
 
@@ -124,7 +127,8 @@ struct KTimer {
     slam_ekf* h;
     TimingPair p;
     bool on;
-    KTimer(slam_ekf* h_, int kid);
+    hipStream_t s;
+    KTimer(slam_ekf* h_, int kid, hipStream_t stream = nullptr);    // default: the handle's main stream
     ~KTimer();
 };
 

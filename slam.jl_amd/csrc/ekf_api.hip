@@ -34,24 +34,27 @@ extern "C" int slam_device_count(void) {
 }
 
 // ---- timing ------------------------------------------------------------------
-KTimer::KTimer(slam_ekf* h_, int kid) : h(h_), on(h_->timing == 1 || ((h_->timing >> (kid + 1)) & 1)) {
+KTimer::KTimer(slam_ekf* h_, int kid, hipStream_t stream)
+    : h(h_), on(h_->timing == 1 || ((h_->timing >> (kid + 1)) & 1)), s(stream ? stream : h_->stream) {
     if (!on) return;
     if (!h->free_pairs.empty()) {
         p = h->free_pairs.back();
         h->free_pairs.pop_back();
     } else {
-        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) {
+        // timing only: no system-scope fence (cache write-back + invalidate) when the event fires
+        if (hipEventCreateWithFlags(&p.a, hipEventDisableSystemFence) != hipSuccess ||
+            hipEventCreateWithFlags(&p.b, hipEventDisableSystemFence) != hipSuccess) {
             on = false;
             return;
         }
     }
     p.kid = kid;
-    (void)hipEventRecord(p.a, h->stream);
+    (void)hipEventRecord(p.a, s);
 }
 
 KTimer::~KTimer() {
     if (!on) return;
-    (void)hipEventRecord(p.b, h->stream);
+    (void)hipEventRecord(p.b, s);
     h->pairs.push_back(p);
 }
 
@@ -113,10 +116,10 @@ int ensure_obs_capacity(slam_ekf* h, int nobs) {
 }
 
 static void free_update_workspace(slam_ekf* h) {
-    dev_free(h->PHt); dev_free(h->Kd); dev_free(h->W1); dev_free(h->W2); dev_free(h->Cmat);
+    dev_free(h->PHt); dev_free(h->PHtS); dev_free(h->Kd); dev_free(h->W1); dev_free(h->W2); dev_free(h->Cmat);
     dev_free(h->Smat); dev_free(h->Mwork); dev_free(h->gvec);
     h->W1 = h->W2 = nullptr;
-    h->PHt = h->Kd = h->Cmat = h->Smat = h->Mwork = h->gvec = nullptr;
+    h->PHt = h->PHtS = h->Kd = h->Cmat = h->Smat = h->Mwork = h->gvec = nullptr;
     h->kcap = 0;
 }
 
@@ -138,6 +141,7 @@ int ensure_update_workspace(slam_ekf* h, int m) {
     free_update_workspace(h);
     int rc;
     if ((rc = dev_alloc_zero(&h->PHt, sizeof(double) * (size_t)h->npad * cap, h->stream))) return rc;
+    if ((rc = dev_alloc_zero(&h->PHtS, sizeof(double) * (size_t)(3 + cap) * cap, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->Kd, sizeof(double) * (size_t)h->npad * cap, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->W1, h->esz * (size_t)h->npad * 2 * cap, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->W2, h->esz * (size_t)h->npad * 2 * cap, h->stream))) return rc;
@@ -185,6 +189,9 @@ extern "C" int slam_ekf_destroy(slam_ekf_t h) {
     if (h->h_small) (void)hipHostFree(h->h_small);
     if (h->h_status) (void)hipHostFree(h->h_status);
     if (h->stage_ev) (void)hipEventDestroy(h->stage_ev);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return SLAM_OK;
@@ -195,8 +202,15 @@ static int create_impl(slam_ekf* h) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, h->device));
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&h->stage_ev, hipEventDisableTiming));
+    // the main stream carries the critical chain; the side stream (full P*H' panel) yields to it
+    int prio_lo = 0, prio_hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    HIP_TRY(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
+    HIP_TRY(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
+    // ordering-only events between kernels of this device: no system-scope fence
+    HIP_TRY(hipEventCreateWithFlags(&h->stage_ev, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
     int rc;
     if ((rc = update_kernels_init())) return rc;
     if ((rc = dev_alloc_zero(&h->x, h->esz * (size_t)h->ncap, h->stream))) return rc;
@@ -238,9 +252,10 @@ extern "C" int slam_ekf_create(slam_ekf_t* out, int dtype, int max_landmarks, in
     h->x = h->P = nullptr;
     h->stream = nullptr;
     h->stage_ev = nullptr; h->stage_pending = 0;
+    h->stream2 = nullptr; h->ev_fork = h->ev_join = nullptr; h->PHtS = nullptr;
     h->kcap = 0;
     h->W1 = h->W2 = nullptr;
-    h->PHt = h->Kd = h->Cmat = h->Smat = h->Mwork = h->gvec = nullptr;
+    h->PHt = h->PHtS = h->Kd = h->Cmat = h->Smat = h->Mwork = h->gvec = nullptr;
     h->tiles = nullptr; h->tiles_T = h->tiles_len = h->tiles_cap = 0;
     h->obsbuf = nullptr; h->idfbuf = nullptr; h->ocap = 0;
     h->h_obs = nullptr; h->h_idf = nullptr; h->h_assoc = nullptr; h->d_assoc = nullptr;

@@ -92,6 +92,36 @@ __global__ __launch_bounds__(256) void pht_kernel(const T* __restrict__ x, const
 }
 
 // ---------------------------------------------------------------------------
+// K2c: the COMPACT panel -- the 3 + 2m rows of P*H' the factorisation needs (pose rows, then each observed
+// landmark's two rows), written to rows 0 .. 3+2m-1 of PHtS.  One workgroup per row, one thread per observation:
+// all 2m gathers of a row are in flight at once and the rows are spread over the CUs (a few workgroups gathering
+// 4000 scattered values each are limited by one CU's miss queue).  The full n-row panel is formed meanwhile on
+// the second stream.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(128) void pht_compact_kernel(const T* __restrict__ x, const T* __restrict__ P, int ld, int n,
+                                                           const int32_t* __restrict__ idf, int m, int k, int kp,
+                                                           double* __restrict__ PHtS, int pitch, int tile_log2,
+                                                           const int32_t* __restrict__ dcount) {
+    SLAM_DEVICE_COUNT(dcount, m, k, kp)
+    const int slot = blockIdx.x;
+    if (slot >= 3 + 2 * m) return;
+    const int r = slot < 3 ? slot : 3 + 2 * (idf[(slot - 3) >> 1] - 1) + ((slot - 3) & 1);
+    const double xv = (double)x[0], yv = (double)x[1], phi = (double)x[2];
+    const double p0 = (double)sym_at(P, ld, tile_log2, r, 0), p1 = (double)sym_at(P, ld, tile_log2, r, 1),
+                 p2 = (double)sym_at(P, ld, tile_log2, r, 2);
+    double* out = PHtS + (size_t)slot * pitch;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        const int f = 3 + 2 * (idf[i] - 1);
+        const double q0 = (double)sym_at(P, ld, tile_log2, r, f), q1 = (double)sym_at(P, ld, tile_log2, r, f + 1);
+        const ObsModel om = obs_model(xv, yv, phi, (double)x[f], (double)x[f + 1]);
+        out[2 * i] = om.Hv[0] * p0 + om.Hv[1] * p1 + om.Hv[2] * p2 + om.Hf[0] * q0 + om.Hf[1] * q1;
+        out[2 * i + 1] = om.Hv[3] * p0 + om.Hv[4] * p1 + om.Hv[5] * p2 + om.Hf[2] * q0 + om.Hf[3] * q1;
+    }
+    for (int c = k + threadIdx.x; c < kp; c += blockDim.x) out[c] = 0.0;
+}
+
+// ---------------------------------------------------------------------------
 // K4: one workgroup builds S, factors it and emits C = inv(chol(S)).
 //
 // Factorisation: in-place Gauss-Jordan elimination without pivoting on the SPD
@@ -494,9 +524,9 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int i = grp + t * G;
-                const int f = sf[i < m ? i : 0];
-                q0[t] = PHt[(size_t)f * pht_pitch + b];
-                q1[t] = PHt[(size_t)(f + 1) * pht_pitch + b];
+                const int ii = i < m ? i : 0;               // PHt is the COMPACT panel: rows 3 + 2i, 3 + 2i + 1 belong to observation i
+                q0[t] = PHt[(size_t)(3 + 2 * ii) * pht_pitch + b];
+                q1[t] = PHt[(size_t)(4 + 2 * ii) * pht_pitch + b];
             }
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
@@ -520,10 +550,9 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
         if (a < k && b < k) {
             const int i = a >> 1, ra = a & 1;
             const double* h = hb + 10 * i;
-            const int f = sf[i];
             s = h[3 * ra + 0] * PHt[(size_t)0 * pht_pitch + b] + h[3 * ra + 1] * PHt[(size_t)1 * pht_pitch + b] +
-                h[3 * ra + 2] * PHt[(size_t)2 * pht_pitch + b] + h[6 + 2 * ra + 0] * PHt[(size_t)f * pht_pitch + b] +
-                h[6 + 2 * ra + 1] * PHt[(size_t)(f + 1) * pht_pitch + b];
+                h[3 * ra + 2] * PHt[(size_t)2 * pht_pitch + b] + h[6 + 2 * ra + 0] * PHt[(size_t)(3 + 2 * i) * pht_pitch + b] +
+                h[6 + 2 * ra + 1] * PHt[(size_t)(4 + 2 * i) * pht_pitch + b];
             if ((b >> 1) == i) s += ra ? ((b & 1) ? R3 : R1) : ((b & 1) ? R2 : R0);     // RR block = R (column-major args)
         } else {
             s = (a == b) ? 1.0 : 0.0;
@@ -850,11 +879,25 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form, const int32_t*
     T* W2 = (T*)h->W2;
     const bool joseph = form == SLAM_FORM_JOSEPH;
 
-    {   // K2/K3
-        KTimer t(h, SLAM_K_PHT);
+    // K2/K3.  The factorisation is ONE workgroup and needs only 3 + 2m rows of P*H': those are formed first, on the
+    // main stream (compact panel PHtS); the full n-row panel -- which only W1 = PHt*C and x += PHt*g consume -- is formed
+    // meanwhile on the second stream, on the 255 CUs the factorisation leaves idle.
+    const int tlog = h->dtype == SLAM_F32 ? 7 : 6;
+    HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
+    HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+    {
+        KTimer t(h, SLAM_K_PHT, h->stream2);
         const dim3 grid((n + 255) / 256, kp / (2 * PHT_OBS));
-        hipLaunchKernelGGL(pht_kernel<T>, grid, dim3(256), 0, h->stream, x, P, h->ld, n, h->idfbuf, m, k, kp, h->PHt, pitchA,
-                           h->dtype == SLAM_F32 ? 7 : 6, dcount);
+        // (16 KiB of unused dynamic LDS per workgroup keeps these workgroups off the CU that runs the factorisation,
+        //  whose 145 KiB leave less than that free)
+        hipLaunchKernelGGL(pht_kernel<T>, grid, dim3(256), 16384, h->stream2, x, P, h->ld, n, h->idfbuf, m, k, kp, h->PHt,
+                           pitchA, tlog, dcount);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev_join, h->stream2));
+    {
+        hipLaunchKernelGGL(pht_compact_kernel<T>, dim3(3 + 2 * m), dim3(128), 0, h->stream, x, P, h->ld, n, h->idfbuf, m, k, kp,
+                           h->PHtS, pitchA, tlog, dcount);
     }
     HIP_TRY(hipGetLastError());
     {   // K4
@@ -864,15 +907,16 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form, const int32_t*
         const size_t shm = aux + (in_lds ? (size_t)kp * (kp + 1) * sizeof(double) : 0);
         unsigned long long* stamps = h->debug_stamps ? (unsigned long long*)(h->d_small + 40) : (unsigned long long*)nullptr;
         if (in_lds)
-            hipLaunchKernelGGL((factor_kernel<T, true>), dim3(1), dim3(FACTOR_THREADS), shm, h->stream, x, h->PHt, pitchA,
+            hipLaunchKernelGGL((factor_kernel<T, true>), dim3(1), dim3(FACTOR_THREADS), shm, h->stream, x, h->PHtS, pitchA,
                                h->obsbuf, h->idfbuf, m, k, kp, R[0], R[1], R[2], R[3], h->Cmat, pitchA, h->gvec,
                                joseph ? h->Smat : (double*)nullptr, joseph ? 1 : 0, (double*)nullptr, h->d_status, stamps, dcount, h->factor_blocked);
         else
-            hipLaunchKernelGGL((factor_kernel<T, false>), dim3(1), dim3(FACTOR_THREADS), shm, h->stream, x, h->PHt, pitchA,
+            hipLaunchKernelGGL((factor_kernel<T, false>), dim3(1), dim3(FACTOR_THREADS), shm, h->stream, x, h->PHtS, pitchA,
                                h->obsbuf, h->idfbuf, m, k, kp, R[0], R[1], R[2], R[3], h->Cmat, pitchA, h->gvec,
                                joseph ? h->Smat : (double*)nullptr, joseph ? 1 : 0, h->Mwork, h->d_status, stamps, dcount, 0);
     }
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));          // join: the full panel is ready
     const dim3 pg_grid(h->npad / PG_ROWS, (kp + PG_COLS - 1) / PG_COLS);
     int kp_total;
     {   // K5

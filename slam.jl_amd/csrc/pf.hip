@@ -555,7 +555,7 @@ static int pf_create_impl(slam_pf* h) {
     if ((rc = pf_alloc(&h->d_src, sizeof(int32_t) * n, h->stream))) return rc;
     HIP_TRY(hipHostMalloc((void**)&h->h_ids, sizeof(int32_t) * 2 * h->ocap, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&h->h_obs, sizeof(double) * 4 * h->ocap, hipHostMallocDefault));
-    for (int b = 0; b < 2; ++b) HIP_TRY(hipEventCreateWithFlags(&h->stage_ev[b], hipEventDisableTiming));
+    for (int b = 0; b < 2; ++b) HIP_TRY(hipEventCreateWithFlags(&h->stage_ev[b], hipEventDisableTiming | hipEventDisableSystemFence));
     HIP_TRY(hipHostGetDevicePointer((void**)&h->h_ids_dev, h->h_ids, 0));
     HIP_TRY(hipHostGetDevicePointer((void**)&h->h_obs_dev, h->h_obs, 0));
     HIP_TRY(hipHostMalloc((void**)&h->h_out, sizeof(double) * 8, hipHostMallocDefault));
