@@ -512,10 +512,9 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
         // its <= 35 loads of PHt are all issued before the first use.
         const int G = nt / kp;
         const int b = tid % kp, grp = tid / kp;
-        for (int idx = tid; idx < kp * kp; idx += nt) {                 // identity padding first
-            const int a = idx / kp, bb = idx - a * kp;
-            if (a >= k || bb >= k) M[(size_t)a * mp + bb] = (a == bb) ? 1.0 : 0.0;
-        }
+        for (int a = tid >> 5; a < kp; a += nt >> 5)                    // identity padding first
+            for (int bb = tid & 31; bb < kp; bb += 32)
+                if (a >= k || bb >= k) M[(size_t)a * mp + bb] = (a == bb) ? 1.0 : 0.0;
         if (grp < G && b < k) {
             const double p0 = PHt[(size_t)0 * pht_pitch + b];
             const double p1 = PHt[(size_t)1 * pht_pitch + b];
@@ -544,8 +543,8 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
             }
         }
     } else {
-    for (int idx = tid; idx < kp * kp; idx += nt) {
-        const int a = idx / kp, b = idx - a * kp;
+    for (int a = tid >> 5; a < kp; a += nt >> 5)      // 32 consecutive columns per row visit: no integer division
+        for (int b = tid & 31; b < kp; b += 32) {
         double s;
         if (a < k && b < k) {
             const int i = a >> 1, ra = a & 1;
@@ -575,8 +574,8 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
         __syncthreads();
     }
     if (Sout) {
-        for (int idx = tid; idx < kp * kp; idx += nt) {
-            const int a = idx / kp, b = idx - a * kp;
+        for (int a = tid >> 5; a < kp; a += nt >> 5)      // 32 consecutive columns per row visit: no integer division
+            for (int b = tid & 31; b < kp; b += 32) {
             Sout[(size_t)a * c_pitch + b] =
                 (a < k && b < k) ? (M[(size_t)a * mp + b] + M[(size_t)b * mp + a]) * 0.5 : 0.0;
         }
@@ -624,8 +623,8 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
     STAMP(5);
     if (!want_sinv) {
         // C[a][b] = Linv[b][a]/sqrt(D_b) (a<b), 1/sqrt(D_b) (a==b), 0 below and in the padding
-        for (int idx = tid; idx < kp * kp; idx += nt) {
-            const int a = idx / kp, b = idx - a * kp;         // consecutive threads: consecutive b (coalesced store,
+        for (int a = tid >> 5; a < kp; a += nt >> 5)      // 32 consecutive columns per row visit: no integer division
+            for (int b = tid & 31; b < kp; b += 32) {         // consecutive threads: consecutive b (coalesced store,
             double c = 0.0;                                   //   conflict-free LDS column walk thanks to the odd pitch)
             if (a < k && b < k) {
                 if (a == b) c = mvec[b];
@@ -635,8 +634,8 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
         }
     } else {
         // inv(S) = C*C' :  Sinv[a][b] = sum_{c >= max(a,b)} C[a][c] C[b][c]   (Joseph form needs K = PHt*inv(S))
-        for (int idx = tid; idx < kp * kp; idx += nt) {
-            const int a = idx / kp, b = idx - a * kp;
+        for (int a = tid >> 5; a < kp; a += nt >> 5)      // 32 consecutive columns per row visit: no integer division
+            for (int b = tid & 31; b < kp; b += 32) {
             double s = 0.0;
             if (a < k && b < k) {
                 const int c0 = a > b ? a : b;
