@@ -17,16 +17,17 @@
 // them bit-for-bit symmetric also in the Joseph form.  Algorithmic traffic per
 // update: n^2/2 elements read + n^2/2 written; algorithmic work n^2*k flops.
 //
-// fp32: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).  A 256-thread
-// workgroup owns a 128 x 128 tile; its four waves own 64 x 64 quadrants as 2 x 2
-// MFMA blocks (64 accumulator registers).  The product is accumulated from zero
-// and subtracted from P once (the reference's order: form W1*W1', then subtract).
-// The k-loop is software pipelined: panels travel global -> registers -> LDS in
-// chunks of 32 columns with two LDS buffers and ONE barrier per chunk; the loads
-// of chunk c+1 and of the P tile itself are in flight while chunk c feeds the
-// MFMAs.  Each lane pulls FOUR consecutive k of its row with one ds_read_b128 and
-// feeds four MFMAs -- the k index inside an MFMA is only a label, so lane half h
-// takes k = kc+4h..kc+4h+3 for both operands.
+// fp32: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).  A 512-thread
+// workgroup owns a 128 x 128 tile; wave (wr, wc) of its eight owns rows 64 wr..,
+// columns 32 wc.. as 2 x 1 MFMA blocks (32 accumulator registers; 128 VGPRs per
+// wave, so two workgroups = four waves per SIMD are resident).  The product is
+// accumulated from zero and subtracted from P once (the reference's order: form
+// W1*W1', then subtract).  Panels travel global -> registers -> LDS in chunks of
+// 32 columns with two LDS buffers and ONE barrier per chunk; the loads of chunk
+// c+1 are in flight while chunk c feeds the MFMAs, the P tile is requested behind
+// the tile's last panel request.  Each lane pulls FOUR consecutive k of its row
+// with one ds_read_b128 and feeds four MFMAs -- the k index inside an MFMA is
+// only a label, so lane half h takes k = kc+4h..kc+4h+3 for both operands.
 //
 // MFMA orientation: D[i][j] = sum_k A[i][k] B[k][j], j on lanes, i in registers.
 // P is column-major, so rows of P go on the LANES (j) and columns in the
