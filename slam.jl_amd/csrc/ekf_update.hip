@@ -765,17 +765,35 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 constexpr int W1_THREADS = 512;
 
 template <typename TO, int NCB>      // NCB = kp / 16
-__device__ __forceinline__ void w1_mfma_body(const double* __restrict__ PHt, int pitchA, const double* sC, int kp,
-                                             TO* __restrict__ W1, int pitchW, TO* __restrict__ x, int n,
-                                             const double* __restrict__ g) {
+__device__ __forceinline__ void w1_mfma_body(const double* __restrict__ PHt, int pitchA, const double* __restrict__ Cmat,
+                                             int pitchC, double* sC, TO* __restrict__ W1, int pitchW, TO* __restrict__ x,
+                                             int n, const double* __restrict__ g) {
+    constexpr int kp = 16 * NCB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, kk = lane >> 4;
     const int r0 = (blockIdx.x * (W1_THREADS / 64) + wave) * 16;
-    // the wave's 16 x kp block of PHt: all loads in flight at once
+    // the wave's 16 x kp block of PHt: all loads in flight at once, BEFORE the staging of C (one memory latency for both)
     f64x2 a[NCB * 2];
     const double* arow = PHt + (size_t)(r0 + i) * pitchA + 2 * kk;
 #pragma unroll
     for (int s = 0; s < NCB * 2; ++s) a[s] = *reinterpret_cast<const f64x2*>(arow + 8 * s);
+    // stage C (upper triangular) into LDS: up to 16 loads per thread in flight (kp is a compile-time constant here:
+    // no integer division, static trip counts)
+    constexpr int PER = kp * kp / W1_THREADS;          // 2, 8, 18, 32 elements per thread
+    constexpr int BATCH = PER < 16 ? PER : 16;
+#pragma unroll
+    for (int base = 0; base < PER; base += BATCH) {
+        double v[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int idx = (base + u) * W1_THREADS + threadIdx.x;
+            const int ar = idx / kp, c = idx % kp;
+            v[u] = (base + u < PER && ar <= c) ? Cmat[(size_t)ar * pitchC + c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u)
+            if (base + u < PER) sC[(base + u) * W1_THREADS + threadIdx.x] = v[u];
+    }
     f64x4 acc[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) acc[cb] = f64x4{0.0, 0.0, 0.0, 0.0};
@@ -821,27 +839,12 @@ __global__ __launch_bounds__(W1_THREADS) void w1_mfma_kernel(const double* __res
         SLAM_DEVICE_COUNT(dcount, m, k, kp)
         if (m == 0) return;
     }
-    extern __shared__ double sC[];                    // [kp][kp]
-    // stage C: eight loads in flight per thread (a plain copy loop serialises one L2 latency per element)
-    for (int base = 0; base < kp * kp; base += 8 * W1_THREADS) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = base + u * W1_THREADS + threadIdx.x;
-            const int a = idx / kp, c = idx - a * kp;
-            v[u] = (idx < kp * kp && a <= c) ? Cmat[(size_t)a * pitchC + c] : 0.0;      // upper triangular
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = base + u * W1_THREADS + threadIdx.x;
-            if (idx < kp * kp) sC[idx] = v[u];
-        }
-    }
+    extern __shared__ double sC[];                    // [kp][kp], staged inside the body
     // (the barrier is inside the body, after the wave's PHt loads have been issued)
-    if (kp == 32) w1_mfma_body<TO, 2>(PHt, pitchA, sC, kp, W1, pitchW, x, n, g);
-    else if (kp == 64) w1_mfma_body<TO, 4>(PHt, pitchA, sC, kp, W1, pitchW, x, n, g);
-    else if (kp == 96) w1_mfma_body<TO, 6>(PHt, pitchA, sC, kp, W1, pitchW, x, n, g);
-    else w1_mfma_body<TO, 8>(PHt, pitchA, sC, kp, W1, pitchW, x, n, g);
+    if (kp == 32) w1_mfma_body<TO, 2>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g);
+    else if (kp == 64) w1_mfma_body<TO, 4>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g);
+    else if (kp == 96) w1_mfma_body<TO, 6>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g);
+    else w1_mfma_body<TO, 8>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g);
 }
 
 // x += PHt * g      (ekf.jl:74 with W*v = PHt*(C*C'*v)); 8 lanes per row
