@@ -266,6 +266,7 @@ extern "C" int slam_ekf_create(slam_ekf_t* out, int dtype, int max_landmarks, in
     h->async_updates = 0; h->deferred = 0; h->pending_status = 0; h->debug_stamps = 0;
     h->debug_flags = getenv("SLAMHIP_DEBUG") ? atoi(getenv("SLAMHIP_DEBUG")) : 0;
     h->dd_prof = nullptr;
+    h->xflags = getenv("SLAMHIP_X") ? atoi(getenv("SLAMHIP_X")) : 0;
     h->factor_blocked = !(getenv("SLAMHIP_FACTOR") && !strcmp(getenv("SLAMHIP_FACTOR"), "scalar"));
     h->timing = 0;
     for (int i = 0; i < SLAM_K_COUNT; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
