@@ -59,8 +59,6 @@ struct slam_ekf {
     void* x;          // [ncap]
     void* P;          // [ld * npad] column-major, whole 128 x 128 tiles; rows/cols >= n are zero padding
     hipStream_t stream;
-    hipStream_t stream2;   // update(): the full P*H' panel is formed here while the main stream factors S
-    hipEvent_t ev_fork, ev_join;
     double* PHtS;          // compact panel [3 + kcap][kcap]: the rows of P*H' the factorisation needs
     hipEvent_t stage_ev;   // marks the last H2D copy out of the pinned staging buffers
     int stage_pending;

@@ -189,9 +189,6 @@ extern "C" int slam_ekf_destroy(slam_ekf_t h) {
     if (h->h_small) (void)hipHostFree(h->h_small);
     if (h->h_status) (void)hipHostFree(h->h_status);
     if (h->stage_ev) (void)hipEventDestroy(h->stage_ev);
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return SLAM_OK;
@@ -202,15 +199,9 @@ static int create_impl(slam_ekf* h) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, h->device));
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    // the main stream carries the critical chain; the side stream (full P*H' panel) yields to it
-    int prio_lo = 0, prio_hi = 0;
-    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    HIP_TRY(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
-    HIP_TRY(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     // ordering-only events between kernels of this device: no system-scope fence
     HIP_TRY(hipEventCreateWithFlags(&h->stage_ev, hipEventDisableTiming | hipEventDisableSystemFence));
-    HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence));
-    HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming | hipEventDisableSystemFence));
     int rc;
     if ((rc = update_kernels_init())) return rc;
     if ((rc = dev_alloc_zero(&h->x, h->esz * (size_t)h->ncap, h->stream))) return rc;
@@ -252,7 +243,7 @@ extern "C" int slam_ekf_create(slam_ekf_t* out, int dtype, int max_landmarks, in
     h->x = h->P = nullptr;
     h->stream = nullptr;
     h->stage_ev = nullptr; h->stage_pending = 0;
-    h->stream2 = nullptr; h->ev_fork = h->ev_join = nullptr; h->PHtS = nullptr;
+    h->PHtS = nullptr;
     h->kcap = 0;
     h->W1 = h->W2 = nullptr;
     h->PHt = h->PHtS = h->Kd = h->Cmat = h->Smat = h->Mwork = h->gvec = nullptr;

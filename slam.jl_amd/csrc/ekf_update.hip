@@ -38,16 +38,17 @@ namespace {
 // ---------------------------------------------------------------------------
 constexpr int PHT_OBS = 16;
 
+// (a device function: it runs as the workgroups 1.. of the fused factor kernel, next to the one-workgroup
+//  factorisation; row0 = first row of this workgroup, by = its chunk of PHT_OBS observations)
 template <typename T>
-__global__ __launch_bounds__(256) void pht_kernel(const T* __restrict__ x, const T* __restrict__ P, int ld, int n,
-                                                   const int32_t* __restrict__ idf, int m, int k, int kp,
-                                                   double* __restrict__ PHt, int pitch, int tile_log2,
-                                                   const int32_t* __restrict__ dcount) {
+__device__ __forceinline__ void pht_body(const T* __restrict__ x, const T* __restrict__ P, int ld, int n,
+                                         const int32_t* __restrict__ idf, int m, int k, int kp, double* __restrict__ PHt,
+                                         int pitch, int tile_log2, const int32_t* __restrict__ dcount, int row0, int by) {
     __shared__ double sh[PHT_OBS][10];
     __shared__ int sf[PHT_OBS];
     SLAM_DEVICE_COUNT(dcount, m, k, kp)
     const int tid = threadIdx.x;
-    const int i0 = blockIdx.y * PHT_OBS;
+    const int i0 = by * PHT_OBS;
     if (2 * i0 >= kp) return;                                   // (device count: a chunk beyond the padded width)
     const int mc = (m - i0 < PHT_OBS) ? m - i0 : PHT_OBS;       // observations in this chunk (may be <= 0 for pure padding)
     if (tid < mc) {
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void pht_kernel(const T* __restrict__ x, const
         sf[tid] = f;
     }
     __syncthreads();
-    const int r = blockIdx.x * blockDim.x + tid;
+    const int r = row0 + tid;
     if (r >= n) return;
     double* out = PHt + (size_t)r * pitch + 2 * i0;
     if (mc > 0) {
@@ -453,7 +454,7 @@ __device__ inline bool eliminate_in_memory(double* M, int mp, int k, double* mve
 // INLDS = true: M lives in LDS and is addressed as LDS (ds_* instructions).  A single kernel that picked
 // "LDS or global" at run time made every access a FLAT instruction -- 3x slower per elimination step.
 template <typename T, bool INLDS>
-__global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
+__device__ __forceinline__ void factor_body(
     const T* __restrict__ x, const double* __restrict__ PHt, int pht_pitch, const double* __restrict__ z,
     const int32_t* __restrict__ idf, int m, int k, int kp, double R0, double R1, double R2, double R3,
     double* __restrict__ Cout, int c_pitch, double* __restrict__ gvec, double* __restrict__ Sout, int want_sinv,
@@ -650,6 +651,27 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
     }
     STAMP(6);
 #undef STAMP
+}
+
+// The launched kernel: workgroup 0 factors S (it needs only the COMPACT panel formed just before), workgroups 1.. form
+// the FULL n-row panel P*H' meanwhile -- which only W1 = PHt*C and x += PHt*g consume -- on the CUs the one-workgroup
+// factorisation leaves idle.  One launch, one stream: a fork/join over two streams cost two event hops (~12 us) and
+// was measured.  (Every workgroup is given the factorisation's LDS, so the panel workgroups run one per CU.)
+template <typename T, bool INLDS>
+__global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
+    const T* __restrict__ x, const double* __restrict__ PHtS, int pht_pitch, const double* __restrict__ z,
+    const int32_t* __restrict__ idf, int m, int k, int kp, double R0, double R1, double R2, double R3,
+    double* __restrict__ Cout, int c_pitch, double* __restrict__ gvec, double* __restrict__ Sout, int want_sinv,
+    double* __restrict__ Mglobal, int32_t* __restrict__ status, unsigned long long* __restrict__ stamps,
+    const int32_t* __restrict__ dcount, int blocked, const T* __restrict__ P, int ld, int n, double* __restrict__ PHt,
+    int tile_log2, int nbx) {
+    if (blockIdx.x == 0) {
+        factor_body<T, INLDS>(x, PHtS, pht_pitch, z, idf, m, k, kp, R0, R1, R2, R3, Cout, c_pitch, gvec, Sout, want_sinv, Mglobal,
+                              status, stamps, dcount, blocked);
+    } else {
+        const int b = blockIdx.x - 1;
+        pht_body<T>(x, P, ld, n, idf, m, k, kp, PHt, pht_pitch, tile_log2, dcount, (b % nbx) * FACTOR_THREADS, b / nbx);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -881,44 +903,35 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form, const int32_t*
     T* W2 = (T*)h->W2;
     const bool joseph = form == SLAM_FORM_JOSEPH;
 
-    // K2/K3.  The factorisation is ONE workgroup and needs only 3 + 2m rows of P*H': those are formed first, on the
-    // main stream (compact panel PHtS); the full n-row panel -- which only W1 = PHt*C and x += PHt*g consume -- is formed
-    // meanwhile on the second stream, on the 255 CUs the factorisation leaves idle.
+    // K2c: the 3 + 2m rows of P*H' the factorisation needs (compact panel PHtS); the full panel is formed by the
+    // fused kernel below, next to the factorisation
     const int tlog = h->dtype == SLAM_F32 ? 7 : 6;
-    HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
-    HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
     {
-        KTimer t(h, SLAM_K_PHT, h->stream2);
-        const dim3 grid((n + 255) / 256, kp / (2 * PHT_OBS));
-        // (16 KiB of unused dynamic LDS per workgroup keeps these workgroups off the CU that runs the factorisation,
-        //  whose 145 KiB leave less than that free)
-        hipLaunchKernelGGL(pht_kernel<T>, grid, dim3(256), 16384, h->stream2, x, P, h->ld, n, h->idfbuf, m, k, kp, h->PHt,
-                           pitchA, tlog, dcount);
-    }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(h->ev_join, h->stream2));
-    {
+        KTimer t(h, SLAM_K_PHT);
         hipLaunchKernelGGL(pht_compact_kernel<T>, dim3(3 + 2 * m), dim3(128), 0, h->stream, x, P, h->ld, n, h->idfbuf, m, k, kp,
                            h->PHtS, pitchA, tlog, dcount);
     }
     HIP_TRY(hipGetLastError());
-    {   // K4
+    {   // K4 + K2/K3 (full panel), one launch
         KTimer t(h, SLAM_K_FACTOR);
         const bool in_lds = kp <= 128;
+        const int nbx = (n + FACTOR_THREADS - 1) / FACTOR_THREADS, nby = kp / (2 * PHT_OBS);
+        const dim3 fgrid(1 + nbx * nby);
         const size_t aux = (size_t)7 * kp * sizeof(double) + (size_t)m * (10 * sizeof(double) + sizeof(int));
         const size_t shm = aux + (in_lds ? (size_t)kp * (kp + 1) * sizeof(double) : 0);
         unsigned long long* stamps = h->debug_stamps ? (unsigned long long*)(h->d_small + 40) : (unsigned long long*)nullptr;
         if (in_lds)
-            hipLaunchKernelGGL((factor_kernel<T, true>), dim3(1), dim3(FACTOR_THREADS), shm, h->stream, x, h->PHtS, pitchA,
+            hipLaunchKernelGGL((factor_kernel<T, true>), fgrid, dim3(FACTOR_THREADS), shm, h->stream, x, h->PHtS, pitchA,
                                h->obsbuf, h->idfbuf, m, k, kp, R[0], R[1], R[2], R[3], h->Cmat, pitchA, h->gvec,
-                               joseph ? h->Smat : (double*)nullptr, joseph ? 1 : 0, (double*)nullptr, h->d_status, stamps, dcount, h->factor_blocked);
+                               joseph ? h->Smat : (double*)nullptr, joseph ? 1 : 0, (double*)nullptr, h->d_status, stamps, dcount, h->factor_blocked,
+                               (const T*)P, h->ld, n, h->PHt, tlog, nbx);
         else
-            hipLaunchKernelGGL((factor_kernel<T, false>), dim3(1), dim3(FACTOR_THREADS), shm, h->stream, x, h->PHtS, pitchA,
+            hipLaunchKernelGGL((factor_kernel<T, false>), fgrid, dim3(FACTOR_THREADS), shm, h->stream, x, h->PHtS, pitchA,
                                h->obsbuf, h->idfbuf, m, k, kp, R[0], R[1], R[2], R[3], h->Cmat, pitchA, h->gvec,
-                               joseph ? h->Smat : (double*)nullptr, joseph ? 1 : 0, h->Mwork, h->d_status, stamps, dcount, 0);
+                               joseph ? h->Smat : (double*)nullptr, joseph ? 1 : 0, h->Mwork, h->d_status, stamps, dcount, 0,
+                               (const T*)P, h->ld, n, h->PHt, tlog, nbx);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));          // join: the full panel is ready
     const dim3 pg_grid(h->npad / PG_ROWS, (kp + PG_COLS - 1) / PG_COLS);
     int kp_total;
     {   // K5
@@ -968,9 +981,11 @@ int update_kernels_init() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&w1_mfma_kernel<double>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    // (the fused factor kernel also holds ~1.4 KiB of static LDS for its panel workgroups: static + dynamic <= 160 KiB)
+    const int fbig = big - 4096;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_kernel<float, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, big));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, fbig));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_kernel<double, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, big));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, fbig));
     return SLAM_OK;
 }
