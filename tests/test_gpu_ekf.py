@@ -376,6 +376,32 @@ def test_many_observations_and_large_k(pkg, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_observe_with_many_observations(pkg, dtype):
+    """observe() with nz = 300 > 256: the gating sweep runs in two chunks and the compaction waits for the last one;
+    k = 2m > 128 takes the global-memory factorisation inside the fused factor/panel launch.  Distinct, well
+    separated landmarks (so S is well conditioned at this k); state against the oracle's three calls."""
+    rng = np.random.default_rng(33)
+    N = 400
+    x, P = random_state(rng, N, spread=2000.0)
+    st = pkg.EKFSlamState(x, P, dtype=dtype, max_landmarks=N + 8)
+    xo, Po = rounded(st)
+    ids = rng.permutation(N)[:297] + 1
+    z = np.hstack([noisy_obs(rng, xo, ids), np.vstack([rng.uniform(5000, 6000, 3), rng.uniform(-1, 1, 3)])])
+    z = z[:, rng.permutation(300)]
+    a = st.observe(z, R, 4.0, 25.0)
+    nis, nd = O.association_table_sparse(xo, Po, z, R)
+    ao = O.assoc_vector(nis, nd, 4.0, 25.0)
+    assert np.array_equal(a, ao) and int(np.sum(ao > 0)) > 64
+    zf, idf, zn = O.split_assoc(z, ao)
+    Pprior = Po
+    xo, Po = O.update_sparse(xo, Po, zf, R, idf)
+    xo, Po = O.add_features_sparse(xo, Po, zn, R)
+    assert st.N == N + zn.shape[1]
+    check_state(st, xo, Po, dtype, "observe nz=300", fx=4.0, fP=100.0, prior=Pprior)
+    st.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_joseph_form(pkg, dtype):
     rng = np.random.default_rng(5)
     N, m = 150, 12
