@@ -287,12 +287,105 @@ __device__ __forceinline__ void dd_tile(DdCtx& c, int2 tile, int2 next, smem_t& 
     }
 }
 
+// ---- streaming path for runs of OFF-DIAGONAL tiles -----------------------------------------------------------------
+// The LDS pipeline does not know about tiles: every chunk, whichever tile it belongs to, is [steps on buffer pb] ->
+// [fill buffer pb^1 with the following chunk] -> barrier -> [request the chunk after that].  A tile boundary is then
+// only register work: P_old - acc is formed in the MFMA layout and stored with dword buffer stores (an accumulator
+// register covers 32 consecutive rows of one column = a full 128-byte line per half-wave, so nothing has to pass
+// through LDS), acc is cleared and the k-loop of the next tile is already fed.  Compared with dd_tile this removes
+// two of the six barriers per tile, the per-wave LDS transposes, and the pipeline drain at the tile boundary.
+__device__ __forceinline__ void load_p_mfma(const DdCtx& c, int R0, int C0, float (&pold)[2][16]) {
+    const auto rs = band_rsrc(c.P + (size_t)C0 * c.ld, c.ld);
+    const int voff = (4 * c.lh * c.ld + c.l31) * 4;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int soff = ((32 * c.wc + 8 * (r >> 2) + (r & 3)) * c.ld + R0 + 64 * c.wr + 32 * rb) * 4;
+            pold[rb][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+        }
+}
+
+__device__ __forceinline__ void store_p_mfma(const DdCtx& c, int R0, int C0, const float (&pold)[2][16], f32x16 (&acc)[2]) {
+    const auto rs = band_rsrc(c.P + (size_t)C0 * c.ld, c.ld);
+    const int voff = (4 * c.lh * c.ld + c.l31) * 4;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int soff = ((32 * c.wc + 8 * (r >> 2) + (r & 3)) * c.ld + R0 + 64 * c.wr + 32 * rb) * 4;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pold[rb][r] - acc[rb][r]), rs, voff, soff, 0);
+            acc[rb][r] = 0.0f;
+        }
+}
+
+// Processes list[slot], list[slot + nper], ... while they are off-diagonal.  NCH = chunks per tile (2..4), a
+// compile-time constant: the body of a tile is straight-line code, so the compiler's vmcnt bookkeeping is exact (a
+// panel chunk is waited for with vmcnt(#younger requests), never with vmcnt(0) behind the P tile or the stores).
+// On entry gx/gy hold the request for chunk 0 of the first tile; on return `slot` is the first unprocessed position
+// and, if that tile exists, gx/gy hold the request for ITS chunk 0 -- the contract of dd_tile, which takes over for
+// the diagonal tiles.
+template <bool DBG, int NCH>
+__device__ __forceinline__ void dd_stream(DdCtx& c, const int2* __restrict__ list, int L, int nper, int& slot, smem_t& smem,
+                                          f32x4 (&gx)[2], f32x4 (&gy)[2]) {
+    auto fetch = [&](int sl) { return sl < L ? list[sl] : make_int2(-1, -1); };
+    constexpr int PCH = NCH - 2;                       // the chunk at whose start the P tile is requested
+    int2 tile = fetch(slot);
+    int2 next = fetch(slot + nper);
+    f32x16 acc[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
+    float pold[2][16];
+    Frag f0;
+    const int last_steps = (c.kp - (NCH - 1) * KC <= 16) ? 2 : 4;
+    fill_lds(c, smem, 0, gx, gy);
+    __syncthreads();
+    request_chunk(c, tile, 1, gx, gy);
+    // buffer parity: chunk ch of a tile sits in buffer (base + ch) & 1; with NCH odd the base flips per tile
+    int base = 0;
+    for (;;) {
+        const bool next_off = next.x >= 0 && next.x != next.y;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int pb = (base + ch) & 1;
+            if (ch == PCH) load_p_mfma(c, tile.x * TILE, tile.y * TILE, pold);
+            if (ch < NCH - 1) {
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    read_frag(c, smem, pb, 8 * st, f0);
+                    mfma_step<DBG>(c, f0, acc);
+                }
+                fill_lds(c, smem, pb ^ 1, gx, gy);               // chunk ch + 1 of this tile
+                __syncthreads();
+                if (ch + 2 < NCH) request_chunk(c, tile, ch + 2, gx, gy);
+                else if (next.x >= 0) request_chunk(c, next, 0, gx, gy);      // (also when `next` is diagonal: hand-over)
+            } else {
+                for (int st = 0; st < last_steps; ++st) {
+                    read_frag(c, smem, pb, 8 * st, f0);
+                    mfma_step<DBG>(c, f0, acc);
+                }
+                if (next_off) fill_lds(c, smem, pb ^ 1, gx, gy); // chunk 0 of the next tile
+                __syncthreads();
+                if (next_off) request_chunk(c, next, 1, gx, gy);
+                store_p_mfma(c, tile.x * TILE, tile.y * TILE, pold, acc);
+            }
+        }
+        slot += nper;
+        if (!next_off) return;
+        tile = next;
+        next = fetch(slot + nper);
+        base = (base + NCH) & 1;
+    }
+}
+
 // PERSISTENT kernel: gridDim.x = 8 * nper workgroups (two per CU: four waves per SIMD); workgroup b
 // walks the tile list of XCD b % 8 with stride nper.  Memory operations of a wave are asynchronous: a
 // wave that moves on to the next tile's MFMAs lets its stores drain behind them.  The first tile is
 // peeled so that the loop header sees the same load/store history on both of its incoming edges and the
 // compiler can emit counted vmcnt waits for the panel chunk instead of vmcnt(0).
-template <bool DBG>
+template <bool DBG, int STREAM = 0>          // STREAM = chunks per tile (2..4) for the streaming path, 0: dd_tile only
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void downdate_f32_mfma(float* __restrict__ P, int ld, int n,
                                                                  const float* __restrict__ X, const float* __restrict__ Y,
                                                                  int pitch, int kp, const int2* __restrict__ tiles, int L,
@@ -338,8 +431,14 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
     request_chunk(c, tile, 0, gx, gy);
     slot += nper;
     int2 next = slot < L ? list[slot] : make_int2(-1, -1);
-    // off-diagonal tiles first (the lists keep the diagonal ones at their end): branch-free hot loop
-    if (tile.x != tile.y) {
+    // off-diagonal tiles first (the lists keep the diagonal ones at their end)
+    if (STREAM >= 2 && tile.x != tile.y && c.nchunks == STREAM) {
+        slot = rk;
+        dd_stream<DBG, (STREAM >= 2 ? STREAM : 2)>(c, list, L, nper, slot, smem, gx, gy);
+        tile = slot < L ? list[slot] : make_int2(-1, -1);
+        slot += nper;
+        next = slot < L ? list[slot] : make_int2(-1, -1);
+    } else if (tile.x != tile.y) {
         dd_tile<false, DBG>(c, tile, next, smem, sD, sV, gx, gy);               // peeled first tile
         while (next.x >= 0 && next.x != next.y) {
             tile = next;
@@ -543,6 +642,18 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
             hipLaunchKernelGGL(downdate_f32_mfma<true>, dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,
                                (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
                                h->d_status, h->debug_flags, (unsigned long long*)h->dd_prof, dcount, joseph);
+        else if (!(h->xflags & 4) && kp_total > 32 && kp_total <= 128) {     // (observe(): kp_total is an upper bound; the kernel falls back to dd_tile if the real chunk count differs)
+            // streaming (tile-boundary-free) path for the off-diagonal tiles, one instantiation per chunk count
+            const int nch = (kp_total + KC - 1) / KC;
+#define DD_LAUNCH_STREAM(NCH)                                                                                          \
+    hipLaunchKernelGGL((downdate_f32_mfma<false, NCH>), dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, \
+                       n, (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,       \
+                       h->d_status, h->xflags << 8, (unsigned long long*)nullptr, dcount, joseph)
+            if (nch == 4) DD_LAUNCH_STREAM(4);
+            else if (nch == 3) DD_LAUNCH_STREAM(3);
+            else DD_LAUNCH_STREAM(2);
+#undef DD_LAUNCH_STREAM
+        }
         else
             hipLaunchKernelGGL(downdate_f32_mfma<false>, dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,
                                (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
