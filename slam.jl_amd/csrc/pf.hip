@@ -57,6 +57,8 @@ struct slam_pf {
     double* h_out;       // pinned [8]: seven statistics + the sequence word the host polls
     double* h_out_dev;   // its device-side address
     long long out_seq;
+    double pending_shift;    // slam_pf_normalize defers its shift: the next kernel that touches logw applies it
+    int has_pending;
     double* d_cdf;       // [n_global]
     double* d_bsum;      // [scan blocks]
     int32_t* d_src;      // [n] gather source: >= 0 local index, < 0: -(recv position + 1)
@@ -166,6 +168,8 @@ __device__ __forceinline__ LmRow<T> load_row(const T* __restrict__ row, int64_t 
 }
 
 __device__ inline double block_reduce(double v, double* sh, bool is_max);
+__device__ __forceinline__ void fold_partials(const double* __restrict__ part, int nblocks, int relative,
+                                              double* __restrict__ out, double* __restrict__ host_out, long long seq);
 
 // Per-block weight statistics with the block's OWN maximum as the shift (one pass; pf_fold_kernel rescales):
 // part[b] = {m_b, sum e, sum e^2, sum e x, sum e y, sum e sin(phi), sum e cos(phi)},  e = exp(logw - shift_b),
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256) void pf_step_kernel(T* __restrict__ pose, T* _
                                                        int64_t n, int64_t first, uint32_t step, uint64_t seed, T V, T G,
                                                        T wheelbase, T sigV, T sigG, T dt, const double* __restrict__ z,
                                                        const int32_t* __restrict__ ids, int m, T R00, T R10, T R01, T R11,
-                                                       double* __restrict__ part) {
+                                                       double* __restrict__ part, T pend) {
     // the observation list may live in pinned HOST memory (zero-copy staging): one read per workgroup into LDS
     extern __shared__ double s_obs[];              // [m][2] doubles, then [m] ints
     int32_t* s_ids = reinterpret_cast<int32_t*>(s_obs + 2 * m);
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(256) void pf_step_kernel(T* __restrict__ pose, T* _
         x = xn; y = yn; phi = pn;
         if (valid) { pose[p] = x; pose[n + p] = y; pose[2 * n + p] = phi; }
     }
-    T lw = logw[p];
+    T lw = logw[p] - pend;        // `pend`: the normalisation shift deferred by slam_pf_normalize (0 if none)
     LmRow<T> pre = {0, 0, 0, 0, 0};
     bool have = false;
     if (m > 0 && !(s_ids[0] & NEW_FLAG)) {
@@ -286,6 +290,8 @@ __global__ __launch_bounds__(256) void pf_step_kernel(T* __restrict__ pose, T* _
         lw += (T)-0.5 * (y0 * y0 + y1 * y1) - log(u00 * u11) - (T)1.8378770664093453;   // log(2 pi)
     }
     if (valid) logw[p] = lw;
+    // (folding the partials in the last workgroup to finish was tried: its agent-scope release/acquire is an L2
+    //  write-back + invalidate on this multi-XCD part and doubled the kernel's time; a 1-workgroup fold kernel follows)
     if (STATS) block_weight_stats<T>(lw, x, y, phi, valid, 1, part);
 }
 
@@ -316,9 +322,8 @@ __global__ __launch_bounds__(256) void pf_stats_kernel(const T* __restrict__ log
 
 // out = {M, sum, sum2, sx, sy, ss, sc} over all blocks: M = max_b m_b, block sums rescaled by exp(m_b - M)
 // (its square for the second moment).  One workgroup.
-__global__ __launch_bounds__(256) void pf_fold_kernel(const double* __restrict__ part, int nblocks, int relative,
-                                                      double* __restrict__ out, double* __restrict__ host_out,
-                                                      long long seq) {
+__device__ __forceinline__ void fold_partials(const double* __restrict__ part, int nblocks, int relative,
+                                              double* __restrict__ out, double* __restrict__ host_out, long long seq) {
     __shared__ double sh[4];
     double m = -__builtin_inf();
     for (int b = threadIdx.x; b < nblocks; b += 256) m = fmax(m, part[(size_t)b * 8]);
@@ -342,6 +347,12 @@ __global__ __launch_bounds__(256) void pf_fold_kernel(const double* __restrict__
         __threadfence_system();
         __hip_atomic_store(reinterpret_cast<long long*>(host_out + 7), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+__global__ __launch_bounds__(256) void pf_fold_kernel(const double* __restrict__ part, int nblocks, int relative,
+                                                      double* __restrict__ out, double* __restrict__ host_out,
+                                                      long long seq) {
+    fold_partials(part, nblocks, relative, out, host_out, seq);
 }
 
 template <typename T>
@@ -562,6 +573,7 @@ static int pf_create_impl(slam_pf* h) {
     memset(h->h_out, 0, sizeof(double) * 8);
     HIP_TRY(hipHostGetDevicePointer((void**)&h->h_out_dev, h->h_out, 0));
     h->out_seq = 0;
+    h->pending_shift = 0.0; h->has_pending = 0;
     // uniform weights over the GLOBAL particle set
     const double lw = -log((double)h->n_global);
     PF_DISPATCH(h,
@@ -607,6 +619,8 @@ extern "C" int slam_pf_create(slam_pf_t* out, int dtype, int64_t n_local, int64_
 extern "C" int slam_pf_set_pose(slam_pf_t h, const double pose[3]) {
     ARG_CHECK(h != nullptr && pose != nullptr, "null argument");
     HIP_TRY(hipSetDevice(h->device));
+    h->has_pending = 0;                                // logw is overwritten: a deferred normalisation shift is moot
+    h->pending_shift = 0.0;
     const double lw = -log((double)h->n_global);
     PF_DISPATCH(h,
                 hipLaunchKernelGGL(pf_set_pose_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream,
@@ -648,6 +662,25 @@ extern "C" int slam_pf_predict(slam_pf_t h, double V, double G, double wheelbase
                                    h->n, h->first, h->step, h->seed, (T)V, (T)G, (T)wheelbase, (T)sV, (T)sG, (T)dt));
     HIP_TRY(hipGetLastError());
     h->step += 1;
+    return SLAM_OK;
+}
+
+// slam_pf_normalize only RECORDS its shift; the next kernel that reads logw applies it (the fused step kernel takes it
+// as a parameter, everything else flushes it first) -- one launch less per filter step.
+static double pf_take_pending(slam_pf* h) {
+    const double p = h->has_pending ? h->pending_shift : 0.0;
+    h->has_pending = 0;
+    h->pending_shift = 0.0;
+    return p;
+}
+
+static int pf_flush_pending(slam_pf* h) {
+    if (!h->has_pending) return SLAM_OK;
+    const double shift = pf_take_pending(h);
+    PF_DISPATCH(h,
+                hipLaunchKernelGGL(pf_shift_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->logw, h->n, (T)shift),
+                hipLaunchKernelGGL(pf_shift_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->logw, h->n, (T)shift));
+    HIP_TRY(hipGetLastError());
     return SLAM_OK;
 }
 
@@ -698,23 +731,21 @@ extern "C" int slam_pf_update_known(slam_pf_t h, const double* z, const int32_t*
     const double* dz;
     const int32_t* di;
     if ((rc = pf_stage(h, z, ids, m, &dz, &di))) return rc;
+    const double pend = pf_take_pending(h);              // a deferred normalisation shift is applied on the way
     PF_DISPATCH(h,
                 hipLaunchKernelGGL((pf_step_kernel<T, false, false>), dim3(grid_for(h->n)), dim3(256), (size_t)m * 20, h->stream,
                                    (T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->first, 0u, h->seed, (T)0, (T)0,
-                                   (T)1, (T)0, (T)0, (T)0, dz, di, m, (T)R[0], (T)R[1], (T)R[2], (T)R[3], (double*)nullptr),
+                                   (T)1, (T)0, (T)0, (T)0, dz, di, m, (T)R[0], (T)R[1], (T)R[2], (T)R[3], (double*)nullptr, (T)pend),
                 hipLaunchKernelGGL((pf_step_kernel<T, false, false>), dim3(grid_for(h->n)), dim3(256), (size_t)m * 20, h->stream,
                                    (T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->first, 0u, h->seed, (T)0, (T)0,
-                                   (T)1, (T)0, (T)0, (T)0, dz, di, m, (T)R[0], (T)R[1], (T)R[2], (T)R[3], (double*)nullptr));
+                                   (T)1, (T)0, (T)0, (T)0, dz, di, m, (T)R[0], (T)R[1], (T)R[2], (T)R[3], (double*)nullptr, (T)pend));
     HIP_TRY(hipGetLastError());
     return pf_stage_done(h);
 }
 
 // fold the per-block partials in d_part and bring the seven numbers to the host
-static int pf_fold_and_read(slam_pf* h, int relative_to_max, double out[7]) {
-    h->out_seq += 1;
-    hipLaunchKernelGGL(pf_fold_kernel, dim3(1), dim3(256), 0, h->stream, (const double*)h->d_part, h->red_blocks,
-                       relative_to_max, h->d_out, h->h_out_dev, h->out_seq);
-    HIP_TRY(hipGetLastError());
+// wait (polling pinned memory) for the statistics published under sequence number h->out_seq
+static int pf_wait_stats(slam_pf* h, double out[7]) {
     volatile long long* flag = reinterpret_cast<volatile long long*>(h->h_out + 7);
     unsigned long long spins = 0;
     while (*flag != h->out_seq) {
@@ -732,6 +763,14 @@ static int pf_fold_and_read(slam_pf* h, int relative_to_max, double out[7]) {
     return SLAM_OK;
 }
 
+static int pf_fold_and_read(slam_pf* h, int relative_to_max, double out[7]) {
+    h->out_seq += 1;
+    hipLaunchKernelGGL(pf_fold_kernel, dim3(1), dim3(256), 0, h->stream, (const double*)h->d_part, h->red_blocks,
+                       relative_to_max, h->d_out, h->h_out_dev, h->out_seq);
+    HIP_TRY(hipGetLastError());
+    return pf_wait_stats(h, out);
+}
+
 /* F1 + F2/F3 + the local part of F4 as ONE sweep over the particles: predict, the m known-id updates and the weight
  * statistics {max logw, sum exp(logw - max), sum exp(2 (logw - max))}.  Same particles as slam_pf_predict +
  * slam_pf_update_known (bit for bit), same statistics as slam_pf_weight_stats.  Synchronises (the caller needs Neff). */
@@ -747,15 +786,16 @@ extern "C" int slam_pf_step(slam_pf_t h, double V, double G, double wheelbase, c
     const int32_t* di = h->h_ids_dev;
     if (m && (rc = pf_stage(h, z, ids, m, &dz, &di))) return rc;
     const double sV = sqrt(Q[0]), sG = sqrt(Q[3]);
+    const double pend = pf_take_pending(h);
     PF_DISPATCH(h,
                 hipLaunchKernelGGL((pf_step_kernel<T, true, true>), dim3(grid_for(h->n)), dim3(256), (size_t)m * 20, h->stream,
                                    (T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
                                    (T)G, (T)wheelbase, (T)sV, (T)sG, (T)dt, dz, di, m, (T)Rz[0], (T)Rz[1], (T)Rz[2], (T)Rz[3],
-                                   h->d_part),
+                                   h->d_part, (T)pend),
                 hipLaunchKernelGGL((pf_step_kernel<T, true, true>), dim3(grid_for(h->n)), dim3(256), (size_t)m * 20, h->stream,
                                    (T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
                                    (T)G, (T)wheelbase, (T)sV, (T)sG, (T)dt, dz, di, m, (T)Rz[0], (T)Rz[1], (T)Rz[2], (T)Rz[3],
-                                   h->d_part));
+                                   h->d_part, (T)pend));
     HIP_TRY(hipGetLastError());
     if (m && (rc = pf_stage_done(h))) return rc;
     h->step += 1;
@@ -782,6 +822,7 @@ extern "C" int slam_pf_step_normalized(slam_pf_t h, double V, double G, double w
 // with w = exp(logw - shift), shift = local max if relative_to_max else 0.
 static int pf_stats(slam_pf* h, int relative_to_max, double out[7]) {
     HIP_TRY(hipSetDevice(h->device));
+    { const int rcf = pf_flush_pending(h); if (rcf) return rcf; }
     PF_DISPATCH(h,
                 hipLaunchKernelGGL(pf_stats_kernel<T>, dim3(h->red_blocks), dim3(256), 0, h->stream, (const T*)h->logw,
                                    (const T*)h->pose[h->cur], h->n, relative_to_max, h->d_part),
@@ -814,16 +855,17 @@ extern "C" int slam_pf_normalize(slam_pf_t h, double gmax, double gsum) {
     ARG_CHECK(gsum > 0.0, "gsum must be positive");
     HIP_TRY(hipSetDevice(h->device));
     const double shift = gmax + log(gsum);
-    PF_DISPATCH(h,
-                hipLaunchKernelGGL(pf_shift_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->logw, h->n, (T)shift),
-                hipLaunchKernelGGL(pf_shift_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->logw, h->n, (T)shift));
-    HIP_TRY(hipGetLastError());
+    const int rc = pf_flush_pending(h);          // (two normalisations in a row: the first shift is applied on its own)
+    if (rc) return rc;
+    h->pending_shift = shift;                    // applied by the next kernel that touches logw
+    h->has_pending = 1;
     return SLAM_OK;
 }
 
 extern "C" int slam_pf_copy_logw(slam_pf_t h, void* d_dst) {
     ARG_CHECK(h != nullptr && d_dst != nullptr, "null argument");
     HIP_TRY(hipSetDevice(h->device));
+    { const int rcf = pf_flush_pending(h); if (rcf) return rcf; }
     HIP_TRY(hipMemcpyAsync(d_dst, h->logw, h->esz * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return SLAM_OK;
@@ -888,6 +930,7 @@ extern "C" int slam_pf_resample_apply(slam_pf_t h, const int32_t* d_anc, const i
                 hipLaunchKernelGGL(pf_gather_kernel<T>, grid, dim3(256), 0, h->stream, (const T*)h->pose[h->cur],
                                    (const T*)h->lm[h->cur], (T*)h->pose[nxt], (T*)h->lm[nxt], h->n, nrows, h->d_src,
                                    (const T*)d_remote_records, nremote));
+    (void)pf_take_pending(h);                          // logw is overwritten: a deferred shift is moot
     const double lw = -log((double)h->n_global);      // uniform weights again
     PF_DISPATCH(h,
                 hipLaunchKernelGGL(pf_fill_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->logw, h->n, (T)lw),
@@ -902,6 +945,7 @@ extern "C" int slam_pf_download(slam_pf_t h, void* pose, void* logw, void* lm) {
     ARG_CHECK(h != nullptr, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     const size_t n = (size_t)h->n;
+    { const int rcf = pf_flush_pending(h); if (rcf) return rcf; }
     if (pose) HIP_TRY(hipMemcpyAsync(pose, h->pose[h->cur], h->esz * 3 * n, hipMemcpyDeviceToHost, h->stream));
     if (logw) HIP_TRY(hipMemcpyAsync(logw, h->logw, h->esz * n, hipMemcpyDeviceToHost, h->stream));
     if (lm) HIP_TRY(hipMemcpyAsync(lm, h->lm[h->cur], h->esz * 5 * n * (size_t)h->nl, hipMemcpyDeviceToHost, h->stream));

@@ -1,0 +1,11 @@
+mkdir -p gpurun_out
+cd /tmp && export TMPDIR=/tmp
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/pfprof
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pfprof -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pfprof.log 2>&1
+python3 - <<'PY'
+import csv, glob, os
+f = glob.glob(os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/pfprof/**/*kernel_stats.csv', recursive=True)[0]
+for r in list(csv.DictReader(open(f)))[:14]:
+    n = r['Name'].replace('void (anonymous namespace)::', '')[:56]
+    print(f"{n:58s} calls {r['Calls']:>5s} avg {float(r['AverageNs'])/1000:9.1f} us")
+PY
