@@ -347,16 +347,33 @@ __global__ __launch_bounds__(256) void pf_stats_kernel(const T* __restrict__ log
 __device__ __forceinline__ void fold_partials(const double* __restrict__ part, int nblocks, int relative,
                                               double* __restrict__ out, double* __restrict__ host_out, long long seq) {
     __shared__ double sh[4];
+    // one pass over the partials: up to four records per thread stay in registers between the max and the sums
+    // (more than 1024 partials: the remainder goes through the plain two-pass loop below)
+    double q[4][7];
     double m = -__builtin_inf();
-    for (int b = threadIdx.x; b < nblocks; b += 256) m = fmax(m, part[(size_t)b * 8]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int b = threadIdx.x + 256 * u;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) q[u][i] = b < nblocks ? part[(size_t)b * 8 + i] : (i == 0 ? -__builtin_inf() : 0.0);
+        m = fmax(m, q[u][0]);
+    }
+    for (int b = threadIdx.x + 1024; b < nblocks; b += 256) m = fmax(m, part[(size_t)b * 8]);
     const double M = block_reduce(m, sh, true);
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    for (int b = threadIdx.x; b < nblocks; b += 256) {
-        const double* q = part + (size_t)b * 8;
-        const double f = relative ? exp(q[0] - M) : 1.0;
-        acc[0] += q[1] * f;
-        acc[1] += q[2] * f * f;
-        acc[2] += q[3] * f; acc[3] += q[4] * f; acc[4] += q[5] * f; acc[5] += q[6] * f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const double f = relative ? (q[u][0] == -__builtin_inf() ? 0.0 : exp(q[u][0] - M)) : 1.0;
+        acc[0] += q[u][1] * f;
+        acc[1] += q[u][2] * f * f;
+        acc[2] += q[u][3] * f; acc[3] += q[u][4] * f; acc[4] += q[u][5] * f; acc[5] += q[u][6] * f;
+    }
+    for (int b = threadIdx.x + 1024; b < nblocks; b += 256) {
+        const double* qq = part + (size_t)b * 8;
+        const double f = relative ? exp(qq[0] - M) : 1.0;
+        acc[0] += qq[1] * f;
+        acc[1] += qq[2] * f * f;
+        acc[2] += qq[3] * f; acc[3] += qq[4] * f; acc[4] += qq[5] * f; acc[5] += qq[6] * f;
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) acc[i] = block_reduce(acc[i], sh, false);
