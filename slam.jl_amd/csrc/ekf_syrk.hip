@@ -325,11 +325,11 @@ __device__ __forceinline__ void store_p_mfma(const DdCtx& c, int R0, int C0, con
 // On entry gx/gy hold the request for chunk 0 of the first tile; on return `slot` is the first unprocessed position
 // and, if that tile exists, gx/gy hold the request for ITS chunk 0 -- the contract of dd_tile, which takes over for
 // the diagonal tiles.
-template <bool DBG, int NCH>
+template <bool DBG, int NCH, int POFF = 2>
 __device__ __forceinline__ void dd_stream(DdCtx& c, const int2* __restrict__ list, int L, int nper, int& slot, smem_t& smem,
                                           f32x4 (&gx)[2], f32x4 (&gy)[2]) {
     auto fetch = [&](int sl) { return sl < L ? list[sl] : make_int2(-1, -1); };
-    constexpr int PCH = NCH - 2;                       // the chunk at whose start the P tile is requested
+    constexpr int PCH = NCH - POFF > 0 ? NCH - POFF : 0;  // the chunk at whose start the P tile is requested
     int2 tile = fetch(slot);
     int2 next = fetch(slot + nper);
     f32x16 acc[2];
@@ -385,7 +385,7 @@ __device__ __forceinline__ void dd_stream(DdCtx& c, const int2* __restrict__ lis
 // wave that moves on to the next tile's MFMAs lets its stores drain behind them.  The first tile is
 // peeled so that the loop header sees the same load/store history on both of its incoming edges and the
 // compiler can emit counted vmcnt waits for the panel chunk instead of vmcnt(0).
-template <bool DBG, int STREAM = 0>          // STREAM = chunks per tile (2..4) for the streaming path, 0: dd_tile only
+template <bool DBG, int STREAM = 0, int POFF = 2>   // STREAM = chunks per tile (2..4) for the streaming path, 0: dd_tile only
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void downdate_f32_mfma(float* __restrict__ P, int ld, int n,
                                                                  const float* __restrict__ X, const float* __restrict__ Y,
                                                                  int pitch, int kp, const int2* __restrict__ tiles, int L,
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
     // off-diagonal tiles first (the lists keep the diagonal ones at their end)
     if (STREAM >= 2 && tile.x != tile.y && c.nchunks == STREAM) {
         slot = rk;
-        dd_stream<DBG, (STREAM >= 2 ? STREAM : 2)>(c, list, L, nper, slot, smem, gx, gy);
+        dd_stream<DBG, (STREAM >= 2 ? STREAM : 2), POFF>(c, list, L, nper, slot, smem, gx, gy);
         tile = slot < L ? list[slot] : make_int2(-1, -1);
         slot += nper;
         next = slot < L ? list[slot] : make_int2(-1, -1);
@@ -645,14 +645,21 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
         else if (!(h->xflags & 4) && kp_total > 32 && kp_total <= 128) {     // (observe(): kp_total is an upper bound; the kernel falls back to dd_tile if the real chunk count differs)
             // streaming (tile-boundary-free) path for the off-diagonal tiles, one instantiation per chunk count
             const int nch = (kp_total + KC - 1) / KC;
+// (P tile requested three chunks before the epilogue at four chunks per tile, two otherwise: one-box A/B, tools/gpu_abx.sh:
+            //  offsets 1 / 2 / 3 / 4 gave 0.449 / 0.440 / 0.434 / 0.453 ms)
+#define DD_LAUNCH_STREAM4()                                                                                            \
+    hipLaunchKernelGGL((downdate_f32_mfma<false, 4, 3>), dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, \
+                       n, (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,       \
+                       h->d_status, h->xflags << 8, (unsigned long long*)nullptr, dcount, joseph)
 #define DD_LAUNCH_STREAM(NCH)                                                                                          \
     hipLaunchKernelGGL((downdate_f32_mfma<false, NCH>), dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, \
                        n, (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,       \
                        h->d_status, h->xflags << 8, (unsigned long long*)nullptr, dcount, joseph)
-            if (nch == 4) DD_LAUNCH_STREAM(4);
+            if (nch == 4) DD_LAUNCH_STREAM4();
             else if (nch == 3) DD_LAUNCH_STREAM(3);
             else DD_LAUNCH_STREAM(2);
 #undef DD_LAUNCH_STREAM
+#undef DD_LAUNCH_STREAM4
         }
         else
             hipLaunchKernelGGL(downdate_f32_mfma<false>, dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,

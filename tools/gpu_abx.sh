@@ -5,7 +5,7 @@ rm -f gpurun_out/abx.log
 for i in $(seq $REPS); do
   for v in $VALS; do
     export $VAR=$v
-    timeout -k 10 200 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-fastslam 2>/dev/null | python -c "
+    timeout -k 10 200 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-fastslam 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
