@@ -43,6 +43,7 @@
 // fp64: the same triangular scheme on v_mfma_f64_16x16x4_f64 (64 x 64 tiles); at the k of
 // BASELINE.json's fp64 configuration the down-date is HBM-bound.
 #include <algorithm>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -572,7 +573,8 @@ __global__ __launch_bounds__(256) void downdate_f64_mfma(double* __restrict__ P,
 // (= workgroup id % 8 under round-robin dispatch) walks super-rows of SR tile rows, largest
 // first, column by column; its workgroups take slots rk, rk + nper, ...  Diagonal tiles come last.
 void build_tile_order(int T, std::vector<int2>& out) {
-    constexpr int NX = 8, SR = 4;
+    constexpr int NX = 8;
+    const int SR = getenv("SLAMHIP_SR") ? atoi(getenv("SLAMHIP_SR")) : 4;      // tile rows per super-row (experiment knob)
     const int nsr = (T + SR - 1) / SR;
     std::vector<long> load(NX, 0);
     std::vector<std::vector<int>> mine(NX);
