@@ -197,6 +197,16 @@ int slam_pf_predict(slam_pf_t h, double V, double G, double wheelbase, const dou
  * logw += log N(v; 0, S).  First sighting: initialisation like add_features
  * (src/ekf.jl:94-103,112) without the vehicle-covariance term.  Enqueued. */
 int slam_pf_update_known(slam_pf_t h, const double* z, const int32_t* ids, int m, const double R[4]);
+/* SURVEY 8f N4 (no reference code): FastSLAM-1.0 with UNKNOWN correspondences.  slam_pf_clear_landmarks marks
+ * every landmark slot of every particle unused (Pxx = -1).  slam_pf_update_unknown: m <= 16 (range, bearing) pairs;
+ * every particle associates them with its OWN landmarks by the gated nearest-neighbour rule of associate()
+ * (src/data-association.jl:1-51) with compute_association (:53-63) on the landmark's 2 x 2 block, all against the
+ * map before this step's updates; then, in observation order, matched landmarks get the update of
+ * slam_pf_update_known and new ones start in the particle's lowest unused slot (none left: dropped).  d_assoc:
+ * DEVICE pointer to m * n int32 ([m][n]) or NULL; slot >= 0 matched, -1 new, -2 dropped.  Enqueued. */
+int slam_pf_clear_landmarks(slam_pf_t h);
+int slam_pf_update_unknown(slam_pf_t h, const double* z, int m, const double R[4], double gate1, double gate2,
+                           int32_t* d_assoc);
 /* F1 + F2/F3 + the local part of F4 as ONE sweep over the particles: slam_pf_predict, slam_pf_update_known
  * and slam_pf_weight_stats in one kernel (same particles bit for bit; out as slam_pf_weight_stats).  Synchronises. */
 int slam_pf_step(slam_pf_t h, double V, double G, double wheelbase, const double Q[4], double dt,

@@ -194,6 +194,93 @@ class OraclePF:
             # w *= exp(-nis/2) / (2 pi sqrt(det S));  nis = y'y,  sqrt(det S) = u00*u11
             self.logw = self.logw - 0.5 * (y0 * y0 + y1 * y1) - np.log(u00 * u11) - math.log(2 * math.pi)
 
+    # N4: unknown correspondences -----------------------------------------------------------------
+    def clear_landmarks(self):
+        """Every slot of every particle unused: Pxx = -1 is the "no landmark here" mark."""
+        self.lm[:] = 0.0
+        self.lm[:, 2, :] = -1.0
+        self.seen[:] = False
+
+    def associate_unknown(self, z, R, gate1, gate2):
+        """Per-particle gated nearest neighbour over the particle's OWN landmarks: the rule of ``associate``
+        (src/data-association.jl:1-51, order-independent form of SURVEY 3.2) with ``compute_association``
+        (:53-63) restricted to the landmark's 2 x 2 block.  Returns assoc[m, n]: slot >= 0 matched, -1 new,
+        -2 dropped.  All observations are associated against the map as it is BEFORE this step's updates."""
+        z = np.asarray(z, dtype=np.float64).reshape(2, -1)
+        R = np.asarray(R, dtype=np.float64)
+        m = z.shape[1]
+        x, y, phi = self.pose
+        best_nd = np.full((m, self.n), np.inf)
+        best_l = np.full((m, self.n), -1, dtype=np.int64)
+        near = np.zeros((m, self.n), dtype=bool)
+        for l in range(self.nl):
+            lx, ly, pxx, pxy, pyy = self.lm[l]
+            ok = pxx >= 0.0
+            with np.errstate(all="ignore"):
+                dx, dy = lx - x, ly - y
+                d2 = dx * dx + dy * dy
+                d = np.sqrt(d2)
+                zp1 = np.arctan2(dy, dx) - phi
+                h00, h01, h10, h11 = dx / d, dy / d, -dy / d2, dx / d2          # src/common.jl:162
+                t00 = pxx * h00 + pxy * h01
+                t01 = pxx * h10 + pxy * h11
+                t10 = pxy * h00 + pyy * h01
+                t11 = pxy * h10 + pyy * h11
+                s00 = h00 * t00 + h01 * t10 + R[0, 0]                           # S = Hf Pf Hf' + R (:59), not symmetrised
+                s01 = h00 * t01 + h01 * t11 + R[0, 1]
+                s10 = h10 * t00 + h11 * t10 + R[1, 0]
+                s11 = h10 * t01 + h11 * t11 + R[1, 1]
+                det = s00 * s11 - s01 * s10
+                rdet = 1.0 / det
+                qa, qb, qc = s11 * rdet, -(s01 + s10) * rdet, s00 * rdet
+                logdet = np.log(det)
+                for i in range(m):
+                    v0 = z[0, i] - d
+                    v1 = _wrap(z[1, i] - zp1)                                   # :57
+                    nis = qa * v0 * v0 + qb * v0 * v1 + qc * v1 * v1            # :60
+                    nd = nis + logdet                                           # :61
+                    better = ok & (nis < gate1) & (nd < best_nd[i])             # strict: the lowest slot wins a tie
+                    best_nd[i] = np.where(better, nd, best_nd[i])
+                    best_l[i] = np.where(better, l, best_l[i])
+                    near[i] |= ok & (nis <= gate2)
+        return np.where(best_l >= 0, best_l, np.where(near, -2, -1))
+
+    def update_unknown(self, z, R, gate1, gate2):
+        """associate_unknown, then in observation order: matched -> the 2 x 2 update of update_known on that slot
+        (a second observation of the same landmark sees the first one's update); new -> the initialisation of
+        update_known in the particle's lowest unused slot (none left: the observation is dropped)."""
+        z = np.asarray(z, dtype=np.float64).reshape(2, -1)
+        assoc = self.associate_unknown(z, R, gate1, gate2)
+        saved_seen = self.seen.copy()
+        pidx = np.arange(self.n)
+        for i in range(z.shape[1]):
+            a = assoc[i].copy()
+            newp = a == -1
+            if newp.any():
+                free = self.lm[:, 2, :] < 0.0                                    # [L, n]
+                first_free = np.argmax(free, axis=0)
+                has_free = free[first_free, pidx]
+                a = np.where(newp, np.where(has_free, first_free, -2), a)
+            for l in range(self.nl):
+                sel = a == l
+                if not sel.any():
+                    continue
+                is_new = sel & newp
+                for mask, seen_flag in ((sel & ~newp, True), (is_new, False)):
+                    if not mask.any():
+                        continue
+                    sub = OraclePF.__new__(OraclePF)                             # the 2 x 2 arithmetic of update_known on a view
+                    sub.pose = self.pose[:, mask]
+                    sub.lm = self.lm[:, :, mask].copy()
+                    sub.logw = self.logw[mask].copy()
+                    sub.seen = np.zeros(self.nl, dtype=bool)
+                    sub.seen[l] = seen_flag
+                    OraclePF.update_known(sub, z[:, i:i + 1], [l + 1], R)
+                    self.lm[:, :, mask] = sub.lm
+                    self.logw[mask] = sub.logw
+        self.seen = saved_seen
+        return assoc
+
     # F4 ------------------------------------------------------------------------------------------
     def weight_stats(self):
         """Local (max logw, sum exp(logw-max), sum exp(2(logw-max)))."""

@@ -97,6 +97,8 @@ SIGNATURES = {
     "slam_pf_init_landmarks": (C.c_int, [_h, _dp, C.c_int, C.c_double, C.c_double]),
     "slam_pf_predict": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, _dp, C.c_double]),
     "slam_pf_update_known": (C.c_int, [_h, _dp, _ip, C.c_int, _dp]),
+    "slam_pf_clear_landmarks": (C.c_int, [_h]),
+    "slam_pf_update_unknown": (C.c_int, [_h, _dp, C.c_int, _dp, C.c_double, C.c_double, C.c_void_p]),
     "slam_pf_step": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, _dp, C.c_double, _dp, _ip, C.c_int, _dp, _dp]),
     "slam_pf_step_normalized": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, _dp, C.c_double, _dp, _ip, C.c_int, _dp,
                                           _dp]),

@@ -190,6 +190,79 @@ __device__ __forceinline__ void block_weight_stats(T lw, T x, T y, T phi, bool v
     }
 }
 
+// F3: first sighting of a landmark -- src/ekf.jl:94-103,112 without the pose term.
+template <typename T>
+__device__ __forceinline__ void lm_init(T* __restrict__ row, int64_t n, T x, T y, T phi, T r, T b, T R00, T R10, T R01, T R11,
+                                        bool valid) {
+    const T s = sin(phi + b), c = cos(phi + b);
+    const T g00 = c, g01 = -r * s, g10 = s, g11 = r * c;
+    const T a00 = g00 * R00 + g01 * R10, a01 = g00 * R01 + g01 * R11;
+    const T a10 = g10 * R00 + g11 * R10, a11 = g10 * R01 + g11 * R11;
+    if (valid) {
+        row[0] = x + r * c;
+        row[n] = y + r * s;
+        row[2 * n] = a00 * g00 + a01 * g01;
+        row[3 * n] = a00 * g10 + a01 * g11;
+        row[4 * n] = a10 * g10 + a11 * g11;
+    }
+}
+
+// F2: the 2 x 2 EKF update of one landmark record (`cur`, its 5 values) and the log-weight increment.
+template <typename T>
+__device__ __forceinline__ void lm_update(T* __restrict__ row, int64_t n, const LmRow<T>& cur, T x, T y, T phi, T r, T b, T R00,
+                                          T R10, T R01, T R11, bool valid, T& lw) {
+    const T lx = cur.lx, ly = cur.ly, pxx = cur.pxx, pxy = cur.pxy, pyy = cur.pyy;
+    const T dx = lx - x, dy = ly - y;
+    const T d2 = dx * dx + dy * dy;
+    // fp32: hardware reciprocal square roots (v_rsq_f32, 1 ulp) instead of IEEE sqrt + eight IEEE divisions -- the
+    // kernel's time is one third arithmetic at four waves per SIMD; fp64 keeps the exact operations.
+    T d, h00, h01, h10, h11;
+    if constexpr (sizeof(T) == 4) {
+        const T rd = __builtin_amdgcn_rsqf(d2);
+        d = d2 * rd;
+        const T rd2 = rd * rd;
+        h00 = dx * rd; h01 = dy * rd; h10 = -dy * rd2; h11 = dx * rd2;           // src/common.jl:162
+    } else {
+        d = sqrt(d2);
+        h00 = dx / d; h01 = dy / d; h10 = -dy / d2; h11 = dx / d2;
+    }
+    const T v0 = r - d;                                               // src/ekf.jl:58
+    const T v1 = wrap_pi<T>(b - (atan2(dy, dx) - phi));
+    const T t00 = pxx * h00 + pxy * h01, t01 = pxx * h10 + pxy * h11;  // PHt
+    const T t10 = pxy * h00 + pyy * h01, t11 = pxy * h10 + pyy * h11;
+    const T s00 = h00 * t00 + h01 * t10 + R00;                         // S = Hf PHt + R (:68)
+    const T s01a = h00 * t01 + h01 * t11 + R01;
+    const T s10a = h10 * t00 + h11 * t10 + R10;
+    const T s11 = h10 * t01 + h11 * t11 + R11;
+    const T s01 = (T)0.5 * (s01a + s10a);                             // (:69)
+    T u00, u01, u11, c00, c01, c11;                                   // chol(S) upper (:70), C = inv(U)
+    if constexpr (sizeof(T) == 4) {
+        c00 = __builtin_amdgcn_rsqf(s00);
+        u00 = s00 * c00;
+        u01 = s01 * c00;
+        const T tt = s11 - u01 * u01;
+        c11 = __builtin_amdgcn_rsqf(tt);
+        u11 = tt * c11;
+        c01 = -u01 * (c00 * c11);
+    } else {
+        u00 = sqrt(s00);
+        u01 = s01 / u00;
+        u11 = sqrt(s11 - u01 * u01);
+        c00 = (T)1 / u00; c01 = -u01 / (u00 * u11); c11 = (T)1 / u11;
+    }
+    const T w00 = t00 * c00, w01 = t00 * c01 + t01 * c11;             // W1 = PHt C (:71)
+    const T w10 = t10 * c00, w11 = t10 * c01 + t11 * c11;
+    const T y0 = c00 * v0, y1 = c01 * v0 + c11 * v1;                  // C' v
+    if (valid) {
+        row[0] = lx + w00 * y0 + w01 * y1;                            // x += W v (:72,:74)
+        row[n] = ly + w10 * y0 + w11 * y1;
+        row[2 * n] = pxx - (w00 * w00 + w01 * w01);                   // P -= W1 W1' (:75)
+        row[3 * n] = pxy - (w00 * w10 + w01 * w11);
+        row[4 * n] = pyy - (w10 * w10 + w11 * w11);
+    }
+    lw += (T)-0.5 * (y0 * y0 + y1 * y1) - log(u00 * u11) - (T)1.8378770664093453;   // log(2 pi)
+}
+
 // F1 + F2/F3 (+ F4 partials): one pass over the particle -- predict (PREDICT), the m known-id updates, and
 // (STATS) the block's weight statistics, so that a filter step is ONE sweep of HBM instead of five launches.
 // The record of observation i+1 is requested before observation i is processed (two records in flight per
@@ -246,75 +319,111 @@ __global__ __launch_bounds__(256) void pf_step_kernel(T* __restrict__ pose, T* _
             }
         }
         if (code & NEW_FLAG) {                         // F3: src/ekf.jl:94-103,112 without the pose term
-            const T s = sin(phi + b), c = cos(phi + b);
-            const T g00 = c, g01 = -r * s, g10 = s, g11 = r * c;
-            const T a00 = g00 * R00 + g01 * R10, a01 = g00 * R01 + g01 * R11;
-            const T a10 = g10 * R00 + g11 * R10, a11 = g10 * R01 + g11 * R11;
-            if (valid) {
-                row[0] = x + r * c;
-                row[n] = y + r * s;
-                row[2 * n] = a00 * g00 + a01 * g01;
-                row[3 * n] = a00 * g10 + a01 * g11;
-                row[4 * n] = a10 * g10 + a11 * g11;
-            }
+            lm_init<T>(row, n, x, y, phi, r, b, R00, R10, R01, R11, valid);
             continue;
         }
         if (!have_cur) cur = load_row<T>(row, n);
-        const T lx = cur.lx, ly = cur.ly, pxx = cur.pxx, pxy = cur.pxy, pyy = cur.pyy;
-        const T dx = lx - x, dy = ly - y;
-        const T d2 = dx * dx + dy * dy;
-        // fp32: hardware reciprocal square roots (v_rsq_f32, 1 ulp) instead of IEEE sqrt + eight IEEE divisions -- the
-        // kernel's time is one third arithmetic at four waves per SIMD; fp64 keeps the exact operations.
-        T d, h00, h01, h10, h11;
-        if constexpr (sizeof(T) == 4) {
-            const T rd = __builtin_amdgcn_rsqf(d2);
-            d = d2 * rd;
-            const T rd2 = rd * rd;
-            h00 = dx * rd; h01 = dy * rd; h10 = -dy * rd2; h11 = dx * rd2;           // src/common.jl:162
-        } else {
-            d = sqrt(d2);
-            h00 = dx / d; h01 = dy / d; h10 = -dy / d2; h11 = dx / d2;
-        }
-        const T v0 = r - d;                                               // src/ekf.jl:58
-        const T v1 = wrap_pi<T>(b - (atan2(dy, dx) - phi));
-        const T t00 = pxx * h00 + pxy * h01, t01 = pxx * h10 + pxy * h11;  // PHt
-        const T t10 = pxy * h00 + pyy * h01, t11 = pxy * h10 + pyy * h11;
-        const T s00 = h00 * t00 + h01 * t10 + R00;                         // S = Hf PHt + R (:68)
-        const T s01a = h00 * t01 + h01 * t11 + R01;
-        const T s10a = h10 * t00 + h11 * t10 + R10;
-        const T s11 = h10 * t01 + h11 * t11 + R11;
-        const T s01 = (T)0.5 * (s01a + s10a);                             // (:69)
-        T u00, u01, u11, c00, c01, c11;                                   // chol(S) upper (:70), C = inv(U)
-        if constexpr (sizeof(T) == 4) {
-            c00 = __builtin_amdgcn_rsqf(s00);
-            u00 = s00 * c00;
-            u01 = s01 * c00;
-            const T tt = s11 - u01 * u01;
-            c11 = __builtin_amdgcn_rsqf(tt);
-            u11 = tt * c11;
-            c01 = -u01 * (c00 * c11);
-        } else {
-            u00 = sqrt(s00);
-            u01 = s01 / u00;
-            u11 = sqrt(s11 - u01 * u01);
-            c00 = (T)1 / u00; c01 = -u01 / (u00 * u11); c11 = (T)1 / u11;
-        }
-        const T w00 = t00 * c00, w01 = t00 * c01 + t01 * c11;             // W1 = PHt C (:71)
-        const T w10 = t10 * c00, w11 = t10 * c01 + t11 * c11;
-        const T y0 = c00 * v0, y1 = c01 * v0 + c11 * v1;                  // C' v
-        if (valid) {
-            row[0] = lx + w00 * y0 + w01 * y1;                            // x += W v (:72,:74)
-            row[n] = ly + w10 * y0 + w11 * y1;
-            row[2 * n] = pxx - (w00 * w00 + w01 * w01);                   // P -= W1 W1' (:75)
-            row[3 * n] = pxy - (w00 * w10 + w01 * w11);
-            row[4 * n] = pyy - (w10 * w10 + w11 * w11);
-        }
-        lw += (T)-0.5 * (y0 * y0 + y1 * y1) - log(u00 * u11) - (T)1.8378770664093453;   // log(2 pi)
+        lm_update<T>(row, n, cur, x, y, phi, r, b, R00, R10, R01, R11, valid, lw);
     }
     if (valid) logw[p] = lw;
     // (folding the partials in the last workgroup to finish was tried: its agent-scope release/acquire is an L2
     //  write-back + invalidate on this multi-XCD part and doubled the kernel's time; a 1-workgroup fold kernel follows)
     if (STATS) block_weight_stats<T>(lw, x, y, phi, valid, 1, part);
+}
+
+// ---- N4: unknown correspondences --------------------------------------------------------------------
+// Per-particle gated nearest neighbour over the particle's OWN landmark slots (a slot with Pxx < 0 holds no
+// landmark): the rule of associate() (src/data-association.jl:1-51 in the order-independent form of SURVEY 3.2)
+// with compute_association() (:53-63) restricted to the landmark's 2 x 2 block.  One thread per particle.
+// Pass 1 sweeps the slots ONCE (coalesced: the particle index is the fastest one) and keeps, for each of the
+// m <= UNK_MAX observations, the best candidate in registers; all observations are associated against the map as
+// it is BEFORE this step's updates.  Pass 2 applies them in observation order: matched -> lm_update on that slot,
+// new -> lm_init in the particle's lowest unused slot (none left: dropped).
+constexpr int UNK_MAX = 16;
+
+template <typename T>
+__global__ __launch_bounds__(256) void pf_update_unknown_kernel(const T* __restrict__ pose, T* __restrict__ lm,
+                                                                 T* __restrict__ logw, int64_t n, int nl,
+                                                                 const double* __restrict__ z, int m, T R00, T R10, T R01,
+                                                                 T R11, T gate1, T gate2, T pend,
+                                                                 int32_t* __restrict__ assoc_out) {
+    __shared__ double s_obs[2 * UNK_MAX];
+    for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) s_obs[i] = z[i];
+    __syncthreads();
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const T x = pose[p], y = pose[n + p], phi = pose[2 * n + p];
+    T lw = logw[p] - pend;
+    const T INF = (T)__builtin_inf();
+    T best_nd[UNK_MAX];
+    int best_l[UNK_MAX];
+    unsigned near = 0u;
+#pragma unroll
+    for (int i = 0; i < UNK_MAX; ++i) { best_nd[i] = INF; best_l[i] = -1; }
+    for (int l = 0; l < nl; ++l) {
+        const T* row = lm + (size_t)l * 5 * n + p;
+        const T pxx = row[2 * n];
+        if (pxx < (T)0) continue;
+        const T lx = row[0], ly = row[n], pxy = row[3 * n], pyy = row[4 * n];
+        const T dx = lx - x, dy = ly - y;
+        const T d2 = dx * dx + dy * dy;
+        const T d = sqrt(d2);
+        const T zp1 = atan2(dy, dx) - phi;
+        const T h00 = dx / d, h01 = dy / d, h10 = -dy / d2, h11 = dx / d2;      // src/common.jl:162
+        const T t00 = pxx * h00 + pxy * h01, t01 = pxx * h10 + pxy * h11;
+        const T t10 = pxy * h00 + pyy * h01, t11 = pxy * h10 + pyy * h11;
+        const T s00 = h00 * t00 + h01 * t10 + R00;                              // S = Hf Pf Hf' + R (:59), not symmetrised
+        const T s01 = h00 * t01 + h01 * t11 + R01;
+        const T s10 = h10 * t00 + h11 * t10 + R10;
+        const T s11 = h10 * t01 + h11 * t11 + R11;
+        const T det = s00 * s11 - s01 * s10;
+        const T rdet = (T)1 / det;
+        const T qa = s11 * rdet, qb = -(s01 + s10) * rdet, qc = s00 * rdet;
+        const T logdet = log(det);
+#pragma unroll
+        for (int i = 0; i < UNK_MAX; ++i) {
+            if (i < m) {
+                const T v0 = (T)s_obs[2 * i] - d;
+                const T v1 = wrap_pi<T>((T)s_obs[2 * i + 1] - zp1);              // :57
+                const T nis = qa * v0 * v0 + qb * v0 * v1 + qc * v1 * v1;        // :60
+                const T nd = nis + logdet;                                       // :61
+                if (nis < gate1 && nd < best_nd[i]) { best_nd[i] = nd; best_l[i] = l; }     // strict: lowest slot wins a tie
+                if (nis <= gate2) near |= 1u << i;
+            }
+        }
+    }
+    int next_free = 0;                                   // unused slots are handed out in ascending order
+#pragma unroll
+    for (int i = 0; i < UNK_MAX; ++i) {
+        if (i < m) {
+            const int a = best_l[i] >= 0 ? best_l[i] : (((near >> i) & 1u) ? -2 : -1);
+            if (assoc_out) assoc_out[(size_t)i * n + p] = a;
+            const T r = (T)s_obs[2 * i], b = (T)s_obs[2 * i + 1];
+            if (a >= 0) {
+                T* row = lm + (size_t)a * 5 * n + p;
+                const LmRow<T> cur = load_row<T>(row, n);
+                lm_update<T>(row, n, cur, x, y, phi, r, b, R00, R10, R01, R11, true, lw);
+            } else if (a == -1) {
+                int slot = next_free;
+                while (slot < nl && !(lm[((size_t)slot * 5 + 2) * n + p] < (T)0)) ++slot;
+                if (slot < nl) {
+                    lm_init<T>(lm + (size_t)slot * 5 * n + p, n, x, y, phi, r, b, R00, R10, R01, R11, true);
+                    next_free = slot + 1;
+                }
+            }
+        }
+    }
+    logw[p] = lw;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pf_clear_lm_kernel(T* __restrict__ lm, int64_t n, int nl) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    for (int l = 0; l < nl; ++l) {
+        T* row = lm + (size_t)l * 5 * n + p;
+        row[0] = (T)0; row[n] = (T)0; row[2 * n] = (T)-1; row[3 * n] = (T)0; row[4 * n] = (T)0;
+    }
 }
 
 // ---- F4: reductions ------------------------------------------------------------------------------
@@ -842,6 +951,49 @@ extern "C" int slam_pf_step(slam_pf_t h, double V, double G, double wheelbase, c
     if ((rc = pf_fold_and_read(h, 1, s))) return rc;
     out[0] = s[0]; out[1] = s[1]; out[2] = s[2];
     return SLAM_OK;
+}
+
+/* N4.  Every landmark slot of every particle unused (Pxx = -1 marks "no landmark here"). */
+extern "C" int slam_pf_clear_landmarks(slam_pf_t h) {
+    ARG_CHECK(h != nullptr, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    PF_DISPATCH(h,
+                hipLaunchKernelGGL(pf_clear_lm_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->lm[h->cur], h->n, h->nl),
+                hipLaunchKernelGGL(pf_clear_lm_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->lm[h->cur], h->n, h->nl));
+    HIP_TRY(hipGetLastError());
+    for (int l = 0; l < h->nl; ++l) h->seen[l] = 0;
+    return SLAM_OK;
+}
+
+/* N4.  m <= 16 (range, bearing) pairs with UNKNOWN correspondences: every particle associates them with its own
+ * landmarks (gates as in associate(), src/data-association.jl:1-51), updates the matched ones, starts new landmarks
+ * in its lowest unused slots.  d_assoc (device, [m][n] int32, may be NULL) receives the decisions: slot >= 0
+ * matched, -1 new, -2 dropped.  Enqueued. */
+extern "C" int slam_pf_update_unknown(slam_pf_t h, const double* z, int m, const double R[4], double gate1, double gate2,
+                                      int32_t* d_assoc) {
+    ARG_CHECK(h != nullptr, "null handle");
+    ARG_CHECK(m >= 0 && m <= UNK_MAX, "slam_pf_update_unknown takes at most 16 observations per call");
+    if (m == 0) return SLAM_OK;
+    ARG_CHECK(z != nullptr && R != nullptr, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    // the observation list goes through a staging slot like the known-id path (ids unused)
+    std::vector<int32_t> ones((size_t)m, 1);
+    std::vector<char> seen_backup(h->seen);
+    const double* dz;
+    const int32_t* di;
+    int rc = pf_stage(h, z, ones.data(), m, &dz, &di);
+    h->seen = seen_backup;                           // (pf_stage marks ids as seen: not meaningful here)
+    if (rc) return rc;
+    const double pend = pf_take_pending(h);
+    PF_DISPATCH(h,
+                hipLaunchKernelGGL(pf_update_unknown_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream,
+                                   (const T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->nl, dz, m, (T)R[0], (T)R[1],
+                                   (T)R[2], (T)R[3], (T)gate1, (T)gate2, (T)pend, d_assoc),
+                hipLaunchKernelGGL(pf_update_unknown_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream,
+                                   (const T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->nl, dz, m, (T)R[0], (T)R[1],
+                                   (T)R[2], (T)R[3], (T)gate1, (T)gate2, (T)pend, d_assoc));
+    HIP_TRY(hipGetLastError());
+    return pf_stage_done(h);
 }
 
 /* slam_pf_step followed by slam_pf_normalize with the shard's OWN statistics, for a filter that lives on one GPU

@@ -101,6 +101,30 @@ class PFShard:
         r = _small(R)
         check(lib.slam_pf_update_known(self._h, _ptr(zp), _ptr(idv, C.c_int32), zp.shape[0], _ptr(r)))
 
+    def clear_landmarks(self):
+        """Every landmark slot of every particle unused (the start of an unknown-correspondence run)."""
+        check(lib.slam_pf_clear_landmarks(self._h))
+
+    def update_unknown(self, z, R, gate1, gate2, want_assoc=False):
+        """Unknown correspondences: per-particle gated nearest-neighbour association against the
+        particle's own landmarks, then updates / new landmarks.  ``want_assoc``: return the decisions as an
+        int32 torch tensor [m, n] on the device (slot >= 0 matched, -1 new, -2 dropped)."""
+        zp = _obs(z)
+        m = zp.shape[0]
+        if m == 0:
+            return None
+        r = _small(R)
+        assoc = None
+        ptr = None
+        if want_assoc:
+            import torch
+            assoc = torch.empty((m, self.n), dtype=torch.int32, device=self.device)
+            ptr = C.c_void_p(assoc.data_ptr())
+        check(lib.slam_pf_update_unknown(self._h, _ptr(zp), m, _ptr(r), float(gate1), float(gate2), ptr))
+        if want_assoc:
+            self.sync()
+        return assoc
+
     def weight_stats(self):
         out = np.empty(3)
         check(lib.slam_pf_weight_stats(self._h, _ptr(out)))

@@ -251,3 +251,50 @@ def test_full_size_config4_properties(pkg):
     pf.shard.resample_apply(ident, None, None)
     assert np.array_equal(pf.shard.download(landmarks=False)[0], before)
     pf.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_unknown_correspondences_against_oracle(pkg, dtype):
+    """per-particle gated nearest-neighbour association over each particle's own landmark slots,
+    then updates / new landmarks (slam_pf_update_unknown), against the oracle.  The run starts from an empty map
+    (every observation is new), revisits landmarks (matched), adds more later, overflows the slot capacity
+    (dropped) and includes an observation inside the outer but outside the inner gate (dropped).  Decisions must be
+    identical in fp64; in fp32 the geometry is evaluated in fp32, so a vanishing fraction may flip at a gate."""
+    n, nslots, seed = 1500 + 13, 6, 11
+    lm = np.array([[12.0, 3.0], [6.0, -9.0], [-10.0, 4.0], [15.0, -2.0], [-4.0, -12.0], [9.0, 11.0], [-13.0, -6.0]])
+    sh = pkg.PFShard(n, nslots, seed, dtype=dtype)
+    orc = F.OraclePF(n, nslots, seed)
+    for f in (sh, orc):
+        f.set_pose([0.5, -0.5, 0.3])
+        f.clear_landmarks()
+    rng = np.random.default_rng(5)
+    pose = np.array([0.5, -0.5, 0.3])
+    tol = TOL[dtype]
+    plan = [[1, 2], [2, 1, 3], [1, 3, 4, 2], [5, 1], [6, 2, 3], [7, 4, 6]]          # 7 > 6 slots: the last new one is dropped
+    agree = total = 0
+    for t, ids in enumerate(plan):
+        for f in (sh, orc):
+            f.predict(3.0, 0.02 * t, 4.0, Q, 0.1)
+        pose = np.array([pose[0] + 0.3 * math.cos(0.02 * t + pose[2]), pose[1] + 0.3 * math.sin(0.02 * t + pose[2]),
+                         pose[2] + 0.3 * math.sin(0.02 * t) / 4.0])
+        z = observe(lm, pose, np.array(ids), rng)
+        if t == 3:
+            z = np.hstack([z, z[:, 1:2] + np.array([[0.35], [0.0]])])      # 3.5 sigma off in range: inside gate2 only
+        a = sh.update_unknown(z, R, 4.0, 25.0, want_assoc=True).cpu().numpy()
+        ao = orc.update_unknown(z, R, 4.0, 25.0)
+        agree += int(np.sum(a == ao))
+        total += a.size
+        if dtype == "f64":
+            assert np.array_equal(a, ao), f"step {t}"
+        same = np.all(a == ao, axis=0)                    # compare the state where the decisions agree
+        pose_g, logw_g, lm_g = sh.download()
+        assert close(pose_g[:, same], orc.pose[:, same], tol, scale=20.0)
+        used_o = orc.lm[:, 2, :] >= 0
+        assert np.array_equal((lm_g[:, 2, :] >= 0)[:, same], used_o[:, same])
+        mask = used_o[:, None, :] & same[None, None, :]
+        mask = np.broadcast_to(mask, orc.lm.shape)
+        assert close(np.where(mask, lm_g, 0.0), np.where(mask, orc.lm, 0.0), 10 * tol, scale=20.0)
+        assert close(logw_g[same], orc.logw[same], 10 * tol, scale=max(1.0, float(np.max(np.abs(orc.logw)))))
+    assert agree >= 0.999 * total
+    assert int((orc.lm[:, 2, :] >= 0).sum(axis=0).max()) == nslots          # the capacity was reached
+    sh.close()
