@@ -381,6 +381,18 @@ class FastSLAM:
             self.resample()
         return neff, bool(do)
 
+    def step_unknown(self, V, G, wheelbase, Q, dt, z, R, gate1, gate2, force_resample=None):
+        """The filter step with UNKNOWN correspondences: predict, per-particle gated nearest-neighbour
+        association + updates / new landmarks, normalise, (Neff-triggered) resample.  Returns (Neff, resampled?).
+        Resampling copies whole particle records, unused landmark slots included, so it needs no change."""
+        self.predict(V, G, wheelbase, Q, dt)
+        self.shard.update_unknown(z, R, gate1, gate2)
+        neff = self.normalize()
+        do = force_resample if force_resample is not None else (neff < self.neff_frac * self.shard.n_global)
+        if do:
+            self.resample()
+        return neff, bool(do)
+
     def mean_pose(self):
         s = self.comm.allreduce_sum(list(self.shard.mean_pose_sums()))
         return np.array([s[0], s[1], math.atan2(s[2], s[3])])       # weights are normalised: sums are means

@@ -18,6 +18,8 @@ class NumpyShard:
     def init_landmarks(self, xy, var, jit): self.o.init_landmarks(xy, var, jit)
     def predict(self, V, G, w, Q, dt): self.o.predict(V, G, w, Q, dt)
     def update_known(self, z, ids, R): self.o.update_known(z, ids, R)
+    def clear_landmarks(self): self.o.clear_landmarks()
+    def update_unknown(self, z, R, gate1, gate2, want_assoc=False): return self.o.update_unknown(z, R, gate1, gate2)
     def weight_stats(self): return self.o.weight_stats()
     def normalize(self, gmax, gsum): self.o.normalize(gmax, gsum)
     def mean_pose_sums(self): return self.o.mean_pose_sums()

@@ -223,6 +223,38 @@ def test_driver_end_to_end_against_oracle(pkg, dtype):
     gpu.shard.close()
 
 
+def test_unknown_correspondence_driver_against_oracle(pkg):
+    """FastSLAM.step_unknown (predict + per-particle association + updates + normalise + resample) on one GPU vs
+    the oracle driven through the same host logic; fp64 so that the decisions are identical."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    from pf_numpy_shard import NumpyShard
+    n, nslots, seed = 2048, 8, 41
+    lm = np.array([[12.0, 3.0], [6.0, -9.0], [-10.0, 4.0], [15.0, -2.0], [-4.0, -12.0], [9.0, 11.0]])
+    gpu = pkg.FastSLAM(pkg.PFShard(n, nslots, seed, dtype="f64"), None)
+    cpu = pkg.FastSLAM(NumpyShard(n, nslots, seed), None)
+    for f in (gpu, cpu):
+        f.shard.set_pose([0.0, 0.0, 0.2])
+        f.shard.clear_landmarks()
+    rng = np.random.default_rng(3)
+    pose = np.array([0.0, 0.0, 0.2])
+    for t in range(7):
+        pose = np.array([pose[0] + 0.3 * math.cos(0.02 + pose[2]), pose[1] + 0.3 * math.sin(0.02 + pose[2]),
+                         pose[2] + 0.3 * math.sin(0.02) / 4.0])
+        ids = np.array([1 + t % 6, 1 + (t + 2) % 6, 1 + (t + 4) % 6])
+        z = observe(lm, pose, ids, rng)
+        ng, dg = gpu.step_unknown(3.0, 0.02, 4.0, Q, 0.1, z, R, 4.0, 25.0, force_resample=(t == 4))
+        nc, dc = cpu.step_unknown(3.0, 0.02, 4.0, Q, 0.1, z, R, 4.0, 25.0, force_resample=(t == 4))
+        assert dg == dc and ng == pytest.approx(nc, rel=1e-7)
+        pose_g, logw_g, lm_g = gpu.shard.download()
+        assert np.array_equal(lm_g[:, 2, :] >= 0, cpu.shard.o.lm[:, 2, :] >= 0), f"step {t}: slot usage differs"
+        assert close(pose_g, cpu.shard.o.pose, 1e-9, scale=20.0) and close(logw_g, cpu.shard.o.logw, 1e-8, scale=50.0)
+    gpu.normalize(); cpu.normalize()
+    assert close(gpu.mean_pose(), cpu.mean_pose(), 1e-7, scale=1.0)
+    assert np.hypot(*(gpu.mean_pose()[:2] - pose[:2])) < 1.0
+    gpu.shard.close()
+
+
 def test_full_size_config4_properties(pkg):
     """BASELINE.json config 4 at full size on one GPU: 262144 particles x 512 landmarks, 16 known-id
     observations per step, fp32.  Size-independent properties only."""
