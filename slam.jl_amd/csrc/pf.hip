@@ -842,9 +842,11 @@ static int pf_stage(slam_pf* h, const double* z, const int32_t* ids, int m, cons
     int32_t* hi = h->h_ids + (size_t)slot * h->ocap;
     double* hz = h->h_obs + (size_t)slot * 2 * h->ocap;
     for (int i = 0; i < m; ++i) {
-        const int l = ids[i] - 1;
-        hi[i] = l | (h->seen[l] ? 0 : NEW_FLAG);
-        h->seen[l] = 1;
+        if (ids) {                                       // (ids == nullptr: unknown correspondences, observations only)
+            const int l = ids[i] - 1;
+            hi[i] = l | (h->seen[l] ? 0 : NEW_FLAG);
+            h->seen[l] = 1;
+        }
         hz[2 * i] = z[2 * i];
         hz[2 * i + 1] = z[2 * i + 1];
     }
@@ -976,13 +978,9 @@ extern "C" int slam_pf_update_unknown(slam_pf_t h, const double* z, int m, const
     if (m == 0) return SLAM_OK;
     ARG_CHECK(z != nullptr && R != nullptr, "null argument");
     HIP_TRY(hipSetDevice(h->device));
-    // the observation list goes through a staging slot like the known-id path (ids unused)
-    std::vector<int32_t> ones((size_t)m, 1);
-    std::vector<char> seen_backup(h->seen);
     const double* dz;
     const int32_t* di;
-    int rc = pf_stage(h, z, ones.data(), m, &dz, &di);
-    h->seen = seen_backup;                           // (pf_stage marks ids as seen: not meaningful here)
+    const int rc = pf_stage(h, z, nullptr, m, &dz, &di);      // the observation list goes through a staging slot
     if (rc) return rc;
     const double pend = pf_take_pending(h);
     PF_DISPATCH(h,
