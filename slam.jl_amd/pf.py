@@ -144,7 +144,8 @@ class PFShard:
         return float(out[0]), float(out[1]), float(out[2])
 
     def step_fused_normalized(self, V, G, wheelbase, Q, dt, z, ids, R):
-        """step_fused + normalize with this shard's own statistics (the whole filter lives here): returns Neff."""
+        """step_fused + normalize with this shard's own statistics (the whole filter lives here): returns
+        (Neff, max normalised log-weight)."""
         zp = _obs(z)
         idv = np.ascontiguousarray(np.asarray(ids, dtype=np.int32).reshape(-1))
         if idv.shape[0] != zp.shape[0]:
@@ -153,7 +154,8 @@ class PFShard:
         out = np.empty(4)
         check(lib.slam_pf_step_normalized(self._h, float(V), float(G), float(wheelbase), _ptr(q), float(dt), _ptr(zp),
                                           _ptr(idv, C.c_int32), zp.shape[0], _ptr(r), _ptr(out)))
-        return float(out[3])
+        T = self.np_dtype                          # (neff, largest log-weight after the shift, exactly as stored)
+        return float(out[3]), float(T(out[0]) - T(out[0] + math.log(out[1])))
 
     def normalize(self, gmax, gsum):
         check(lib.slam_pf_normalize(self._h, float(gmax), float(gsum)))
@@ -301,6 +303,7 @@ class FastSLAM:
         self.comm = comm if comm is not None else _SingleProcess()
         self.neff_frac = float(neff_frac)
         self.fused = True                           # use shard.step_fused when the shard offers it
+        self._gmax_norm = None                      # max log-weight after the last normalize() (None: unknown)
         self.resamples = 0
         self.last_neff = float(shard.n_global)
         assert shard.n * self.comm.world == shard.n_global and shard.first == self.comm.rank * shard.n, (
@@ -310,6 +313,7 @@ class FastSLAM:
         self.shard.predict(V, G, wheelbase, Q, dt)
 
     def update_known(self, z, ids, R):
+        self._gmax_norm = None
         self.shard.update_known(z, ids, R)
 
     def global_stats(self, local=None):
@@ -332,6 +336,10 @@ class FastSLAM:
         gmax, gs1, gs2 = self.global_stats(local)
         self.shard.normalize(gmax, gs1)
         self.last_neff = gs1 * gs1 / gs2
+        # the largest log-weight AFTER the shift, exactly as stored (subtracting one constant in the storage type is
+        # monotone, so it is the image of the old maximum): spares resample() a reduction over all weights + a sync
+        T = getattr(self.shard, "np_dtype", np.float64)
+        self._gmax_norm = float(T(gmax) - T(gmax + math.log(gs1)))
         return self.last_neff
 
     def resample(self):
@@ -340,7 +348,8 @@ class FastSLAM:
         sh, comm = self.shard, self.comm
         u0 = philox_uniform(self.resamples, STREAM_RESAMPLE, sh.seed)
         logw_all = comm.all_gather(sh.logw_tensor(), sh.n_global)      # the all-gather of log-weights
-        gmax = float(logw_all.max().item())
+        gmax = self._gmax_norm if self._gmax_norm is not None else float(logw_all.max().item())
+        self._gmax_norm = None
         anc = sh.ancestors(logw_all, gmax, u0)                          # global ancestor id per local slot, ascending
         if comm.world == 1:                                             # every ancestor is local: nothing to exchange
             sh.resample_apply(anc, None, None)
@@ -368,8 +377,10 @@ class FastSLAM:
         """predict + known-id updates + normalise + (Neff-triggered) resample.  Returns (Neff, resampled?)."""
         fused = getattr(self.shard, "step_fused", None) if self.fused else None
         local = getattr(self.shard, "step_fused_normalized", None) if (self.fused and self.comm.world == 1) else None
+        self._gmax_norm = None
         if local is not None:                       # the whole filter on one GPU: one library call per step
-            neff = self.last_neff = local(V, G, wheelbase, Q, dt, z, ids, R)
+            neff, self._gmax_norm = local(V, G, wheelbase, Q, dt, z, ids, R)
+            self.last_neff = neff
         elif fused is not None:                     # one sweep over the particles instead of five launches
             neff = self.normalize(fused(V, G, wheelbase, Q, dt, z, ids, R))
         else:
@@ -385,6 +396,7 @@ class FastSLAM:
         """The filter step with UNKNOWN correspondences: predict, per-particle gated nearest-neighbour
         association + updates / new landmarks, normalise, (Neff-triggered) resample.  Returns (Neff, resampled?).
         Resampling copies whole particle records, unused landmark slots included, so it needs no change."""
+        self._gmax_norm = None
         self.predict(V, G, wheelbase, Q, dt)
         self.shard.update_unknown(z, R, gate1, gate2)
         neff = self.normalize()

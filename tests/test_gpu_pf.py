@@ -218,6 +218,8 @@ def test_driver_end_to_end_against_oracle(pkg, dtype):
         if dg and dtype == "f32":
             break          # after an fp32 resample individual ancestors may differ at bin edges: stop the element-wise comparison
     gpu.normalize(); cpu.normalize()
+    # the analytically derived maximum of the normalised log-weights (spares resample() a reduction) is EXACT
+    assert gpu._gmax_norm == float(gpu.shard.download(landmarks=False)[1].max())
     assert close(gpu.mean_pose(), cpu.mean_pose(), tol * 100, scale=1.0)
     assert np.hypot(*(gpu.mean_pose()[:2] - pose[:2])) < 0.6
     gpu.shard.close()
