@@ -469,9 +469,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
 // 64 x 64 tile per 256-thread workgroup, wave (wr, wc) owns rows 32 wr.., columns 32 wc.. as 2 x 2 blocks of
 // v_mfma_f64_16x16x4_f64 (exact fp64 FMAs).  Orientation as in the fp32 kernel: D[i][j] with i = COLUMN of P and
 // j = ROW of P, so the 16 lanes of a quarter-wave hold 16 consecutive rows of one column = one 128-byte line.
-// The P tile is requested before the k-loop; at the k of BASELINE.json's fp64 configuration (Joseph form, k_total =
-// 64) a tile needs 2 us of matrix-core time against 13 us of its HBM share, so several resident workgroups per CU
-// are all the overlap this kernel needs.  (The VALU version this replaces was LDS-bound: 12.5 TFLOP/s, 1.7 TB/s.)
+// The P tile is requested before the k-loop; at the k of BASELINE.json's fp64 configuration (Joseph form, two live
+// k-ranges of 16 columns) a tile needs 1 us of matrix-core time against 13 us of its HBM share, so several
+// resident workgroups per CU are all the overlap this kernel needs.  (The VALU version this replaces was LDS-bound: 12.5 TFLOP/s, 1.7 TB/s.)
 constexpr int DT = 64;     // tile edge
 constexpr int DK = 16;     // k-chunk
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -480,12 +480,16 @@ __global__ __launch_bounds__(256) void downdate_f64_mfma(double* __restrict__ P,
                                                          const double* __restrict__ Y, int pitch, int kp,
                                                          const int2* __restrict__ tiles, int L,
                                                          const int32_t* __restrict__ status,
-                                                         const int32_t* __restrict__ dcount, int joseph) {
+                                                         const int32_t* __restrict__ dcount, int joseph, int k16) {
     if (status[0] != 0) return;
+    // Joseph form: X = [K | T], Y = [T | K], each half padded to SLAM_KPAD columns of which only the first
+    // k16 = round_up(k, 16) are non-zero: the k-loop walks the two live ranges and skips the zero padding.
+    int khalf = joseph ? kp / 2 : 0;
     if (dcount) {                     // observe(): the host's kp is an upper bound
         const int k = 2 * dcount[0];
-        kp = joseph ? 2 * ((k + SLAM_KPAD - 1) / SLAM_KPAD * SLAM_KPAD) : (k + 15) / 16 * 16;
-        if (kp == 0) return;
+        if (k == 0) return;
+        k16 = (k + 15) / 16 * 16;
+        khalf = joseph ? (k + SLAM_KPAD - 1) / SLAM_KPAD * SLAM_KPAD : 0;
     }
     const int2 tile = tiles[(size_t)(blockIdx.x & 7) * L + (blockIdx.x >> 3)];     // workgroup b -> list b % 8, slot b / 8
     if (tile.x < 0) return;
@@ -512,7 +516,8 @@ __global__ __launch_bounds__(256) void downdate_f64_mfma(double* __restrict__ P,
                 acc[cb][rb][r] = 0.0;
             }
         }
-    for (int kc = 0; kc < kp; kc += DK) {
+    for (int seg = 0; seg <= joseph; ++seg)
+    for (int kc = seg * khalf; kc < seg * khalf + k16; kc += DK) {
         // 64 x 16 elements per panel, 4 per thread, coalesced along k
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -629,7 +634,7 @@ int ensure_tile_order(slam_ekf* h, int T) {
 
 }  // namespace
 
-int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int pitch, const int32_t* dcount, int joseph) {
+int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int pitch, const int32_t* dcount, int joseph, int k16) {
     const int n = 3 + 2 * h->N;
     const int edge = h->dtype == SLAM_F32 ? TILE : DT;
     const int rc = ensure_tile_order(h, (n + edge - 1) / edge);
@@ -670,7 +675,7 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
     } else {
         hipLaunchKernelGGL(downdate_f64_mfma, dim3(8 * h->tiles_len), dim3(256), 0, h->stream, (double*)h->P, h->ld, n,
                            (const double*)X, (const double*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
-                           h->d_status, dcount, joseph);
+                           h->d_status, dcount, joseph, joseph ? k16 : kp_total);
     }
     HIP_TRY(hipGetLastError());
     return SLAM_OK;

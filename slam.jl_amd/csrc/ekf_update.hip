@@ -20,7 +20,7 @@
 #include "common.h"
 #include "device_math.h"
 
-int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int pitch, const int32_t* dcount, int joseph);   // ekf_syrk.hip
+int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int pitch, const int32_t* dcount, int joseph, int k16);   // ekf_syrk.hip
 
 namespace {
 
@@ -964,7 +964,7 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form, const int32_t*
                                h->gvec, h->d_status, dcount);
     }
     HIP_TRY(hipGetLastError());
-    return launch_downdate(h, kp_total, W1, joseph ? (const void*)W2 : (const void*)W1, pitchW, dcount, joseph ? 1 : 0);
+    return launch_downdate(h, kp_total, W1, joseph ? (const void*)W2 : (const void*)W1, pitchW, dcount, joseph ? 1 : 0, round_up(k, 16));
 }
 
 }  // namespace
