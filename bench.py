@@ -153,7 +153,7 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
     pf.shard.init_landmarks(lm, 0.01, 0.1)
     pose = np.array([0.0, 0.0, 0.3])
     obs = []
-    for t in range(3 * (steps + warmup)):
+    for t in range(4 * (steps + warmup)):
         pose = np.array([pose[0] + 0.2 * math.cos(pose[2]), pose[1] + 0.2 * math.sin(pose[2]), pose[2]])
         ids = (np.arange(M) + M * t) % NL + 1
         dx, dy = lm[ids - 1, 0] - pose[0], lm[ids - 1, 1] - pose[1]
@@ -162,7 +162,9 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
     res = {}
     it = iter(obs)
     import gc
-    for regime, force in (("no_resample", False), ("every_step", True), ("neff_triggered", None)):
+    # (the fourth regime is the FastSLAM-2.0 step of SURVEY 8f N4: the pose drawn from the observation-aware proposal)
+    for regime, force, prop in (("no_resample", False, False), ("every_step", True, False), ("neff_triggered", None, False),
+                                ("proposal_no_resample", False, True)):
         gc.collect()                       # parked until the end of the timed region (see main)
         gc.disable()
         # untimed device warm-up in the regime's own mode (a GPU out of idle needs ~40 ms of load to reach its
@@ -170,22 +172,22 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
         t_pw, n_pw = time.perf_counter(), 0
         while world == 1 and time.perf_counter() - t_pw < 0.08:
             z, ids = obs[n_pw % len(obs)]
-            pf.step(8.0, 0.0, 4.0, Q, 0.025, z, ids, R, force_resample=force)
+            pf.step(8.0, 0.0, 4.0, Q, 0.025, z, ids, R, force_resample=force, proposal=prop)
             n_pw += 1
         for _ in range(30 if world > 1 else 0):        # (multi-rank: a fixed count keeps the ranks' collectives aligned)
             z, ids = obs[n_pw % len(obs)]
-            pf.step(8.0, 0.0, 4.0, Q, 0.025, z, ids, R, force_resample=force)
+            pf.step(8.0, 0.0, 4.0, Q, 0.025, z, ids, R, force_resample=force, proposal=prop)
             n_pw += 1
         for _ in range(warmup):
             z, ids = next(it)
-            pf.step(8.0, 0.0, 4.0, Q, 0.025, z, ids, R, force_resample=force)
+            pf.step(8.0, 0.0, 4.0, Q, 0.025, z, ids, R, force_resample=force, proposal=prop)
         pf.shard.sync()
         fence()
         t0 = time.perf_counter()
         nres = 0
         for _ in range(steps):
             z, ids = next(it)
-            _neff, did = pf.step(8.0, 0.0, 4.0, Q, 0.025, z, ids, R, force_resample=force)
+            _neff, did = pf.step(8.0, 0.0, 4.0, Q, 0.025, z, ids, R, force_resample=force, proposal=prop)
             nres += int(did)
         pf.shard.sync()
         fence()

@@ -211,6 +211,16 @@ int slam_pf_update_unknown(slam_pf_t h, const double* z, int m, const double R[4
  * and slam_pf_weight_stats in one kernel (same particles bit for bit; out as slam_pf_weight_stats).  Synchronises. */
 int slam_pf_step(slam_pf_t h, double V, double G, double wheelbase, const double Q[4], double dt,
                  const double* z, const int32_t* ids, int m, const double R[4], double out[3]);
+/* SURVEY 8f N4 (no reference code): the FastSLAM-2.0 step -- slam_pf_step with the pose drawn from the proposal that
+ * already knows this step's observations (Montemerlo et al. 2003).  The proposal lives in control space: pose =
+ * f(pose, V + u0, G + u1) (src/ekf.jl:39-41) with u = chol(Q) w, w ~ N(0, I) a priori; every observation of a
+ * landmark the particle already holds is assimilated as a linear 2 x 2 measurement of w (Jacobians
+ * src/common.jl:161-162 and src/ekf.jl:27-29, Cholesky form of src/ekf.jl:67-75) and its predictive density goes
+ * into the weight; w is then sampled with the same two normals slam_pf_step uses, and the landmarks are updated
+ * from the sampled pose with the weight left alone.  Q: any symmetric positive definite 2 x 2 matrix.  With
+ * m == 0 it is slam_pf_step bit for bit.  Same statistics in out.  Synchronises. */
+int slam_pf_step_proposal(slam_pf_t h, double V, double G, double wheelbase, const double Q[4], double dt,
+                          const double* z, const int32_t* ids, int m, const double R[4], double out[3]);
 /* slam_pf_step + slam_pf_normalize with the shard's own statistics, for a filter on ONE GPU (n == n_global):
  * one library call per filter step.  out = {max logw, sum, sum2, Neff}. */
 int slam_pf_step_normalized(slam_pf_t h, double V, double G, double wheelbase, const double Q[4], double dt,

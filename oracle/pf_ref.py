@@ -1,4 +1,4 @@
-"""oracle/pf_ref.py -- CPU restatement of the FastSLAM-1.0 particle path (known correspondences).
+"""oracle/pf_ref.py -- CPU restatement of the FastSLAM particle path (1.0, unknown correspondences, 2.0 proposal).
 
 TEST INFRASTRUCTURE ONLY (see oracle/ekf_ref.py for the rules).
 
@@ -193,6 +193,109 @@ class OraclePF:
             self.lm[l, 4] = pyy - (w10 * w10 + w11 * w11)
             # w *= exp(-nis/2) / (2 pi sqrt(det S));  nis = y'y,  sqrt(det S) = u00*u11
             self.logw = self.logw - 0.5 * (y0 * y0 + y1 * y1) - np.log(u00 * u11) - math.log(2 * math.pi)
+
+    # N4: FastSLAM-2.0 proposal -------------------------------------------------------------------
+    def step_proposal(self, V, G, wheelbase, Q, dt, z, ids, R):
+        """One FastSLAM-2.0 step (Montemerlo et al. 2003; no reference code): the pose is drawn from
+        the proposal that already knows this step's observations of landmarks the particle holds.
+
+        The proposal lives in CONTROL space: pose = f(pose, V + u0, G + u1) with the motion model of
+        src/ekf.jl:39-41 and u = Lq w, Lq = chol(Q) (lower), w ~ N(0, I) a priori (sim/sim-utils.jl:35-38).
+        Around w = 0 the pose moves by GL w with GL = Gu Lq (Gu: src/ekf.jl:27-29), so observation i of a landmark
+        with 2 x 2 block (Hf, Pf) (src/common.jl:161-162) is a linear measurement of w,
+            v_i = z_i - h(f(pose, V, G)) = B_i w + noise,  B_i = Hv_i GL,  noise ~ N(0, Sf_i),  Sf_i = Hf Pf Hf' + R,
+        assimilated one after the other in the Cholesky form of src/ekf.jl:67-75 (2 x 2 throughout).  The weight is
+        the product of the predictive densities N(v_i - B_i mu; 0, B_i Sig B_i' + Sf_i); then w = mu + chol(Sig) e
+        with the SAME two normals FastSLAM-1.0's predict would use, the pose follows from the exact motion model,
+        and the landmarks are updated from that pose as in update_known (weights untouched).  First sightings
+        say nothing about the pose; they are initialised from the sampled pose.  Without observations the step
+        is FastSLAM-1.0's predict, bit for bit."""
+        Q = np.asarray(Q, dtype=np.float64)
+        R = np.asarray(R, dtype=np.float64)
+        z = np.asarray(z, dtype=np.float64).reshape(2, -1)
+        ids = np.asarray(ids).reshape(-1)
+        x, y, phi = self.pose
+        lq00 = math.sqrt(Q[0, 0])
+        lq10 = 0.5 * (Q[0, 1] + Q[1, 0]) / lq00
+        lq11 = math.sqrt(Q[1, 1] - lq10 * lq10)
+        # motion mean (u = 0) and GL = Gu Lq
+        s, c = np.sin(G + phi), np.cos(G + phi)
+        vts, vtc = V * dt * s, V * dt * c
+        xm, ym = x + vtc, y + vts
+        pm = _wrap(phi + V * dt * math.sin(G) / wheelbase)
+        gu20, gu21 = dt * math.sin(G) / wheelbase, V * dt * math.cos(G) / wheelbase
+        gl00, gl01 = dt * c * lq00 + (-vts) * lq10, (-vts) * lq11
+        gl10, gl11 = dt * s * lq00 + vtc * lq10, vtc * lq11
+        gl20, gl21 = gu20 * lq00 + gu21 * lq10, gu21 * lq11
+        mu0 = np.zeros(self.n)
+        mu1 = np.zeros(self.n)
+        g00 = np.ones(self.n)
+        g01 = np.zeros(self.n)
+        g11 = np.ones(self.n)
+        logw = self.logw
+        for i, l1 in enumerate(ids):
+            l = int(l1) - 1
+            if not self.seen[l]:
+                continue
+            r, b = z[0, i], z[1, i]
+            lx, ly, pxx, pxy, pyy = self.lm[l]
+            dx, dy = lx - xm, ly - ym
+            d2 = dx * dx + dy * dy
+            d = np.sqrt(d2)
+            h00, h01, h10, h11 = dx / d, dy / d, -dy / d2, dx / d2
+            b00 = -(h00 * gl00 + h01 * gl10)
+            b01 = -(h00 * gl01 + h01 * gl11)
+            b10 = -(h10 * gl00 + h11 * gl10) - gl20
+            b11 = -(h10 * gl01 + h11 * gl11) - gl21
+            v0 = (r - d) - (b00 * mu0 + b01 * mu1)
+            v1 = _wrap(b - (np.arctan2(dy, dx) - pm)) - (b10 * mu0 + b11 * mu1)
+            # Sf = Hf Pf Hf' + R, symmetrised
+            t00 = pxx * h00 + pxy * h01
+            t01 = pxx * h10 + pxy * h11
+            t10 = pxy * h00 + pyy * h01
+            t11 = pxy * h10 + pyy * h11
+            f00 = h00 * t00 + h01 * t10 + R[0, 0]
+            f01 = 0.5 * ((h00 * t01 + h01 * t11 + R[0, 1]) + (h10 * t00 + h11 * t10 + R[1, 0]))
+            f11 = h10 * t01 + h11 * t11 + R[1, 1]
+            # T = Sig B', S = B T + Sf
+            q00 = g00 * b00 + g01 * b01
+            q01 = g00 * b10 + g01 * b11
+            q10 = g01 * b00 + g11 * b01
+            q11 = g01 * b10 + g11 * b11
+            s00 = b00 * q00 + b01 * q10 + f00
+            s01 = 0.5 * ((b00 * q01 + b01 * q11 + f01) + (b10 * q00 + b11 * q10 + f01))
+            s11 = b10 * q01 + b11 * q11 + f11
+            u00 = np.sqrt(s00)
+            u01 = s01 / u00
+            u11 = np.sqrt(s11 - u01 * u01)
+            c00, c01, c11 = 1.0 / u00, -u01 / (u00 * u11), 1.0 / u11
+            w00 = q00 * c00
+            w01 = q00 * c01 + q01 * c11
+            w10 = q10 * c00
+            w11 = q10 * c01 + q11 * c11
+            y0 = c00 * v0
+            y1 = c01 * v0 + c11 * v1
+            mu0 = mu0 + (w00 * y0 + w01 * y1)
+            mu1 = mu1 + (w10 * y0 + w11 * y1)
+            g00 = g00 - (w00 * w00 + w01 * w01)
+            g01 = g01 - (w00 * w10 + w01 * w11)
+            g11 = g11 - (w10 * w10 + w11 * w11)
+            logw = logw - 0.5 * (y0 * y0 + y1 * y1) - np.log(u00 * u11) - math.log(2 * math.pi)
+        # sample w ~ N(mu, Sig), the control, the pose
+        e1, e2 = normals2(self.gids, self.step, STREAM_PREDICT, self.seed)
+        l00 = np.sqrt(g00)
+        l10 = g01 / l00
+        l11 = np.sqrt(g11 - l10 * l10)
+        w0 = mu0 + l00 * e1
+        w1 = mu1 + l10 * e1 + l11 * e2
+        Vn = V + lq00 * w0
+        Gn = G + (lq10 * w0 + lq11 * w1)
+        self.pose = np.stack([x + Vn * dt * np.cos(Gn + phi), y + Vn * dt * np.sin(Gn + phi),
+                              _wrap(phi + Vn * dt * np.sin(Gn) / wheelbase)])
+        self.step += 1
+        # landmark updates / first sightings from the sampled pose; the weights stay as computed above
+        self.update_known(z, ids, R)
+        self.logw = logw
 
     # N4: unknown correspondences -----------------------------------------------------------------
     def clear_landmarks(self):

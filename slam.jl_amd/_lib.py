@@ -100,6 +100,7 @@ SIGNATURES = {
     "slam_pf_clear_landmarks": (C.c_int, [_h]),
     "slam_pf_update_unknown": (C.c_int, [_h, _dp, C.c_int, _dp, C.c_double, C.c_double, C.c_void_p]),
     "slam_pf_step": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, _dp, C.c_double, _dp, _ip, C.c_int, _dp, _dp]),
+    "slam_pf_step_proposal": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, _dp, C.c_double, _dp, _ip, C.c_int, _dp, _dp]),
     "slam_pf_step_normalized": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, _dp, C.c_double, _dp, _ip, C.c_int, _dp,
                                           _dp]),
     "slam_pf_weight_stats": (C.c_int, [_h, _dp]),

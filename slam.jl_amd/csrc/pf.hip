@@ -153,7 +153,9 @@ __global__ __launch_bounds__(256) void pf_init_lm_kernel(T* __restrict__ lm, int
 }
 
 // ---- F2 / F3 -------------------------------------------------------------------------------------
-constexpr int32_t NEW_FLAG = 1 << 30;
+constexpr int32_t NEW_FLAG = 1 << 30;       // observation code: first sighting of this landmark
+constexpr int32_t FRESH_FLAG = 1 << 29;     // a further observation of a landmark first seen in the SAME call
+constexpr int32_t ID_MASK = FRESH_FLAG - 1;
 
 // One landmark record of one particle (5 strided values).
 template <typename T>
@@ -263,10 +265,46 @@ __device__ __forceinline__ void lm_update(T* __restrict__ row, int64_t n, const 
     lw += (T)-0.5 * (y0 * y0 + y1 * y1) - log(u00 * u11) - (T)1.8378770664093453;   // log(2 pi)
 }
 
+// The m known-id observations of one particle at pose (x, y, phi), in order: F2 on a landmark the filter has seen,
+// F3 on a first sighting.  The record of observation i+1 is requested before observation i is processed (two
+// records in flight per particle); a repeat of the same landmark in consecutive observations is re-read after
+// the store instead.
+template <typename T>
+__device__ __forceinline__ void apply_known(T* __restrict__ lm, int64_t n, int64_t p, const double* s_obs, const int32_t* s_ids,
+                                            int m, T x, T y, T phi, T R00, T R10, T R01, T R11, bool valid, T& lw) {
+    LmRow<T> pre = {0, 0, 0, 0, 0};
+    bool have = false;
+    if (m > 0 && !(s_ids[0] & NEW_FLAG)) {
+        pre = load_row<T>(lm + (size_t)(s_ids[0] & ID_MASK) * 5 * n + p, n);
+        have = true;
+    }
+    for (int i = 0; i < m; ++i) {
+        const int32_t code = s_ids[i];
+        const int l = code & ID_MASK;
+        const T r = (T)s_obs[2 * i], b = (T)s_obs[2 * i + 1];
+        T* row = lm + (size_t)l * 5 * n + p;
+        LmRow<T> cur = pre;
+        const bool have_cur = have;
+        have = false;
+        if (i + 1 < m) {
+            const int32_t nc = s_ids[i + 1];
+            const int nl = nc & ID_MASK;
+            if (!(nc & NEW_FLAG) && nl != l) {            // uniform
+                pre = load_row<T>(lm + (size_t)nl * 5 * n + p, n);
+                have = true;
+            }
+        }
+        if (code & NEW_FLAG) {                         // F3: src/ekf.jl:94-103,112 without the pose term
+            lm_init<T>(row, n, x, y, phi, r, b, R00, R10, R01, R11, valid);
+            continue;
+        }
+        if (!have_cur) cur = load_row<T>(row, n);
+        lm_update<T>(row, n, cur, x, y, phi, r, b, R00, R10, R01, R11, valid, lw);
+    }
+}
+
 // F1 + F2/F3 (+ F4 partials): one pass over the particle -- predict (PREDICT), the m known-id updates, and
 // (STATS) the block's weight statistics, so that a filter step is ONE sweep of HBM instead of five launches.
-// The record of observation i+1 is requested before observation i is processed (two records in flight per
-// particle); a repeat of the same landmark in consecutive observations is re-read after the store instead.
 template <typename T, bool PREDICT, bool STATS>
 __global__ __launch_bounds__(256) void pf_step_kernel(T* __restrict__ pose, T* __restrict__ lm, T* __restrict__ logw,
                                                        int64_t n, int64_t first, uint32_t step, uint64_t seed, T V, T G,
@@ -296,39 +334,123 @@ __global__ __launch_bounds__(256) void pf_step_kernel(T* __restrict__ pose, T* _
         if (valid) { pose[p] = x; pose[n + p] = y; pose[2 * n + p] = phi; }
     }
     T lw = logw[p] - pend;        // `pend`: the normalisation shift deferred by slam_pf_normalize (0 if none)
-    LmRow<T> pre = {0, 0, 0, 0, 0};
-    bool have = false;
-    if (m > 0 && !(s_ids[0] & NEW_FLAG)) {
-        pre = load_row<T>(lm + (size_t)(s_ids[0] & (NEW_FLAG - 1)) * 5 * n + p, n);
-        have = true;
-    }
-    for (int i = 0; i < m; ++i) {
-        const int32_t code = s_ids[i];
-        const int l = code & (NEW_FLAG - 1);
-        const T r = (T)s_obs[2 * i], b = (T)s_obs[2 * i + 1];
-        T* row = lm + (size_t)l * 5 * n + p;
-        LmRow<T> cur = pre;
-        const bool have_cur = have;
-        have = false;
-        if (i + 1 < m) {
-            const int32_t nc = s_ids[i + 1];
-            const int nl = nc & (NEW_FLAG - 1);
-            if (!(nc & NEW_FLAG) && nl != l) {            // uniform
-                pre = load_row<T>(lm + (size_t)nl * 5 * n + p, n);
-                have = true;
-            }
-        }
-        if (code & NEW_FLAG) {                         // F3: src/ekf.jl:94-103,112 without the pose term
-            lm_init<T>(row, n, x, y, phi, r, b, R00, R10, R01, R11, valid);
-            continue;
-        }
-        if (!have_cur) cur = load_row<T>(row, n);
-        lm_update<T>(row, n, cur, x, y, phi, r, b, R00, R10, R01, R11, valid, lw);
-    }
+    apply_known<T>(lm, n, p, s_obs, s_ids, m, x, y, phi, R00, R10, R01, R11, valid, lw);
     if (valid) logw[p] = lw;
     // (folding the partials in the last workgroup to finish was tried: its agent-scope release/acquire is an L2
     //  write-back + invalidate on this multi-XCD part and doubled the kernel's time; a 1-workgroup fold kernel follows)
     if (STATS) block_weight_stats<T>(lw, x, y, phi, valid, 1, part);
+}
+
+// ---- N4: FastSLAM-2.0 proposal ------------------------------------------------------------------------
+// One step in which the pose is drawn from the proposal that already knows this step's observations (Montemerlo
+// et al. 2003; no reference code -- SURVEY 8f N4; specified in oracle/pf_ref.py::step_proposal).  The proposal
+// lives in CONTROL space: pose = f(pose, V + u0, G + u1) (src/ekf.jl:39-41), u = Lq w, Lq = chol(Q), w ~ N(0, I)
+// a priori.  Around w = 0 the pose moves by GL w, GL = Gu Lq (Gu: src/ekf.jl:27-29), so an observation of a landmark
+// the particle holds is a linear 2 x 2 measurement of w with noise Sf = Hf Pf Hf' + R: pass 1 assimilates them in
+// the Cholesky form of src/ekf.jl:67-75 and multiplies their predictive densities into the weight, the pose is
+// sampled with the SAME two normals FastSLAM-1.0's predict uses (no observation: the same pose bit for bit), and
+// pass 2 is apply_known from the sampled pose with the weight left alone.  One sweep, records read twice (the
+// second read is an L2 hit for most of them).
+template <typename T>
+__global__ __launch_bounds__(256) void pf_proposal_kernel(T* __restrict__ pose, T* __restrict__ lm, T* __restrict__ logw,
+                                                           int64_t n, int64_t first, uint32_t step, uint64_t seed, T V, T G,
+                                                           T wheelbase, T lq00, T lq10, T lq11, T dt,
+                                                           const double* __restrict__ z, const int32_t* __restrict__ ids,
+                                                           int m, T R00, T R10, T R01, T R11, double* __restrict__ part, T pend) {
+    extern __shared__ double s_obs[];              // [m][2] doubles, then [m] ints
+    int32_t* s_ids = reinterpret_cast<int32_t*>(s_obs + 2 * m);
+    for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) s_obs[i] = z[i];
+    for (int i = threadIdx.x; i < m; i += blockDim.x) s_ids[i] = ids[i];
+    __syncthreads();
+    const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = pi < n;
+    const int64_t p = valid ? pi : n - 1;          // idle lanes shadow the last particle, stores are masked
+    const T x = pose[p], y = pose[n + p], phi = pose[2 * n + p];
+    // motion mean (w = 0) and GL = Gu Lq
+    const T s = sin(G + phi), c = cos(G + phi);
+    const T vts = V * dt * s, vtc = V * dt * c;
+    const T xm = x + vtc, ym = y + vts;
+    const T pm = wrap_pi<T>(phi + V * dt * sin(G) / wheelbase);
+    const T gu20 = dt * sin(G) / wheelbase, gu21 = V * dt * cos(G) / wheelbase;
+    const T gl00 = dt * c * lq00 + (-vts) * lq10, gl01 = (-vts) * lq11;
+    const T gl10 = dt * s * lq00 + vtc * lq10, gl11 = vtc * lq11;
+    const T gl20 = gu20 * lq00 + gu21 * lq10, gl21 = gu21 * lq11;
+    T mu0 = 0, mu1 = 0, g00 = 1, g01 = 0, g11 = 1;
+    T lw = logw[p] - pend;
+    for (int i = 0; i < m; ++i) {
+        const int32_t code = s_ids[i];
+        if (code & (NEW_FLAG | FRESH_FLAG)) continue;  // a landmark first seen in this call says nothing about the pose
+        const T r = (T)s_obs[2 * i], b = (T)s_obs[2 * i + 1];
+        const LmRow<T> cur = load_row<T>(lm + (size_t)code * 5 * n + p, n);
+        const T dx = cur.lx - xm, dy = cur.ly - ym;
+        const T d2 = dx * dx + dy * dy;
+        T d, h00, h01, h10, h11;
+        if constexpr (sizeof(T) == 4) {
+            const T rd = __builtin_amdgcn_rsqf(d2);
+            d = d2 * rd;
+            const T rd2 = rd * rd;
+            h00 = dx * rd; h01 = dy * rd; h10 = -dy * rd2; h11 = dx * rd2;           // src/common.jl:162
+        } else {
+            d = sqrt(d2);
+            h00 = dx / d; h01 = dy / d; h10 = -dy / d2; h11 = dx / d2;
+        }
+        // B = Hv GL with Hv = [-h00 -h01 0; -h10 -h11 -1]  (src/common.jl:161)
+        const T b00 = -(h00 * gl00 + h01 * gl10), b01 = -(h00 * gl01 + h01 * gl11);
+        const T b10 = -(h10 * gl00 + h11 * gl10) - gl20, b11 = -(h10 * gl01 + h11 * gl11) - gl21;
+        const T v0 = (r - d) - (b00 * mu0 + b01 * mu1);
+        const T v1 = wrap_pi<T>(b - (atan2(dy, dx) - pm)) - (b10 * mu0 + b11 * mu1);
+        const T t00 = cur.pxx * h00 + cur.pxy * h01, t01 = cur.pxx * h10 + cur.pxy * h11;      // Pf Hf'
+        const T t10 = cur.pxy * h00 + cur.pyy * h01, t11 = cur.pxy * h10 + cur.pyy * h11;
+        const T f00 = h00 * t00 + h01 * t10 + R00;                                            // Sf, symmetrised
+        const T f01 = (T)0.5 * ((h00 * t01 + h01 * t11 + R01) + (h10 * t00 + h11 * t10 + R10));
+        const T f11 = h10 * t01 + h11 * t11 + R11;
+        const T q00 = g00 * b00 + g01 * b01, q01 = g00 * b10 + g01 * b11;                       // Sig B'
+        const T q10 = g01 * b00 + g11 * b01, q11 = g01 * b10 + g11 * b11;
+        const T s00 = b00 * q00 + b01 * q10 + f00;                                            // S = B Sig B' + Sf
+        const T s01 = (T)0.5 * ((b00 * q01 + b01 * q11 + f01) + (b10 * q00 + b11 * q10 + f01));
+        const T s11 = b10 * q01 + b11 * q11 + f11;
+        T u00, u01, u11, c00, c01, c11;                                                       // chol(S) upper, C = inv(U)
+        if constexpr (sizeof(T) == 4) {
+            c00 = __builtin_amdgcn_rsqf(s00);
+            u00 = s00 * c00;
+            u01 = s01 * c00;
+            const T tt = s11 - u01 * u01;
+            c11 = __builtin_amdgcn_rsqf(tt);
+            u11 = tt * c11;
+            c01 = -u01 * (c00 * c11);
+        } else {
+            u00 = sqrt(s00);
+            u01 = s01 / u00;
+            u11 = sqrt(s11 - u01 * u01);
+            c00 = (T)1 / u00; c01 = -u01 / (u00 * u11); c11 = (T)1 / u11;
+        }
+        const T w00 = q00 * c00, w01 = q00 * c01 + q01 * c11;
+        const T w10 = q10 * c00, w11 = q10 * c01 + q11 * c11;
+        const T y0 = c00 * v0, y1 = c01 * v0 + c11 * v1;
+        mu0 = mu0 + (w00 * y0 + w01 * y1);
+        mu1 = mu1 + (w10 * y0 + w11 * y1);
+        g00 = g00 - (w00 * w00 + w01 * w01);
+        g01 = g01 - (w00 * w10 + w01 * w11);
+        g11 = g11 - (w10 * w10 + w11 * w11);
+        lw += (T)-0.5 * (y0 * y0 + y1 * y1) - log(u00 * u11) - (T)1.8378770664093453;
+    }
+    // w ~ N(mu, Sig), the control, the pose
+    T e1, e2;
+    normals2<T>((uint64_t)(first + p), step, STREAM_PREDICT, seed, e1, e2);
+    const T l00 = sqrt(g00);
+    const T l10 = g01 / l00;
+    const T l11 = sqrt(g11 - l10 * l10);
+    const T w0 = mu0 + l00 * e1;
+    const T w1 = mu1 + l10 * e1 + l11 * e2;
+    const T Vn = V + lq00 * w0;
+    const T Gn = G + (lq10 * w0 + lq11 * w1);
+    const T xn = x + Vn * dt * cos(Gn + phi);         // src/ekf.jl:39-41
+    const T yn = y + Vn * dt * sin(Gn + phi);
+    const T pn = wrap_pi<T>(phi + Vn * dt * sin(Gn) / wheelbase);
+    if (valid) { pose[p] = xn; pose[n + p] = yn; pose[2 * n + p] = pn; logw[p] = lw; }
+    T unused = 0;
+    apply_known<T>(lm, n, p, s_obs, s_ids, m, xn, yn, pn, R00, R10, R01, R11, valid, unused);
+    block_weight_stats<T>(lw, xn, yn, pn, valid, 1, part);
 }
 
 // ---- N4: unknown correspondences --------------------------------------------------------------------
@@ -844,12 +966,14 @@ static int pf_stage(slam_pf* h, const double* z, const int32_t* ids, int m, cons
     for (int i = 0; i < m; ++i) {
         if (ids) {                                       // (ids == nullptr: unknown correspondences, observations only)
             const int l = ids[i] - 1;
-            hi[i] = l | (h->seen[l] ? 0 : NEW_FLAG);
-            h->seen[l] = 1;
+            hi[i] = l | (h->seen[l] == 0 ? NEW_FLAG : h->seen[l] == 2 ? FRESH_FLAG : 0);
+            if (!h->seen[l]) h->seen[l] = 2;             // 2: first seen in this call
         }
         hz[2 * i] = z[2 * i];
         hz[2 * i + 1] = z[2 * i + 1];
     }
+    if (ids)
+        for (int i = 0; i < m; ++i) h->seen[ids[i] - 1] = 1;
     // zero-copy: the kernel reads the pinned slot itself (once per workgroup, into LDS); the caller records the
     // slot's event behind that kernel (pf_stage_done)
     *d_z = h->h_obs_dev + (size_t)slot * 2 * h->ocap;
@@ -946,6 +1070,43 @@ extern "C" int slam_pf_step(slam_pf_t h, double V, double G, double wheelbase, c
                                    (T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
                                    (T)G, (T)wheelbase, (T)sV, (T)sG, (T)dt, dz, di, m, (T)Rz[0], (T)Rz[1], (T)Rz[2], (T)Rz[3],
                                    h->d_part, (T)pend));
+    HIP_TRY(hipGetLastError());
+    if (m && (rc = pf_stage_done(h))) return rc;
+    h->step += 1;
+    double s[7];
+    if ((rc = pf_fold_and_read(h, 1, s))) return rc;
+    out[0] = s[0]; out[1] = s[1]; out[2] = s[2];
+    return SLAM_OK;
+}
+
+/* N4, FastSLAM 2.0: slam_pf_step with the pose drawn from the observation-aware proposal (pf_proposal_kernel).
+ * Same arguments, same statistics; Q may be any symmetric positive definite 2 x 2 matrix (its Cholesky factor
+ * shapes the control noise).  With m == 0 it is slam_pf_step bit for bit. */
+extern "C" int slam_pf_step_proposal(slam_pf_t h, double V, double G, double wheelbase, const double Q[4], double dt,
+                                     const double* z, const int32_t* ids, int m, const double R[4], double out[3]) {
+    ARG_CHECK(h != nullptr && Q != nullptr && out != nullptr, "null argument");
+    double Rz[4] = {0, 0, 0, 0};
+    int rc = pf_check_obs(h, z, ids, m, m ? R : Rz);
+    if (rc) return rc;
+    if (m) for (int i = 0; i < 4; ++i) Rz[i] = R[i];
+    ARG_CHECK(Q[0] > 0.0, "Q is not positive definite");
+    const double lq00 = sqrt(Q[0]), lq10 = 0.5 * (Q[1] + Q[2]) / lq00;
+    ARG_CHECK(Q[3] - lq10 * lq10 > 0.0, "Q is not positive definite");
+    const double lq11 = sqrt(Q[3] - lq10 * lq10);
+    HIP_TRY(hipSetDevice(h->device));
+    const double* dz = h->h_obs_dev;
+    const int32_t* di = h->h_ids_dev;
+    if (m && (rc = pf_stage(h, z, ids, m, &dz, &di))) return rc;
+    const double pend = pf_take_pending(h);
+    PF_DISPATCH(h,
+                hipLaunchKernelGGL(pf_proposal_kernel<T>, dim3(grid_for(h->n)), dim3(256), (size_t)m * 20, h->stream,
+                                   (T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
+                                   (T)G, (T)wheelbase, (T)lq00, (T)lq10, (T)lq11, (T)dt, dz, di, m, (T)Rz[0], (T)Rz[1], (T)Rz[2],
+                                   (T)Rz[3], h->d_part, (T)pend),
+                hipLaunchKernelGGL(pf_proposal_kernel<T>, dim3(grid_for(h->n)), dim3(256), (size_t)m * 20, h->stream,
+                                   (T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
+                                   (T)G, (T)wheelbase, (T)lq00, (T)lq10, (T)lq11, (T)dt, dz, di, m, (T)Rz[0], (T)Rz[1], (T)Rz[2],
+                                   (T)Rz[3], h->d_part, (T)pend));
     HIP_TRY(hipGetLastError());
     if (m && (rc = pf_stage_done(h))) return rc;
     h->step += 1;

@@ -143,6 +143,19 @@ class PFShard:
                                _ptr(idv, C.c_int32), zp.shape[0], _ptr(r), _ptr(out)))
         return float(out[0]), float(out[1]), float(out[2])
 
+    def step_proposal(self, V, G, wheelbase, Q, dt, z, ids, R):
+        """The FastSLAM-2.0 step (slam_pf_step_proposal): as step_fused, but the pose is drawn from the
+        proposal that already knows this step's observations.  Returns the same three statistics."""
+        zp = _obs(z)
+        idv = np.ascontiguousarray(np.asarray(ids, dtype=np.int32).reshape(-1))
+        if idv.shape[0] != zp.shape[0]:
+            raise ValueError("ids and z disagree on the number of observations")
+        q, r = _small(Q), _small(R)
+        out = np.empty(3)
+        check(lib.slam_pf_step_proposal(self._h, float(V), float(G), float(wheelbase), _ptr(q), float(dt), _ptr(zp),
+                                        _ptr(idv, C.c_int32), zp.shape[0], _ptr(r), _ptr(out)))
+        return float(out[0]), float(out[1]), float(out[2])
+
     def step_fused_normalized(self, V, G, wheelbase, Q, dt, z, ids, R):
         """step_fused + normalize with this shard's own statistics (the whole filter lives here): returns
         (Neff, max normalised log-weight)."""
@@ -373,12 +386,16 @@ class FastSLAM:
         self.resamples += 1
         return int(need_ids.numel())
 
-    def step(self, V, G, wheelbase, Q, dt, z, ids, R, force_resample=None):
-        """predict + known-id updates + normalise + (Neff-triggered) resample.  Returns (Neff, resampled?)."""
+    def step(self, V, G, wheelbase, Q, dt, z, ids, R, force_resample=None, proposal=False):
+        """predict + known-id updates + normalise + (Neff-triggered) resample.  Returns (Neff, resampled?).
+        ``proposal``: the FastSLAM-2.0 step -- the pose is drawn from the proposal that knows this step's
+        observations (shard.step_proposal) instead of from the motion model alone."""
         fused = getattr(self.shard, "step_fused", None) if self.fused else None
         local = getattr(self.shard, "step_fused_normalized", None) if (self.fused and self.comm.world == 1) else None
         self._gmax_norm = None
-        if local is not None:                       # the whole filter on one GPU: one library call per step
+        if proposal:
+            neff = self.normalize(self.shard.step_proposal(V, G, wheelbase, Q, dt, z, ids, R))
+        elif local is not None:                       # the whole filter on one GPU: one library call per step
             neff, self._gmax_norm = local(V, G, wheelbase, Q, dt, z, ids, R)
             self.last_neff = neff
         elif fused is not None:                     # one sweep over the particles instead of five launches

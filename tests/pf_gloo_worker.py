@@ -17,6 +17,7 @@ from pf_numpy_shard import NumpyShard  # noqa: E402
 
 def main():
     out_path = sys.argv[1]
+    proposal = len(sys.argv) > 2 and sys.argv[2] == "proposal"      # the FastSLAM-2.0 step
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     pkg = load_package()
@@ -40,7 +41,7 @@ def main():
         ids = (np.arange(3) + 3 * t) % NL + 1
         dx, dy = lm[ids - 1, 0] - pose[0], lm[ids - 1, 1] - pose[1]
         z = np.vstack([np.hypot(dx, dy), np.arctan2(dy, dx) - pose[2]]) + rng.normal(0, [[0.1], [math.pi / 180]], (2, 3))
-        neff, did = pf.step(V, G, 4.0, Q, 0.1, z, ids, R, force_resample=True if t % 2 == 1 else None)
+        neff, did = pf.step(V, G, 4.0, Q, 0.1, z, ids, R, force_resample=True if t % 2 == 1 else None, proposal=proposal)
         info.append((neff, did))
     pf.normalize()
     mp = pf.mean_pose()

@@ -21,6 +21,11 @@ class NumpyShard:
     def clear_landmarks(self): self.o.clear_landmarks()
     def update_unknown(self, z, R, gate1, gate2, want_assoc=False): return self.o.update_unknown(z, R, gate1, gate2)
     def weight_stats(self): return self.o.weight_stats()
+
+    def step_proposal(self, V, G, w, Q, dt, z, ids, R):
+        self.o.step_proposal(V, G, w, Q, dt, z, ids, R)
+        return self.o.weight_stats()
+
     def normalize(self, gmax, gsum): self.o.normalize(gmax, gsum)
     def mean_pose_sums(self): return self.o.mean_pose_sums()
     def logw_tensor(self): return torch.from_numpy(self.o.logw.copy())

@@ -332,3 +332,105 @@ def test_unknown_correspondences_against_oracle(pkg, dtype):
     assert agree >= 0.999 * total
     assert int((orc.lm[:, 2, :] >= 0).sum(axis=0).max()) == nslots          # the capacity was reached
     sh.close()
+
+
+# ---- N4: FastSLAM-2.0 proposal ------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_proposal_step_against_oracle(pkg, dtype):
+    """slam_pf_step_proposal vs oracle/pf_ref.py::step_proposal over several steps: a full (non-diagonal) Q, first
+    sightings, a landmark observed twice in one call, a landmark first seen AND re-observed in the same call (it must
+    not enter the proposal), n not a multiple of the block size."""
+    n, nl, seed = 3000 + 11, 10, 91
+    lm = scene(nl, 21)
+    Qf = np.array([[0.3, 0.004], [0.004, 0.003]])
+    sh = pkg.PFShard(n, nl, seed, dtype=dtype)
+    orc = F.OraclePF(n, nl, seed)
+    for f in (sh, orc):
+        f.set_pose([1.0, -2.0, 0.4])
+        f.init_landmarks(lm[:6], 0.01, 0.1)
+    rng = np.random.default_rng(22)
+    pose = np.array([1.0, -2.0, 0.4])
+    tol = TOL[dtype]
+    for t in range(6):
+        g = 0.04 * t - 0.1
+        pose = np.array([pose[0] + 0.6 * math.cos(g + pose[2]), pose[1] + 0.6 * math.sin(g + pose[2]),
+                         pose[2] + 0.6 * math.sin(g) / 4.0])
+        ids = np.array([1 + t % 6, 1 + (t + 3) % 6, 7 + t % 4, 1 + t % 6, 7 + t % 4])
+        z = observe(lm, pose, ids, rng)
+        stats = sh.step_proposal(6.0, g, 4.0, Qf if t % 2 else Q, 0.1, z, ids, R)
+        orc.step_proposal(6.0, g, 4.0, Qf if t % 2 else Q, 0.1, z, ids, R)
+        p, lw, l = sh.download()
+        assert close(p, orc.pose, tol), f"pose step {t}"
+        assert close(l[:, 0:2], orc.lm[:, 0:2], tol), f"landmark means step {t}"
+        assert close(l[:, 2:5], orc.lm[:, 2:5], tol * 10, scale=float(np.max(np.abs(orc.lm[:, 2:5])))), f"landmark cov {t}"
+        assert close(lw, orc.logw, tol * 10, scale=max(1.0, float(np.max(np.abs(orc.logw))))), f"log-weights step {t}"
+        om, o1, o2 = orc.weight_stats()
+        assert stats[0] == float(lw.max())
+        assert stats[0] == pytest.approx(om, abs=tol * 50) and stats[1] == pytest.approx(o1, rel=tol * 200)
+        gm, s1, _ = stats
+        sh.normalize(gm, s1)
+        orc.normalize(om, o1)
+    sh.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_proposal_without_information_is_the_fused_step(pkg, dtype):
+    """No observation, or first sightings only: the proposal is the motion model, and the step must be
+    slam_pf_step BIT for bit (same Philox words, same arithmetic)."""
+    n, nl, seed = 2000 + 3, 6, 17
+    lm = scene(nl, 5)
+    a = pkg.PFShard(n, nl, seed, dtype=dtype)
+    b = pkg.PFShard(n, nl, seed, dtype=dtype)
+    for f in (a, b):
+        f.set_pose([0.5, 1.5, -0.2])
+        f.init_landmarks(lm[:3], 0.01, 0.1)
+    none = (np.zeros((2, 0)), np.zeros(0, dtype=np.int32))
+    sa = a.step_proposal(6.0, 0.03, 4.0, Q, 0.1, *none, R)
+    sb = b.step_fused(6.0, 0.03, 4.0, Q, 0.1, *none, R)
+    assert sa == sb
+    z = observe(lm, np.array([1.1, 1.4, -0.2]), np.array([4, 5]), np.random.default_rng(0))
+    sa = a.step_proposal(6.0, -0.02, 4.0, Q, 0.1, z, np.array([4, 5]), R)
+    sb = b.step_fused(6.0, -0.02, 4.0, Q, 0.1, z, np.array([4, 5]), R)
+    assert sa == sb
+    for x, y in zip(a.download(), b.download()):
+        assert np.array_equal(x, y)
+    a.close()
+    b.close()
+
+
+def test_proposal_driver_against_oracle_and_neff_gain(pkg):
+    """FastSLAM.step(proposal=True) on one GPU vs the oracle driven through the same host logic (fp64), with a
+    forced resampling in between; and the reason for FastSLAM 2.0: on the same data the effective sample size
+    after an informative observation is several times that of the FastSLAM-1.0 step."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    from pf_numpy_shard import NumpyShard
+    n, nl, seed = 4096, 8, 63
+    lm = scene(nl, 30)
+    gpu = pkg.FastSLAM(pkg.PFShard(n, nl, seed, dtype="f64"), None)
+    cpu = pkg.FastSLAM(NumpyShard(n, nl, seed), None)
+    one = pkg.FastSLAM(pkg.PFShard(n, nl, seed, dtype="f64"), None)           # FastSLAM 1.0 on the same data
+    for f in (gpu, cpu, one):
+        f.shard.set_pose([0.0, 0.0, 0.2])
+        f.shard.init_landmarks(lm, 0.01, 0.1)
+    rng = np.random.default_rng(31)
+    pose = np.array([0.0, 0.0, 0.2])
+    gains = []
+    Q = 9.0 * globals()["Q"]                 # three times the control noise: the observations carry real information
+    for t in range(8):
+        pose = np.array([pose[0] + 0.5 * math.cos(0.05 + pose[2]), pose[1] + 0.5 * math.sin(0.05 + pose[2]),
+                         pose[2] + 0.5 * math.sin(0.05) / 4.0])
+        ids = (np.arange(3) + 3 * t) % nl + 1
+        z = observe(lm, pose, ids, rng)
+        ng, dg = gpu.step(5.0, 0.05, 4.0, Q, 0.1, z, ids, R, force_resample=True, proposal=True)
+        nc, dc = cpu.step(5.0, 0.05, 4.0, Q, 0.1, z, ids, R, force_resample=True, proposal=True)
+        n1, _ = one.step(5.0, 0.05, 4.0, Q, 0.1, z, ids, R, force_resample=True)
+        assert dg == dc and ng == pytest.approx(nc, rel=1e-7)
+        gains.append(ng / n1)
+        pose_g, logw_g, lm_g = gpu.shard.download()
+        assert close(pose_g, cpu.shard.o.pose, 1e-9, scale=20.0) and close(lm_g, cpu.shard.o.lm, 1e-8, scale=40.0), f"step {t}"
+    assert np.median(gains) > 2.0, gains
+    assert close(gpu.mean_pose(), cpu.mean_pose(), 1e-7, scale=1.0)
+    assert np.hypot(*(gpu.mean_pose()[:2] - pose[:2])) < 0.6
+    for f in (gpu, one):
+        f.shard.close()

@@ -158,3 +158,109 @@ def test_systematic_resampling_properties():
     counts = np.bincount(anc, minlength=5000)
     assert np.all(np.abs(counts - 5000 * w) < 1.0 + 1e-9)             # systematic: floor or ceil of N*w
     assert np.array_equal(F.OraclePF.ancestors(np.zeros(64), 0.5), np.arange(64))   # uniform weights: identity
+
+
+# ---- N4: FastSLAM-2.0 proposal ------------------------------------------------------------------------
+def _proposal_case(n=2048, seed=5):
+    lm = np.array([[20.0, 5.0], [15.0, -8.0], [25.0, 12.0], [10.0, 10.0]])
+    pf = F.OraclePF(n, 6, seed=seed)
+    pf.set_pose([1.0, 2.0, 0.3])
+    pf.init_landmarks(lm, 0.01, 0.1)
+    V, G, wb, dt = 8.0, 0.05, 4.0, 0.225
+    Vt, Gt = V + 0.4, G - 0.03                                    # the controls actually applied
+    tp = np.array([1 + Vt * dt * math.cos(Gt + 0.3), 2 + Vt * dt * math.sin(Gt + 0.3), 0.3 + Vt * dt * math.sin(Gt) / wb])
+    z = np.array([[math.hypot(*(l - tp[:2])), math.atan2(l[1] - tp[1], l[0] - tp[0]) - tp[2]] for l in lm]).T
+    return pf, lm, (V, G, wb, dt), z, tp
+
+
+def test_proposal_without_observations_is_the_motion_model():
+    a, _, (V, G, wb, dt), _, _ = _proposal_case()
+    b, _, _, _, _ = _proposal_case()
+    a.step_proposal(V, G, wb, Q, dt, np.zeros((2, 0)), [], R)
+    b.predict(V, G, wb, Q, dt)
+    assert np.array_equal(a.pose, b.pose) and np.array_equal(a.logw, b.logw) and a.step == b.step == 1
+    # ... and so is a step that only has first sightings: they carry no information about the pose
+    a, _, (V, G, wb, dt), z, _ = _proposal_case()
+    b, _, _, _, _ = _proposal_case()
+    a.step_proposal(V, G, wb, Q, dt, z[:, :2], [5, 6], R)
+    b.predict(V, G, wb, Q, dt)
+    b.update_known(z[:, :2], [5, 6], R)
+    assert np.array_equal(a.pose, b.pose) and np.array_equal(a.lm, b.lm) and np.array_equal(a.logw, b.logw)
+
+
+def test_proposal_raises_neff_and_keeps_the_posterior():
+    a, _, (V, G, wb, dt), z, tp = _proposal_case(n=8192)
+    b, _, _, _, _ = _proposal_case(n=8192)
+    ids = [1, 2, 3, 4]
+    a.predict(V, G, wb, Q, dt)
+    a.update_known(z, ids, R)
+    b.step_proposal(V, G, wb, Q, dt, z, ids, R)
+
+    def summary(pf):
+        m, s1, s2 = pf.weight_stats()
+        w = np.exp(pf.logw - m) / s1
+        return s1 * s1 / s2, (w[None] * pf.pose).sum(1)
+    neff1, mean1 = summary(a)
+    neff2, mean2 = summary(b)
+    assert neff2 > 3 * neff1                                        # the point of FastSLAM 2.0
+    assert np.allclose(mean1, mean2, atol=0.02)                     # same target distribution
+    assert np.hypot(*(mean2[:2] - tp[:2])) < 0.1
+    assert np.all(b.lm[:4, 2] > 0) and np.all(b.lm[:4, 2] * b.lm[:4, 4] - b.lm[:4, 3] ** 2 > 0)
+
+
+def test_proposal_sequential_form_equals_the_batch_solution():
+    """The sequential 2 x 2 Cholesky-form assimilation is checked against the textbook batch form on the stacked
+    linear model v = B w + noise:  Sig = (I + B' Sf^-1 B)^-1,  mu = Sig B' Sf^-1 v,  log weight = log N(v; 0, B B' +
+    Sf), with the Jacobians taken from the EKF oracle's predict_observation (src/common.jl:139-165)."""
+    pf, lm, (V, G, wb, dt), z, _ = _proposal_case(n=4)
+    Qf = np.array([[0.3, 0.004], [0.004, 0.003]])                   # a full Q
+    ids = [1, 2, 3, 4, 2]                                           # landmark 2 observed twice
+    z = np.hstack([z, z[:, 1:2] + [[0.05], [0.002]]])
+    before = pf.pose.copy(), pf.lm.copy(), pf.logw.copy()
+    pf.step_proposal(V, G, wb, Qf, dt, z, ids, R)
+    e1, e2 = F.normals2(pf.gids, 0, F.STREAM_PREDICT, pf.seed)
+    Lq = np.linalg.cholesky(Qf)
+    for p in range(4):
+        x, y, phi = before[0][:, p]
+        s, c = math.sin(G + phi), math.cos(G + phi)
+        Gu = np.array([[dt * c, -V * dt * s], [dt * s, V * dt * c], [dt * math.sin(G) / wb, V * dt * math.cos(G) / wb]])
+        GL = Gu @ Lq
+        pm = np.array([x + V * dt * c, y + V * dt * s, phi + V * dt * math.sin(G) / wb])
+        Bs, vs, Sfs = [], [], []
+        for i, l1 in enumerate(ids):
+            rec = before[1][l1 - 1, :, p]
+            xs = np.array([pm[0], pm[1], pm[2], rec[0], rec[1]])
+            zp, H = O.predict_observation(xs, 1)
+            Pf = np.array([[rec[2], rec[3]], [rec[3], rec[4]]])
+            Bs.append(H[:, :3] @ GL)
+            Sfs.append(H[:, 3:5] @ Pf @ H[:, 3:5].T + R)
+            vs.append([z[0, i] - zp[0], O.mpi_to_pi(z[1, i] - zp[1])])
+        B = np.vstack(Bs)
+        v = np.concatenate(vs)
+        Sf = np.zeros((2 * len(ids), 2 * len(ids)))
+        for i, blk in enumerate(Sfs):
+            Sf[2 * i:2 * i + 2, 2 * i:2 * i + 2] = blk
+        Sig = np.linalg.inv(np.eye(2) + B.T @ np.linalg.solve(Sf, B))
+        mu = Sig @ B.T @ np.linalg.solve(Sf, v)
+        Sv = B @ B.T + Sf
+        lw = -0.5 * v @ np.linalg.solve(Sv, v) - 0.5 * np.linalg.slogdet(Sv)[1] - len(ids) * math.log(2 * math.pi)
+        assert pf.logw[p] - before[2][p] == pytest.approx(lw, rel=1e-9)
+        w = mu + np.linalg.cholesky(Sig) @ np.array([e1[p], e2[p]])
+        u = Lq @ w
+        Vn, Gn = V + u[0], G + u[1]
+        want = [x + Vn * dt * math.cos(Gn + phi), y + Vn * dt * math.sin(Gn + phi), phi + Vn * dt * math.sin(Gn) / wb]
+        assert np.allclose(pf.pose[:, p], want, rtol=1e-10, atol=1e-10)
+
+
+def test_proposal_does_not_depend_on_the_split():
+    one, _, (V, G, wb, dt), z, _ = _proposal_case(n=512)
+    one.step_proposal(V, G, wb, Q, dt, z, [1, 2, 3, 4], R)
+    shards = []
+    for g in range(4):
+        full, _, _, _, _ = _proposal_case(n=512)
+        s = F.OraclePF(128, 6, seed=5, first_id=128 * g, n_global=512)
+        s.pose, s.lm, s.seen = full.pose[:, 128 * g:128 * (g + 1)], full.lm[:, :, 128 * g:128 * (g + 1)], full.seen
+        s.step_proposal(V, G, wb, Q, dt, z, [1, 2, 3, 4], R)
+        shards.append(s)
+    assert np.array_equal(np.hstack([s.pose for s in shards]), one.pose)
+    assert np.array_equal(np.concatenate([s.lm for s in shards], axis=2), one.lm)

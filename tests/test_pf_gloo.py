@@ -12,10 +12,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_world(world, tmp_path, port):
-    out = str(tmp_path / f"w{world}")
+def run_world(world, tmp_path, port, mode="known"):
+    out = str(tmp_path / f"w{world}{mode}")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "pf_gloo_worker.py"), out]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "pf_gloo_worker.py"), out, mode]
     env = dict(os.environ, OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -40,3 +40,16 @@ def test_sharded_driver_matches_single_rank(tmp_path):
         assert np.allclose(got["mean_pose"], one["mean_pose"], rtol=1e-12, atol=1e-12)
         for mp in got["all_mean"]:                               # every rank holds the same global estimate
             assert np.allclose(mp, got["mean_pose"], rtol=0, atol=1e-14)
+
+
+@pytest.mark.timeout(600)
+def test_sharded_proposal_step_matches_single_rank(tmp_path):
+    """The same for the FastSLAM-2.0 step (proposal=True): the proposal is per particle, so sharding changes nothing."""
+    one = run_world(1, tmp_path, 29641, "proposal")
+    got = run_world(2, tmp_path, 29642, "proposal")
+    assert got["resamples"] == one["resamples"] >= 5
+    assert np.array_equal(got["pose"], one["pose"]) and np.array_equal(got["lm"], one["lm"])
+    assert np.allclose(got["logw"], one["logw"], rtol=0, atol=1e-12)
+    assert np.allclose(got["info"], one["info"], rtol=1e-12)
+    known = run_world(1, tmp_path, 29643)
+    assert not np.array_equal(known["pose"], one["pose"])          # it is a different sampler
