@@ -351,6 +351,8 @@ __global__ __launch_bounds__(256) void pf_step_kernel(T* __restrict__ pose, T* _
 // sampled with the SAME two normals FastSLAM-1.0's predict uses (no observation: the same pose bit for bit), and
 // pass 2 is apply_known from the sampled pose with the weight left alone.  One sweep, records read twice: 69 us
 // against the 48 us of pf_step_kernel at 262144 particles x 16 observations (the 84 MB of pass 1 at HBM speed).
+// (Keeping the 16 records in registers between the passes, all requested up front, was measured: 166 VGPRs, three
+//  waves per SIMD instead of six, and the step went from 107 to 122 us on the same box.)
 template <typename T>
 __global__ __launch_bounds__(256) void pf_proposal_kernel(T* __restrict__ pose, T* __restrict__ lm, T* __restrict__ logw,
                                                            int64_t n, int64_t first, uint32_t step, uint64_t seed, T V, T G,
