@@ -397,7 +397,20 @@ def main():
             w = tj.get("workload", {})
             if (w.get("landmarks"), w.get("obs_per_step"), w.get("dtype"), w.get("form")) == (N, nz, args.dtype, args.form):
                 traffic = tj["hbm_bytes_per_launch"]           # PMC-derived (separate rocprofv3 --pmc passes), see profiles/
-        if args.dtype == "f32":
+        split_bf16 = (args.dtype == "f32" and args.form == "cholesky" and 64 < k_avg <= 128
+                      and not (int(os.environ.get("SLAMHIP_X", "0")) & 8))
+        if split_bf16:
+            # the down-date runs on the bf16 matrix cores with every fp32 operand split into three bf16 terms (six exact
+            # products per fp32 product, csrc/ekf_syrk.hip): 6x the algorithmic flops at a 16x higher peak, so HBM bounds it
+            roof = {"kernel": "downdate (P -= W1*W1'), fp32 via split-bf16 on the bf16 matrix cores", "bound": "hbm",
+                    "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                    "traffic": traffic, "avg_launch_ms": syrk_avg_s * 1e3, "launches": syrk_n,
+                    "launches_note": f"every {TIMING_STRIDE}th step of the timed region is bracketed by HIP events",
+                    "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
+                    "fp32_equivalent_TFLOPs": tflops, "frac_of_fp32_mfma_peak_157TF": tflops / MFMA_F32_PEAK_TFLOPS,
+                    "bf16_mfma_TFLOPs_executed": 6.0 * tflops,        # (k padded to a multiple of 16 adds a few per cent)
+                    "bf16_mfma_peak_TFLOPs": 2500.0}
+        elif args.dtype == "f32":
             roof = {"kernel": "downdate (P -= W1*W1')", "bound": "mfma", "achieved": tflops,
                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_F32_PEAK_TFLOPS,
                     "traffic": traffic, "avg_launch_ms": syrk_avg_s * 1e3, "launches": syrk_n, "launches_note": f"every {TIMING_STRIDE}th step of the timed region is bracketed by HIP events",

@@ -104,7 +104,7 @@ struct slam_ekf {
     int32_t* d_status;   // [4]  [0] = not-PD flag of the last update
     int32_t* h_status;   // pinned
 
-    int xflags;          // SLAMHIP_X: experiment switches of the production down-date (1: no start stagger, 2: no s_setprio around the MFMAs, 4: no streaming path)
+    int xflags;          // SLAMHIP_X: experiment switches of the production down-date (1: no start stagger, 2: no s_setprio around the MFMAs, 4: no streaming path, 8: no split-bf16 path -- the fp32 matrix cores do the down-date)
     int debug_flags;     // SLAMHIP_DEBUG env bits: 1 = no P stores, 2 = no MFMAs, 4 = no P loads (timing experiments, WRONG results)
     void* dd_prof;       // SLAMHIP_DEBUG & 8: per-wave phase clocks of the fp32 down-date (printed at destroy)
     int factor_blocked;  // K4: blocked MFMA elimination (default) or the scalar one (SLAMHIP_FACTOR=scalar)

@@ -381,12 +381,148 @@ __device__ __forceinline__ void dd_stream(DdCtx& c, const int2* __restrict__ lis
     }
 }
 
+// ---- split-bf16 streaming path ------------------------------------------------------------------------------------
+// The fp32 matrix core (v_mfma_f32_32x32x2_f32, 157 TFLOP/s) is what bounds the path above; the bf16 one is 16 times
+// faster.  Every fp32 number is EXACTLY the sum of three bf16 numbers, v = h + m + l (h = bf16(v), m = bf16(v - h),
+// l = bf16(v - h - m): 3 x 8 significant bits + signs cover the 24 of fp32), and a product of two bf16 numbers is
+// exact in fp32, so x*y = sum over the nine split products, each of them one exact term of an fp32 accumulation.
+// Six of them are formed -- (h,h), (h,m), (m,h), (h,l), (l,h), (m,m); the three left out, (m,l), (l,m), (l,l), are
+// below 2^-25 |x y|, half a unit in the last place of the product itself, i.e. the result carries the rounding of an
+// UNFUSED fp32 multiply-add instead of a fused one.  Measured against the fp64 oracle (tools/acc_downdate.py, N =
+// 1500, 64 observations, rms error of P after one / six updates relative to max|P|): fp32 MFMA path 8.80e-8 /
+// 1.32e-7, this path 7.08e-8 / 1.05e-7, all nine terms 7.08e-8 / 1.05e-7 -- the three small terms change nothing
+// and cost 11 % of the kernel's time; tests/test_gpu_ekf.py holds the comparison.  Six bf16 MFMAs do the work of
+// sixteen fp32 ones: the down-date becomes HBM-bound.
+//
+// Same pipeline as dd_stream with 16 columns of k per chunk (kp is a multiple of 16: no partial chunk).  The panels
+// stay fp32 in global memory; the split happens once per element and tile where the chunk is written to LDS:
+// [buffer][X|Y][h|m|l][128 rows][16 bf16 + pad] with a 48-byte row pitch, which makes the ds_read_b128 of a fragment
+// (lane = row, 16 bytes = 8 consecutive k) conflict-free.  2 x 36,864 B: the same footprint as the fp32 buffers.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+constexpr int KB = 16;                 // k per chunk
+constexpr int BROW = 48;               // bytes per LDS row
+constexpr int BARR = TILE * BROW;      // bytes per [panel][split] array
+
+__device__ __forceinline__ void request_chunk_b(const DdCtx& c, int2 t, int chunk, f32x4& gx, f32x4& gy) {
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.X), (short)0, c.ld * c.pitch * 4, 0x00020000);
+    const auto ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.Y), (short)0, c.ld * c.pitch * 4, 0x00020000);
+    const int tid = threadIdx.x;
+    const int voff = ((tid >> 2) * c.pitch + 4 * (tid & 3)) * 4;            // row tid / 4, k-quad tid % 4
+    gx = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, (t.x * TILE * c.pitch + chunk * KB) * 4, 0));
+    gy = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, voff, (t.y * TILE * c.pitch + chunk * KB) * 4, 0));
+}
+
+// two fp32 -> packed (h, m, l) bf16 pairs; the bf16 values are widened back with bit operations
+__device__ __forceinline__ void split2(float v0, float v1, unsigned& h, unsigned& m, unsigned& l) {
+    const f32x2 v = {v0, v1};
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    const f32x2 r1 = {v0 - __uint_as_float(h << 16), v1 - __uint_as_float(h & 0xffff0000u)};
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+    const f32x2 r2 = {r1.x - __uint_as_float(m << 16), r1.y - __uint_as_float(m & 0xffff0000u)};
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+}
+
+template <bool DBG>
+__device__ __forceinline__ void fill_lds_b(const DdCtx& c, char* sm, int buf, const f32x4& gx, const f32x4& gy) {
+    const int tid = threadIdx.x;
+    char* base = sm + buf * (6 * BARR) + (tid >> 2) * BROW + (tid & 3) * 8;
+#pragma unroll
+    for (int pnl = 0; pnl < 2; ++pnl) {
+        const f32x4 g = pnl ? gy : gx;
+        unsigned h0, m0, l0, h1, m1, l1;
+        if (DBG && (c.dbg & 16)) {             // experiment: no split arithmetic (wrong numbers)
+            h0 = m0 = l0 = __float_as_uint(g.x) ^ __float_as_uint(g.y);
+            h1 = m1 = l1 = __float_as_uint(g.z) ^ __float_as_uint(g.w);
+        } else {
+        split2(g.x, g.y, h0, m0, l0);
+        split2(g.z, g.w, h1, m1, l1);
+        }
+        *reinterpret_cast<u32x2*>(base + (3 * pnl + 0) * BARR) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(base + (3 * pnl + 1) * BARR) = u32x2{m0, m1};
+        *reinterpret_cast<u32x2*>(base + (3 * pnl + 2) * BARR) = u32x2{l0, l1};
+    }
+}
+
+// one chunk = one k16 step: 3 + 2 x 3 fragments, 2 x 6 MFMAs, smallest terms first
+template <bool DBG>
+__device__ __forceinline__ void mfma_chunk_b(const DdCtx& c, const char* sm, int buf, f32x16 (&acc)[2]) {
+    if (DBG && (c.dbg & 2)) return;
+    const char* base = sm + buf * (6 * BARR) + c.l31 * BROW + c.lh * 16;
+    bf16x8 a[3];                       // Y: the wave's 32 columns (the MFMA's A operand, as in read_frag)
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp) a[sp] = *reinterpret_cast<const bf16x8*>(base + (3 + sp) * BARR + (32 * c.wc) * BROW);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        bf16x8 b[3];                   // X: 32 of the wave's 64 rows
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) b[sp] = *reinterpret_cast<const bf16x8*>(base + sp * BARR + (64 * c.wr + 32 * rb) * BROW);
+        if (!(c.xflags & 2)) __builtin_amdgcn_s_setprio(3);
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[rb], 0, 0, 0);      // (m, m)
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[rb], 0, 0, 0);      // (h, l)
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[rb], 0, 0, 0);      // (l, h)
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[rb], 0, 0, 0);      // (h, m)
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[rb], 0, 0, 0);      // (m, h)
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[rb], 0, 0, 0);      // (h, h)
+        if (!(c.xflags & 2)) __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+// As dd_stream: processes list[slot], list[slot + nper], ... while they are off-diagonal; NCH = kp / 16 (>= 2).  On
+// entry gx/gy hold the request for chunk 0 of the first tile.  On return `slot` is the first unprocessed position;
+// nothing is in flight for it (the diagonal tiles that follow use the fp32 pipeline and request their own panels).
+template <bool DBG, int NCH, int POFF>
+__device__ __forceinline__ void dd_stream_b(DdCtx& c, const int2* __restrict__ list, int L, int nper, int& slot, char* sm,
+                                            f32x4& gx, f32x4& gy) {
+    auto fetch = [&](int sl) { return sl < L ? list[sl] : make_int2(-1, -1); };
+    constexpr int PCH = NCH - POFF > 0 ? NCH - POFF : 0;  // the chunk at whose start the P tile is requested
+    int2 tile = fetch(slot);
+    int2 next = fetch(slot + nper);
+    f32x16 acc[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
+    float pold[2][16];
+    fill_lds_b<DBG>(c, sm, 0, gx, gy);
+    __syncthreads();
+    request_chunk_b(c, tile, 1, gx, gy);
+    int base = 0;
+    for (;;) {
+        const bool next_off = next.x >= 0 && next.x != next.y;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int pb = (base + ch) & 1;
+            if (ch == PCH && !(DBG && (c.dbg & 4))) load_p_mfma(c, tile.x * TILE, tile.y * TILE, pold);
+            mfma_chunk_b<DBG>(c, sm, pb, acc);
+            if (ch < NCH - 1) {
+                fill_lds_b<DBG>(c, sm, pb ^ 1, gx, gy);                  // chunk ch + 1 of this tile
+                __syncthreads();
+                if (ch + 2 < NCH) request_chunk_b(c, tile, ch + 2, gx, gy);
+                else if (next_off) request_chunk_b(c, next, 0, gx, gy);
+            } else {
+                if (next_off) fill_lds_b<DBG>(c, sm, pb ^ 1, gx, gy);    // chunk 0 of the next tile
+                __syncthreads();
+                if (next_off) request_chunk_b(c, next, 1, gx, gy);
+                if (!(DBG && (c.dbg & 1))) store_p_mfma(c, tile.x * TILE, tile.y * TILE, pold, acc);
+            }
+        }
+        slot += nper;
+        if (!next_off) return;
+        tile = next;
+        next = fetch(slot + nper);
+        base = (base + NCH) & 1;
+    }
+}
+
 // PERSISTENT kernel: gridDim.x = 8 * nper workgroups (two per CU: four waves per SIMD); workgroup b
 // walks the tile list of XCD b % 8 with stride nper.  Memory operations of a wave are asynchronous: a
 // wave that moves on to the next tile's MFMAs lets its stores drain behind them.  The first tile is
 // peeled so that the loop header sees the same load/store history on both of its incoming edges and the
 // compiler can emit counted vmcnt waits for the panel chunk instead of vmcnt(0).
-template <bool DBG, int STREAM = 0, int POFF = 2>   // STREAM = chunks per tile (2..4) for the streaming path, 0: dd_tile only
+template <bool DBG, int STREAM = 0, int POFF = 2, bool BF = false>   // STREAM = chunks per tile (2..4) for the streaming path, 0: dd_tile only; BF: split-bf16 streaming path where kp allows
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void downdate_f32_mfma(float* __restrict__ P, int ld, int n,
                                                                  const float* __restrict__ X, const float* __restrict__ Y,
                                                                  int pitch, int kp, const int2* __restrict__ tiles, int L,
@@ -429,6 +565,21 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
     int2 tile = slot < L ? list[slot] : make_int2(-1, -1);
     if (tile.x < 0) return;
     f32x4 gx[2], gy[2];
+    if (BF && tile.x != tile.y && kp >= 5 * KB && kp <= 8 * KB && !joseph) {
+        // off-diagonal tiles on the bf16 matrix cores (kp = 80, 96, 112 or 128); the diagonal ones follow below
+        char* sm = reinterpret_cast<char*>(&smem[0][0][0][0]);
+        request_chunk_b(c, tile, 0, gx[0], gy[0]);
+        // (the P tile is requested at the start of the tile's second chunk: one-box A/B of offsets NCH-4 / NCH-2 /
+        //  NCH-1 gave 0.411 / 0.408 / 0.402 ms)
+        switch (kp / KB) {
+            case 8: dd_stream_b<DBG, 8, 7>(c, list, L, nper, slot, sm, gx[0], gy[0]); break;
+            case 7: dd_stream_b<DBG, 7, 6>(c, list, L, nper, slot, sm, gx[0], gy[0]); break;
+            case 6: dd_stream_b<DBG, 6, 5>(c, list, L, nper, slot, sm, gx[0], gy[0]); break;
+            default: dd_stream_b<DBG, 5, 4>(c, list, L, nper, slot, sm, gx[0], gy[0]); break;
+        }
+        tile = slot < L ? list[slot] : make_int2(-1, -1);
+        if (tile.x < 0) return;
+    }
     request_chunk(c, tile, 0, gx, gy);
     slot += nper;
     int2 next = slot < L ? list[slot] : make_int2(-1, -1);
@@ -645,7 +796,11 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
         int per_xcd = 2 * h->num_cus / 8;
         if (per_xcd > h->tiles_len) per_xcd = h->tiles_len;
         if (per_xcd < 1) per_xcd = 1;
-        if (h->debug_flags)      // timing experiments only (SLAMHIP_DEBUG): parts of the kernel switched off
+        if (h->debug_flags & 32)  // timing experiments on the split-bf16 path (1 no stores, 2 no MFMAs, 4 no P loads, 16 no split)
+            hipLaunchKernelGGL((downdate_f32_mfma<true, 4, 3, true>), dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,
+                               (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
+                               h->d_status, h->debug_flags & 0x1f, (unsigned long long*)nullptr, dcount, joseph);
+        else if (h->debug_flags)      // timing experiments only (SLAMHIP_DEBUG): parts of the kernel switched off
             hipLaunchKernelGGL(downdate_f32_mfma<true>, dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,
                                (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
                                h->d_status, h->debug_flags, (unsigned long long*)h->dd_prof, dcount, joseph);
@@ -662,7 +817,12 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
     hipLaunchKernelGGL((downdate_f32_mfma<false, NCH>), dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, \
                        n, (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,       \
                        h->d_status, h->xflags << 8, (unsigned long long*)nullptr, dcount, joseph)
-            if (nch == 4) DD_LAUNCH_STREAM4();
+            if (nch >= 3 && !joseph && !(h->xflags & 8))           // split-bf16 path (SLAMHIP_X bit 8 switches it off)
+                hipLaunchKernelGGL((downdate_f32_mfma<false, 4, 3, true>), dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream,
+                                   (float*)h->P, h->ld, n, (const float*)X, (const float*)Y, pitch, kp_total,
+                                   (const int2*)h->tiles, h->tiles_len, h->d_status, h->xflags << 8,
+                                   (unsigned long long*)nullptr, dcount, joseph);
+            else if (nch == 4) DD_LAUNCH_STREAM4();
             else if (nch == 3) DD_LAUNCH_STREAM(3);
             else DD_LAUNCH_STREAM(2);
 #undef DD_LAUNCH_STREAM

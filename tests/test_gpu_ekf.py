@@ -552,6 +552,46 @@ def test_full_size_10k_landmarks_fp32(pkg):
     st.close()
 
 
+@pytest.mark.parametrize("m", [32, 40, 48, 56, 64])
+def test_split_bf16_downdate_against_the_fp32_matrix_cores(pkg, monkeypatch, m):
+    """fp32 states with 80 <= k <= 128 take the split-bf16 down-date (csrc/ekf_syrk.hip: every fp32 operand as
+    h + m + l in bf16, six exact products per fp32 product on the bf16 matrix cores, fp32 accumulation);
+    SLAMHIP_X=8 keeps the fp32 matrix cores.  Both are compared with the fp64 oracle on the same state: the split
+    path must be at least as accurate as the fp32-MFMA path (up to noise), and both inside the fp32 tolerance.
+    k = 64 is outside the split path's range: there the two handles must agree bit for bit."""
+    rng = np.random.default_rng(100 + m)
+    N = 700                                              # n = 1403: 11 tile rows, 55 off-diagonal tiles
+    x, P = random_state(rng, N, spread=600.0)
+    ids = rng.permutation(N)[:m] + 1
+    got = {}
+    for name, flag in (("split", None), ("fp32", "8")):
+        if flag is None:
+            monkeypatch.delenv("SLAMHIP_X", raising=False)
+        else:
+            monkeypatch.setenv("SLAMHIP_X", flag)
+        st = pkg.EKFSlamState(x, P, dtype="f32", max_landmarks=N)
+        xo, Po = rounded(st)
+        z = noisy_obs(np.random.default_rng(7), xo, ids)
+        st.update(z, R, ids)
+        got[name] = st.download()
+        st.close()
+    monkeypatch.delenv("SLAMHIP_X", raising=False)
+    xn, Pn = O.update_sparse(xo, Po, z, R, ids)
+    err = {}
+    for name, (xg, Pg) in got.items():
+        assert relerr(xg, xn) <= 5e-6
+        d = np.asarray(Pg, dtype=np.float64) - Pn
+        err[name] = (float(np.abs(d).max()), float(np.sqrt((d * d).mean())))
+        assert relerr_cov(Pg, Pn, np.diag(Po)) <= 5e-6, name
+        assert np.array_equal(Pg, Pg.T)
+    if m == 32:
+        assert np.array_equal(got["split"][1], got["fp32"][1])
+    else:
+        assert not np.array_equal(got["split"][1], got["fp32"][1])           # the split path did run
+        assert err["split"][1] <= 1.1 * err["fp32"][1], err                   # rms error: no worse than fp32 MFMA
+        assert err["split"][0] <= 1.5 * err["fp32"][0], err                   # max error
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_telemetry_ellipses_and_monitor_schema(pkg, dtype):
     """Row N3: feature / vehicle ellipses computed on the device from the 2 x 2 blocks (no download of P) against
