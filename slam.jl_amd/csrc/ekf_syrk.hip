@@ -406,11 +406,19 @@ constexpr int KB = 16;                 // k per chunk
 constexpr int BROW = 48;               // bytes per LDS row
 constexpr int BARR = TILE * BROW;      // bytes per [panel][split] array
 
+// Staging map: thread -> (row, k-quad) of a 128 x 16 chunk.  Four lanes share a row (64 contiguous bytes of the
+// panel); the 16 contiguous lanes that a ds_write_b64 services together take rows r, r+2, r+4, r+6, whose 32-byte
+// pieces at a 48-byte pitch fall on disjoint banks (bank = word mod 32 for stores): rows r..r+3 would be 2-way
+// (29 % of the kernel's LDS cycles were conflict cycles with the plain map; worth 0.5 % of its time).
+__device__ __forceinline__ int stage_row(int tid) {
+    return (tid >> 6) * 16 + ((tid >> 5) & 1) * 8 + ((tid >> 4) & 1) + 2 * ((tid >> 2) & 3);
+}
+
 __device__ __forceinline__ void request_chunk_b(const DdCtx& c, int2 t, int chunk, f32x4& gx, f32x4& gy) {
     const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.X), (short)0, c.ld * c.pitch * 4, 0x00020000);
     const auto ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.Y), (short)0, c.ld * c.pitch * 4, 0x00020000);
     const int tid = threadIdx.x;
-    const int voff = ((tid >> 2) * c.pitch + 4 * (tid & 3)) * 4;            // row tid / 4, k-quad tid % 4
+    const int voff = (stage_row(tid) * c.pitch + 4 * (tid & 3)) * 4;
     gx = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, (t.x * TILE * c.pitch + chunk * KB) * 4, 0));
     gy = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, voff, (t.y * TILE * c.pitch + chunk * KB) * 4, 0));
 }
@@ -428,7 +436,7 @@ __device__ __forceinline__ void split2(float v0, float v1, unsigned& h, unsigned
 template <bool DBG>
 __device__ __forceinline__ void fill_lds_b(const DdCtx& c, char* sm, int buf, const f32x4& gx, const f32x4& gy) {
     const int tid = threadIdx.x;
-    char* base = sm + buf * (6 * BARR) + (tid >> 2) * BROW + (tid & 3) * 8;
+    char* base = sm + buf * (6 * BARR) + stage_row(tid) * BROW + (tid & 3) * 8;
 #pragma unroll
     for (int pnl = 0; pnl < 2; ++pnl) {
         const f32x4 g = pnl ? gy : gx;
