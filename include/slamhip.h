@@ -236,6 +236,10 @@ int slam_pf_copy_logw(slam_pf_t h, void* d_dst);
  * (device, handle dtype), gmax their maximum, u0 in [0,1) the shared offset.  d_anc (device,
  * n_local int32) receives the global ancestor id of every local slot.  Synchronises. */
 int slam_pf_ancestors(slam_pf_t h, const void* d_logw_all, double gmax, double u0, int32_t* d_anc);
+/* The same for EVERY slot of the filter: d_anc_all (device, n_global int32).  All ranks compute the identical table,
+ * so each rank knows which of its particles every other rank needs and the record exchange is ONE all-to-all with
+ * no request round.  Synchronises. */
+int slam_pf_ancestors_all(slam_pf_t h, const void* d_logw_all, double gmax, double u0, int32_t* d_anc_all);
 /* Rows of one particle record: 3 pose rows + 5 rows per landmark (x, y, Pxx, Pxy, Pyy). */
 int slam_pf_record_rows(slam_pf_t h, int* rows);
 /* records[row][c] = state row of local particle d_local_idx[c]  (device buffers, handle dtype):

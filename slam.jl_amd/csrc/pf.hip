@@ -1223,7 +1223,8 @@ extern "C" int slam_pf_copy_logw(slam_pf_t h, void* d_dst) {
     return SLAM_OK;
 }
 
-extern "C" int slam_pf_ancestors(slam_pf_t h, const void* d_logw_all, double gmax, double u0, int32_t* d_anc) {
+static int pf_ancestors_impl(slam_pf_t h, const void* d_logw_all, double gmax, double u0, int32_t* d_anc, int64_t first,
+                             int64_t count) {
     ARG_CHECK(h != nullptr && d_logw_all != nullptr && d_anc != nullptr, "null argument");
     ARG_CHECK(u0 >= 0.0 && u0 < 1.0, "u0 must be in [0, 1)");
     HIP_TRY(hipSetDevice(h->device));
@@ -1234,11 +1235,23 @@ extern "C" int slam_pf_ancestors(slam_pf_t h, const void* d_logw_all, double gma
                 hipLaunchKernelGGL(pf_scan1_kernel<T>, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, (const T*)d_logw_all,
                                    h->n_global, gmax, h->d_cdf, h->d_bsum));
     hipLaunchKernelGGL(pf_scan2_kernel, dim3(1), dim3(256), 0, h->stream, h->d_bsum, nb);
-    hipLaunchKernelGGL(pf_ancestor_kernel, dim3(grid_for(h->n)), dim3(256), 0, h->stream, h->d_cdf, h->d_bsum, nb, h->n_global,
-                       h->first, h->n, u0, d_anc);
+    hipLaunchKernelGGL(pf_ancestor_kernel, dim3(grid_for(count)), dim3(256), 0, h->stream, h->d_cdf, h->d_bsum, nb, h->n_global,
+                       first, count, u0, d_anc);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     return SLAM_OK;
+}
+
+extern "C" int slam_pf_ancestors(slam_pf_t h, const void* d_logw_all, double gmax, double u0, int32_t* d_anc) {
+    ARG_CHECK(h != nullptr, "null handle");
+    return pf_ancestors_impl(h, d_logw_all, gmax, u0, d_anc, h->first, h->n);
+}
+
+/* The ancestor of EVERY slot of the filter (n_global entries): every rank computes the same table from the
+ * all-gathered weights, so each knows without further communication which of its particles every other rank needs. */
+extern "C" int slam_pf_ancestors_all(slam_pf_t h, const void* d_logw_all, double gmax, double u0, int32_t* d_anc_all) {
+    ARG_CHECK(h != nullptr, "null handle");
+    return pf_ancestors_impl(h, d_logw_all, gmax, u0, d_anc_all, 0, h->n_global);
 }
 
 extern "C" int slam_pf_record_rows(slam_pf_t h, int* rows) {

@@ -194,6 +194,16 @@ class PFShard:
                                     C.c_void_p(anc.data_ptr())))
         return anc
 
+    def ancestors_all(self, logw_all, gmax, u0):
+        """Global ancestor id of EVERY slot of the filter (n_global int32): identical on every rank."""
+        import torch
+        assert logw_all.is_cuda and logw_all.dtype == self.torch_dtype and logw_all.numel() == self.n_global
+        torch.cuda.synchronize(self.device)            # logw_all was produced on torch's stream
+        anc = torch.empty(self.n_global, dtype=torch.int32, device=self.device)
+        check(lib.slam_pf_ancestors_all(self._h, C.c_void_p(logw_all.data_ptr()), float(gmax), float(u0),
+                                        C.c_void_p(anc.data_ptr())))
+        return anc
+
     def pack(self, local_idx):
         import torch
         idx = local_idx.to(device=self.device, dtype=torch.int32).contiguous()
@@ -316,6 +326,7 @@ class FastSLAM:
         self.comm = comm if comm is not None else _SingleProcess()
         self.neff_frac = float(neff_frac)
         self.fused = True                           # use shard.step_fused when the shard offers it
+        self.force_exchange = False                 # measurement only: take the multi-rank resampling flow on one rank
         self._gmax_norm = None                      # max log-weight after the last normalize() (None: unknown)
         self.resamples = 0
         self.last_neff = float(shard.n_global)
@@ -363,26 +374,31 @@ class FastSLAM:
         logw_all = comm.all_gather(sh.logw_tensor(), sh.n_global)      # the all-gather of log-weights
         gmax = self._gmax_norm if self._gmax_norm is not None else float(logw_all.max().item())
         self._gmax_norm = None
-        anc = sh.ancestors(logw_all, gmax, u0)                          # global ancestor id per local slot, ascending
-        if comm.world == 1:                                             # every ancestor is local: nothing to exchange
-            sh.resample_apply(anc, None, None)
+        if comm.world == 1 and not self.force_exchange:                 # every ancestor is local: nothing to exchange
+            sh.resample_apply(sh.ancestors(logw_all, gmax, u0), None, None)
             self.resamples += 1
             return 0
-        anc64 = anc.to(torch.int64)
-        owner = torch.div(anc64, sh.n, rounding_mode="floor")
-        remote = owner != comm.rank
-        need_ids = torch.unique(anc64[remote])                          # ascending global ids = grouped by owner rank
-        need_owner = torch.div(need_ids, sh.n, rounding_mode="floor")
-        req_counts = torch.bincount(need_owner, minlength=comm.world).to(torch.int64)
-        if comm.world > 1:
-            serve_counts = comm.all_to_all_v(req_counts.reshape(-1, 1), [1] * comm.world, [1] * comm.world).reshape(-1)
-            rc, sc = req_counts.tolist(), serve_counts.tolist()
-            serve_ids = comm.all_to_all_v(need_ids.reshape(-1, 1), rc, sc).reshape(-1)      # ids other ranks want from me
-            rec = sh.pack((serve_ids - sh.first).to(torch.int32))                            # [rows, n_serve]
-            got = comm.all_to_all_v(rec.t().contiguous(), sc, rc)                            # [n_need, rows], ascending ids
-            sh.resample_apply(anc, need_ids.to(torch.int32), got.t().contiguous())
-        else:
-            sh.resample_apply(anc, None, None)
+        # Every rank computes the ancestor of EVERY slot from the same all-gathered weights, so each knows which of its
+        # particles every other rank needs: no request round, ONE all-to-all of records.  The table is ascending
+        # (systematic resampling), and so is the owner of each slot: the (destination rank, ancestor) pairs come out
+        # sorted, unique_consecutive removes the duplicates, and both the send list (my particles, grouped by
+        # destination) and the receive list (ascending ids = grouped by source) are slices of that one list.
+        n, me, world = sh.n, comm.rank, comm.world
+        anc_all = sh.ancestors_all(logw_all, gmax, u0).to(torch.int64)
+        slot_rank = torch.arange(sh.n_global, device=anc_all.device, dtype=torch.int64) // n
+        # (boolean-mask indexing synchronises: each mask is turned into an index list once)
+        remote = torch.nonzero(torch.div(anc_all, n, rounding_mode="floor") != slot_rank).reshape(-1)
+        pairs = torch.unique_consecutive(slot_rank[remote] * sh.n_global + anc_all[remote])
+        dst, aid = torch.div(pairs, sh.n_global, rounding_mode="floor"), pairs % sh.n_global
+        src = torch.div(aid, n, rounding_mode="floor")
+        out_idx, in_idx = torch.nonzero(src == me).reshape(-1), torch.nonzero(dst == me).reshape(-1)
+        send_ids, need_ids = aid[out_idx], aid[in_idx]
+        counts = torch.stack([torch.bincount(dst[out_idx], minlength=world),
+                              torch.bincount(src[in_idx], minlength=world)]).tolist()      # split sizes of the all-to-all
+        rec = sh.pack((send_ids - sh.first).to(torch.int32))                                # [rows, n_send]
+        got = comm.all_to_all_v(rec.t().contiguous(), counts[0], counts[1])                 # [n_need, rows], ascending ids
+        anc = anc_all[sh.first:sh.first + n].to(torch.int32).contiguous()
+        sh.resample_apply(anc, need_ids.to(torch.int32), got.t().contiguous())
         self.resamples += 1
         return int(need_ids.numel())
 

@@ -34,6 +34,9 @@ class NumpyShard:
         anc = OraclePF.ancestors(logw_all.numpy(), u0)
         return torch.from_numpy(anc[self.first:self.first + self.n].astype(np.int32))
 
+    def ancestors_all(self, logw_all, gmax, u0):
+        return torch.from_numpy(OraclePF.ancestors(logw_all.numpy(), u0).astype(np.int32))
+
     def pack(self, local_idx):
         return torch.from_numpy(self.o.record_of(local_idx.numpy().astype(np.int64)).copy())
 

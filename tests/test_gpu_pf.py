@@ -169,6 +169,8 @@ def test_two_shards_with_record_exchange_equal_one_shard(pkg):
     full_anc = full.ancestors(full.logw_tensor(), gmax, u0)
     full.resample_apply(full_anc, None, None)
     ancs = [h.ancestors(logw_all, gmax, u0) for h in halves]
+    for h in halves:                                   # the whole-filter table every rank computes for itself
+        assert torch.equal(h.ancestors_all(logw_all, gmax, u0), torch.cat(ancs))
     assert np.array_equal(torch.cat(ancs).cpu().numpy(), full_anc.cpu().numpy())
     moved = 0
     packs = []
