@@ -419,6 +419,7 @@ __device__ __forceinline__ void request_chunk_b(const DdCtx& c, int2 t, int chun
     const auto ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.Y), (short)0, c.ld * c.pitch * 4, 0x00020000);
     const int tid = threadIdx.x;
     const int voff = (stage_row(tid) * c.pitch + 4 * (tid & 3)) * 4;
+    if (c.dbg & 8) t = make_int2(0, 0);        // experiment (DBG build only sets dbg): every tile reads the panels of tile (0,0)
     gx = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, (t.x * TILE * c.pitch + chunk * KB) * 4, 0));
     gy = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, voff, (t.y * TILE * c.pitch + chunk * KB) * 4, 0));
 }
