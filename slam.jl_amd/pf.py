@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import numpy as np
 
@@ -259,18 +260,71 @@ class _SingleProcess:
         return send
 
 
+class ShmScalars:
+    """All-gather of a few float64 per rank through a shared-memory page, for ranks of ONE node.
+
+    The per-step exchange of a sharded filter is three scalars per rank that the HOST needs (Neff decides about
+    resampling): through a device collective that is a host-to-device copy, a collective launch and a read-back,
+    ~50 us, against a few microseconds here.  Layout [parity][rank][8 float64], entry 7 = the sequence number of the
+    call, written last; a call spins until every rank's entry shows its number.  Two parities: a rank can be at most
+    one call ahead of the slowest one (it needs everybody's entry of call s before it can write call s + 1), so
+    the page of call s is not overwritten while anybody still reads it."""
+    WIDTH = 8
+
+    def __init__(self, dist, rank, world):
+        import socket
+        import uuid
+        hosts = [None] * world
+        dist.all_gather_object(hosts, socket.gethostname())
+        if len(set(hosts)) != 1 or not os.path.isdir("/dev/shm"):
+            raise RuntimeError("ranks are not on one node")
+        name = [f"/dev/shm/slamhip-{uuid.uuid4().hex}" if rank == 0 else None]
+        dist.broadcast_object_list(name, src=0)
+        self.rank, self.world, self.seq = rank, world, 0
+        shape = (2, world, self.WIDTH)
+        if rank == 0:
+            np.zeros(shape, dtype=np.float64).tofile(name[0])
+        dist.barrier()
+        self.mem = np.memmap(name[0], dtype=np.float64, mode="r+", shape=shape)
+        dist.barrier()
+        if rank == 0:
+            os.unlink(name[0])                       # the mappings keep the page alive; nothing is left behind in /dev/shm
+
+    def all_gather(self, vec):
+        assert len(vec) < self.WIDTH
+        self.seq += 1
+        page = self.mem[self.seq & 1]
+        mine = page[self.rank]
+        mine[:len(vec)] = vec
+        mine[self.WIDTH - 1] = self.seq              # published last (x86 keeps the order of the stores)
+        flags = page[:, self.WIDTH - 1]
+        spins = 0
+        while not (flags == self.seq).all():
+            spins += 1
+            if spins > 50_000_000:
+                raise RuntimeError("shared-memory exchange: a rank did not arrive")
+        return page[:, :len(vec)].tolist()
+
+
 class TorchComm:
     """torch.distributed (nccl = RCCL over xGMI on the GPUs, gloo in the CPU tests).
 
     With the gloo backend device tensors are staged through the host (gloo's CUDA support is partial): that
-    is how several ranks can rehearse the real GPU shards on ONE card; RCCL runs never take that path."""
+    is how several ranks can rehearse the real GPU shards on ONE card; RCCL runs never take that path.
+    The per-step scalar exchange goes through shared memory when all ranks share a node (ShmScalars)."""
 
-    def __init__(self, device):
+    def __init__(self, device, shm_scalars=True):
         import torch.distributed as dist
         self.dist = dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.device = device
         self.stage = dist.get_backend() == "gloo"
+        self.shm = None
+        if shm_scalars and self.world > 1 and os.environ.get("SLAMHIP_SHM_SCALARS", "1") != "0":
+            try:
+                self.shm = ShmScalars(dist, self.rank, self.world)
+            except RuntimeError:
+                self.shm = None                      # several nodes: the collective below
 
     def _in(self, t):
         return t.cpu() if self.stage and t.is_cuda else t
@@ -292,6 +346,8 @@ class TorchComm:
 
     def all_gather_scalars(self, vec):
         """[world][len(vec)] float64 table, rows in rank order."""
+        if self.shm is not None:
+            return self.shm.all_gather([float(v) for v in vec])
         import torch
         t = torch.tensor(list(vec), dtype=torch.float64, device="cpu" if self.stage else self.device)
         out = torch.empty(self.world * t.numel(), dtype=torch.float64, device=t.device)

@@ -12,11 +12,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_world(world, tmp_path, port, mode="known"):
-    out = str(tmp_path / f"w{world}{mode}")
+def run_world(world, tmp_path, port, mode="known", shm="1"):
+    out = str(tmp_path / f"w{world}{mode}{shm}")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "pf_gloo_worker.py"), out, mode]
-    env = dict(os.environ, OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1", SLAMHIP_SHM_SCALARS=shm)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     parts = [np.load(f"{out}.rank{k}.npz") for k in range(world)]
@@ -40,6 +40,12 @@ def test_sharded_driver_matches_single_rank(tmp_path):
         assert np.allclose(got["mean_pose"], one["mean_pose"], rtol=1e-12, atol=1e-12)
         for mp in got["all_mean"]:                               # every rank holds the same global estimate
             assert np.allclose(mp, got["mean_pose"], rtol=0, atol=1e-14)
+    # the per-step scalars travel through shared memory by default; the torch.distributed collective must agree
+    coll = run_world(2, tmp_path, 29634, shm="0")
+    shm = run_world(2, tmp_path, 29635, shm="1")
+    for key in ("pose", "lm", "logw", "info"):
+        assert np.array_equal(coll[key], shm[key]), key
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("slamhip-")]       # nothing left behind
 
 
 @pytest.mark.timeout(600)
