@@ -43,7 +43,20 @@ struct slam_pf {
     void* pose[2];       // [3][n]
     void* lm[2];         // [nl][5][n]
     void* logw;          // [n]
-    int cur;             // which of the two state buffers is live
+    int cur;             // landmarks: the buffer legacy (non-lazy) kernels work on; valid when !lazy_dirty
+    int pcur;            // poses: which of the two buffers is live
+    // Lazy resampling (whole filter on this shard): a resampling step permutes POSES and composes ancestor tables; a
+    // landmark's records move only when the landmark is next updated.  Landmark l's record of particle p sits in
+    // buffer lbuf[l] at slot tab[ltab[l]][p] (ltab = -1: slot p).  See "lazy resampling" below.
+    std::vector<int8_t> lbuf;
+    std::vector<int16_t> ltab;
+    std::vector<int> tref;       // landmarks referring to each table
+    std::vector<int32_t> prior;  // staging scratch: a landmark's location before the current call (-1: not yet observed in it)
+    int32_t* d_tab[2];           // [PF_TAB_MAX][n] ancestor tables, two sides (composition is out of place)
+    int tside;
+    int lazy_dirty;              // some landmark is not (buffer cur, identity table)
+    int lazy_off;                // SLAMHIP_PF_EAGER=1: always the eager gather
+    int32_t* d_lmeta;            // [nl] per-landmark work list of the materialise kernel
     std::vector<char> seen;
     int32_t* h_ids;      // pinned, [2][ocap]: observation landmark ids (0-based; bit 30 marks "new landmark"); two
     double* h_obs;       // pinned, [2][ocap][2]   staging slots used alternately, each guarded by an event, read by the kernels
@@ -156,6 +169,14 @@ __global__ __launch_bounds__(256) void pf_init_lm_kernel(T* __restrict__ lm, int
 constexpr int32_t NEW_FLAG = 1 << 30;       // observation code: first sighting of this landmark
 constexpr int32_t FRESH_FLAG = 1 << 29;     // a further observation of a landmark first seen in the SAME call
 constexpr int32_t ID_MASK = FRESH_FLAG - 1;
+// second staged word per observation: where this observation's landmark record is read and written
+constexpr int32_t META_TAB = 0xff;          // table index + 1 (0: the particle's own slot)
+constexpr int32_t META_RBUF = 1 << 8;       // buffer the record is read from
+constexpr int32_t META_WBUF = 1 << 9;       // buffer the updated record goes to (slot p)
+constexpr int META_PRIOR_SHIFT = 10;        // bits 10..18: table + 1 and buffer of the record as it was BEFORE this call
+                                            // (the FastSLAM-2.0 proposal reads every observation against the prior map)
+constexpr int PF_OCAP = 1024;               // observations per call; the meta words sit PF_OCAP ints behind the codes
+constexpr int PF_TAB_MAX = 64;              // live ancestor tables before the maps are materialised
 
 // One landmark record of one particle (5 strided values).
 template <typename T>
@@ -268,21 +289,31 @@ __device__ __forceinline__ void lm_update(T* __restrict__ row, int64_t n, const 
 // The m known-id observations of one particle at pose (x, y, phi), in order: F2 on a landmark the filter has seen,
 // F3 on a first sighting.  The record of observation i+1 is requested before observation i is processed (two
 // records in flight per particle); a repeat of the same landmark in consecutive observations is re-read after
-// the store instead.
+// the store instead.  Records are read where the lazy resampling left them (obs_src: buffer + slot through the
+// landmark's ancestor table) and written to the particle's own slot of the buffer the staging chose.
 template <typename T>
-__device__ __forceinline__ void apply_known(T* __restrict__ lm, int64_t n, int64_t p, const double* s_obs, const int32_t* s_ids,
-                                            int m, T x, T y, T phi, T R00, T R10, T R01, T R11, bool valid, T& lw) {
+__device__ __forceinline__ const T* obs_src(const T* lm0, const T* lm1, const int32_t* __restrict__ tabs, int64_t n, int64_t p,
+                                            int32_t code, int32_t meta) {
+    const int t = meta & META_TAB;
+    const int64_t slot = t ? (int64_t)tabs[(size_t)(t - 1) * n + p] : p;
+    return ((meta & META_RBUF) ? lm1 : lm0) + (size_t)(code & ID_MASK) * 5 * n + slot;
+}
+
+template <typename T>
+__device__ __forceinline__ void apply_known(T* lm0, T* lm1, const int32_t* __restrict__ tabs, int64_t n, int64_t p,
+                                            const double* s_obs, const int32_t* s_ids, const int32_t* s_meta, int m, T x, T y,
+                                            T phi, T R00, T R10, T R01, T R11, bool valid, T& lw) {
     LmRow<T> pre = {0, 0, 0, 0, 0};
     bool have = false;
     if (m > 0 && !(s_ids[0] & NEW_FLAG)) {
-        pre = load_row<T>(lm + (size_t)(s_ids[0] & ID_MASK) * 5 * n + p, n);
+        pre = load_row<T>(obs_src<T>(lm0, lm1, tabs, n, p, s_ids[0], s_meta[0]), n);
         have = true;
     }
     for (int i = 0; i < m; ++i) {
-        const int32_t code = s_ids[i];
+        const int32_t code = s_ids[i], meta = s_meta[i];
         const int l = code & ID_MASK;
         const T r = (T)s_obs[2 * i], b = (T)s_obs[2 * i + 1];
-        T* row = lm + (size_t)l * 5 * n + p;
+        T* row = ((meta & META_WBUF) ? lm1 : lm0) + (size_t)l * 5 * n + p;
         LmRow<T> cur = pre;
         const bool have_cur = have;
         have = false;
@@ -290,7 +321,7 @@ __device__ __forceinline__ void apply_known(T* __restrict__ lm, int64_t n, int64
             const int32_t nc = s_ids[i + 1];
             const int nl = nc & ID_MASK;
             if (!(nc & NEW_FLAG) && nl != l) {            // uniform
-                pre = load_row<T>(lm + (size_t)nl * 5 * n + p, n);
+                pre = load_row<T>(obs_src<T>(lm0, lm1, tabs, n, p, nc, s_meta[i + 1]), n);
                 have = true;
             }
         }
@@ -298,7 +329,7 @@ __device__ __forceinline__ void apply_known(T* __restrict__ lm, int64_t n, int64
             lm_init<T>(row, n, x, y, phi, r, b, R00, R10, R01, R11, valid);
             continue;
         }
-        if (!have_cur) cur = load_row<T>(row, n);
+        if (!have_cur) cur = load_row<T>(obs_src<T>(lm0, lm1, tabs, n, p, code, meta), n);
         lm_update<T>(row, n, cur, x, y, phi, r, b, R00, R10, R01, R11, valid, lw);
     }
 }
@@ -306,16 +337,18 @@ __device__ __forceinline__ void apply_known(T* __restrict__ lm, int64_t n, int64
 // F1 + F2/F3 (+ F4 partials): one pass over the particle -- predict (PREDICT), the m known-id updates, and
 // (STATS) the block's weight statistics, so that a filter step is ONE sweep of HBM instead of five launches.
 template <typename T, bool PREDICT, bool STATS>
-__global__ __launch_bounds__(256) void pf_step_kernel(T* __restrict__ pose, T* __restrict__ lm, T* __restrict__ logw,
+__global__ __launch_bounds__(256) void pf_step_kernel(T* __restrict__ pose, T* lm0, T* lm1, const int32_t* __restrict__ tabs,
+                                                       T* __restrict__ logw,
                                                        int64_t n, int64_t first, uint32_t step, uint64_t seed, T V, T G,
                                                        T wheelbase, T sigV, T sigG, T dt, const double* __restrict__ z,
                                                        const int32_t* __restrict__ ids, int m, T R00, T R10, T R01, T R11,
                                                        double* __restrict__ part, T pend) {
     // the observation list may live in pinned HOST memory (zero-copy staging): one read per workgroup into LDS
-    extern __shared__ double s_obs[];              // [m][2] doubles, then [m] ints
+    extern __shared__ double s_obs[];              // [m][2] doubles, then [m] codes, then [m] meta words
     int32_t* s_ids = reinterpret_cast<int32_t*>(s_obs + 2 * m);
+    int32_t* s_meta = s_ids + m;
     for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) s_obs[i] = z[i];
-    for (int i = threadIdx.x; i < m; i += blockDim.x) s_ids[i] = ids[i];
+    for (int i = threadIdx.x; i < m; i += blockDim.x) { s_ids[i] = ids[i]; s_meta[i] = ids[PF_OCAP + i]; }
     __syncthreads();
     const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = pi < n;
@@ -334,7 +367,7 @@ __global__ __launch_bounds__(256) void pf_step_kernel(T* __restrict__ pose, T* _
         if (valid) { pose[p] = x; pose[n + p] = y; pose[2 * n + p] = phi; }
     }
     T lw = logw[p] - pend;        // `pend`: the normalisation shift deferred by slam_pf_normalize (0 if none)
-    apply_known<T>(lm, n, p, s_obs, s_ids, m, x, y, phi, R00, R10, R01, R11, valid, lw);
+    apply_known<T>(lm0, lm1, tabs, n, p, s_obs, s_ids, s_meta, m, x, y, phi, R00, R10, R01, R11, valid, lw);
     if (valid) logw[p] = lw;
     // (folding the partials in the last workgroup to finish was tried: its agent-scope release/acquire is an L2
     //  write-back + invalidate on this multi-XCD part and doubled the kernel's time; a 1-workgroup fold kernel follows)
@@ -354,15 +387,17 @@ __global__ __launch_bounds__(256) void pf_step_kernel(T* __restrict__ pose, T* _
 // (Keeping the 16 records in registers between the passes, all requested up front, was measured: 166 VGPRs, three
 //  waves per SIMD instead of six, and the step went from 107 to 122 us on the same box.)
 template <typename T>
-__global__ __launch_bounds__(256) void pf_proposal_kernel(T* __restrict__ pose, T* __restrict__ lm, T* __restrict__ logw,
+__global__ __launch_bounds__(256) void pf_proposal_kernel(T* __restrict__ pose, T* lm0, T* lm1, const int32_t* __restrict__ tabs,
+                                                           T* __restrict__ logw,
                                                            int64_t n, int64_t first, uint32_t step, uint64_t seed, T V, T G,
                                                            T wheelbase, T lq00, T lq10, T lq11, T dt,
                                                            const double* __restrict__ z, const int32_t* __restrict__ ids,
                                                            int m, T R00, T R10, T R01, T R11, double* __restrict__ part, T pend) {
-    extern __shared__ double s_obs[];              // [m][2] doubles, then [m] ints
+    extern __shared__ double s_obs[];              // [m][2] doubles, then [m] codes, then [m] meta words
     int32_t* s_ids = reinterpret_cast<int32_t*>(s_obs + 2 * m);
+    int32_t* s_meta = s_ids + m;
     for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) s_obs[i] = z[i];
-    for (int i = threadIdx.x; i < m; i += blockDim.x) s_ids[i] = ids[i];
+    for (int i = threadIdx.x; i < m; i += blockDim.x) { s_ids[i] = ids[i]; s_meta[i] = ids[PF_OCAP + i]; }
     __syncthreads();
     const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = pi < n;
@@ -383,7 +418,7 @@ __global__ __launch_bounds__(256) void pf_proposal_kernel(T* __restrict__ pose, 
         const int32_t code = s_ids[i];
         if (code & (NEW_FLAG | FRESH_FLAG)) continue;  // a landmark first seen in this call says nothing about the pose
         const T r = (T)s_obs[2 * i], b = (T)s_obs[2 * i + 1];
-        const LmRow<T> cur = load_row<T>(lm + (size_t)code * 5 * n + p, n);
+        const LmRow<T> cur = load_row<T>(obs_src<T>(lm0, lm1, tabs, n, p, code, s_meta[i] >> META_PRIOR_SHIFT), n);   // the prior map
         const T dx = cur.lx - xm, dy = cur.ly - ym;
         const T d2 = dx * dx + dy * dy;
         T d, h00, h01, h10, h11;
@@ -451,7 +486,7 @@ __global__ __launch_bounds__(256) void pf_proposal_kernel(T* __restrict__ pose, 
     const T pn = wrap_pi<T>(phi + Vn * dt * sin(Gn) / wheelbase);
     if (valid) { pose[p] = xn; pose[n + p] = yn; pose[2 * n + p] = pn; logw[p] = lw; }
     T unused = 0;
-    apply_known<T>(lm, n, p, s_obs, s_ids, m, xn, yn, pn, R00, R10, R01, R11, valid, unused);
+    apply_known<T>(lm0, lm1, tabs, n, p, s_obs, s_ids, s_meta, m, xn, yn, pn, R00, R10, R01, R11, valid, unused);
     block_weight_stats<T>(lw, xn, yn, pn, valid, 1, part);
 }
 
@@ -773,6 +808,67 @@ __global__ __launch_bounds__(256) void pf_pack_kernel(const T* __restrict__ pose
     rec[(size_t)row * cnt + c] = src_row[idx[c]];
 }
 
+// ---- lazy resampling ------------------------------------------------------------------------------------
+// When the whole filter lives on this shard, resampling does not copy the particles' maps (2.7 GB per step at
+// 262144 x 512).  It gathers the POSES and composes one small table per group of landmarks: landmark l's record of
+// particle p is found in buffer lbuf[l] at slot tab[ltab[l]][p].  With known correspondences every particle updates
+// the SAME landmarks in a call, so an update reads through the table, writes the particle's own slot of the OTHER
+// buffer, and the landmark is "identity" again; landmarks that were identity at a resampling share the new table
+// (= the ancestor vector), older tables are composed with it (tab'[p] = tab[anc[p]]) and die when their last
+// landmark is updated.  At m observations per call there are about nl / m live tables: a resampling step moves
+// megabytes instead of gigabytes.  Everything that wants plain maps (download, pack, the unknown-correspondence
+// sweep, a sharded filter's record exchange) calls pf_materialise first: the eager gather, landmark by landmark.
+template <typename T>
+__global__ __launch_bounds__(256) void pf_pose_gather_kernel(const T* __restrict__ pose_old, T* __restrict__ pose_new, int64_t n,
+                                                              const int32_t* __restrict__ anc) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int64_t a = anc[p];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) pose_new[(size_t)r * n + p] = pose_old[(size_t)r * n + a];
+}
+
+struct TabList {
+    int32_t count;               // live tables to compose
+    int32_t fresh;               // index of the new table (= anc), or -1
+    int16_t idx[PF_TAB_MAX];
+};
+
+__global__ __launch_bounds__(256) void pf_compose_kernel(const int32_t* __restrict__ tin, int32_t* __restrict__ tout, int64_t n,
+                                                          const int32_t* __restrict__ anc, TabList tl) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int32_t a = anc[p];
+    if (tl.fresh >= 0) tout[(size_t)tl.fresh * n + p] = a;
+    for (int i = 0; i < tl.count; ++i) {
+        const size_t t = (size_t)tl.idx[i];
+        tout[t * n + p] = tin[t * n + a];
+    }
+}
+
+// work[l]: -1 nothing to do, else (table + 1) | source buffer << 8 | destination buffer << 9
+constexpr int MAT_LMS = 12;      // landmarks per thread
+template <typename T>
+__global__ __launch_bounds__(256) void pf_materialise_kernel(T* lm0, T* lm1, const int32_t* __restrict__ tabs, int64_t n, int nl,
+                                                              const int32_t* __restrict__ work) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int l0 = blockIdx.y * MAT_LMS, l1 = l0 + MAT_LMS < nl ? l0 + MAT_LMS : nl;
+    for (int l = l0; l < l1; ++l) {
+        const int32_t w = work[l];
+        if (w < 0) continue;                                   // (uniform)
+        const int t = w & META_TAB;
+        const int64_t slot = t ? (int64_t)tabs[(size_t)(t - 1) * n + p] : p;
+        const T* src = ((w & META_RBUF) ? lm1 : lm0) + (size_t)l * 5 * n + slot;
+        T* dst = ((w & META_WBUF) ? lm1 : lm0) + (size_t)l * 5 * n + p;
+        T v[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) v[c] = src[(size_t)c * n];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) dst[(size_t)c * n] = v[c];
+    }
+}
+
 template <typename P>
 int pf_alloc(P** p, size_t bytes, hipStream_t s) {
     *p = nullptr;
@@ -805,7 +901,7 @@ extern "C" int slam_pf_destroy(slam_pf_t h) {
         if (h->pose[b]) (void)hipFree(h->pose[b]);
         if (h->lm[b]) (void)hipFree(h->lm[b]);
     }
-    void* devs[] = {h->logw, h->d_part, h->d_out, h->d_cdf, h->d_bsum, h->d_src};
+    void* devs[] = {h->logw, h->d_part, h->d_out, h->d_cdf, h->d_bsum, h->d_src, h->d_tab[0], h->d_tab[1], h->d_lmeta};
     for (void* p : devs)
         if (p) (void)hipFree(p);
     if (h->h_ids) (void)hipHostFree(h->h_ids);
@@ -828,7 +924,7 @@ static int pf_create_impl(slam_pf* h) {
         if ((rc = pf_alloc(&h->lm[b], h->esz * 5 * n * (size_t)h->nl, h->stream))) return rc;
     }
     if ((rc = pf_alloc(&h->logw, h->esz * n, h->stream))) return rc;
-    h->ocap = 1024;
+    h->ocap = PF_OCAP;
     h->red_blocks = grid_for(h->n);                  // one partial record per 256 particles
     if ((rc = pf_alloc(&h->d_part, sizeof(double) * 8 * h->red_blocks, h->stream))) return rc;
     if ((rc = pf_alloc(&h->d_out, sizeof(double) * 8, h->stream))) return rc;
@@ -836,7 +932,11 @@ static int pf_create_impl(slam_pf* h) {
     const size_t nb = ((size_t)h->n_global + SCAN_BLOCK - 1) / SCAN_BLOCK;
     if ((rc = pf_alloc(&h->d_bsum, sizeof(double) * (nb + 1), h->stream))) return rc;
     if ((rc = pf_alloc(&h->d_src, sizeof(int32_t) * n, h->stream))) return rc;
-    HIP_TRY(hipHostMalloc((void**)&h->h_ids, sizeof(int32_t) * 2 * h->ocap, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&h->h_ids, sizeof(int32_t) * 4 * PF_OCAP, hipHostMallocDefault));
+    memset(h->h_ids, 0, sizeof(int32_t) * 4 * PF_OCAP);
+    for (int b = 0; b < 2; ++b)
+        if ((rc = pf_alloc(&h->d_tab[b], sizeof(int32_t) * (size_t)PF_TAB_MAX * n, h->stream))) return rc;
+    if ((rc = pf_alloc(&h->d_lmeta, sizeof(int32_t) * (size_t)h->nl, h->stream))) return rc;
     HIP_TRY(hipHostMalloc((void**)&h->h_obs, sizeof(double) * 4 * h->ocap, hipHostMallocDefault));
     for (int b = 0; b < 2; ++b) HIP_TRY(hipEventCreateWithFlags(&h->stage_ev[b], hipEventDisableTiming | hipEventDisableSystemFence));
     HIP_TRY(hipHostGetDevicePointer((void**)&h->h_ids_dev, h->h_ids, 0));
@@ -876,7 +976,11 @@ extern "C" int slam_pf_create(slam_pf_t* out, int dtype, int64_t n_local, int64_
     slam_pf* h = new slam_pf();
     h->dtype = dtype; h->device = device; h->esz = dtype == SLAM_F32 ? 4 : 8;
     h->n = n_local; h->n_global = n_global; h->first = first_id; h->nl = max_landmarks;
-    h->seed = seed; h->step = 0; h->cur = 0; h->stream = nullptr;
+    h->seed = seed; h->step = 0; h->cur = 0; h->pcur = 0; h->stream = nullptr;
+    h->lbuf.assign(max_landmarks, 0); h->ltab.assign(max_landmarks, -1); h->tref.assign(PF_TAB_MAX, 0);
+    h->prior.assign(max_landmarks, -1);
+    h->d_tab[0] = h->d_tab[1] = nullptr; h->d_lmeta = nullptr; h->tside = 0; h->lazy_dirty = 0;
+    h->lazy_off = getenv("SLAMHIP_PF_EAGER") && atoi(getenv("SLAMHIP_PF_EAGER")) ? 1 : 0;
     h->pose[0] = h->pose[1] = h->lm[0] = h->lm[1] = h->logw = nullptr;
     h->h_ids = nullptr; h->h_obs = nullptr; h->ocap = 0;
     h->stage_ev[0] = h->stage_ev[1] = nullptr; h->stage_used[0] = h->stage_used[1] = 0; h->stage_slot = 0;
@@ -888,6 +992,87 @@ extern "C" int slam_pf_create(slam_pf_t* out, int dtype, int64_t n_local, int64_
     return SLAM_OK;
 }
 
+// ---- lazy resampling: host bookkeeping ----------------------------------------------------------------------
+static void pf_release_table(slam_pf* h, int l) {
+    if (h->ltab[l] >= 0) {
+        h->tref[h->ltab[l]] -= 1;
+        h->ltab[l] = -1;
+    }
+}
+
+// Bring every landmark to (buffer h->cur, identity table): what the non-lazy kernels expect.  Two passes at most:
+// a landmark that sits in h->cur behind a table cannot be gathered in place, it goes to the other buffer first.
+static int pf_materialise(slam_pf* h) {
+    if (!h->lazy_dirty) return SLAM_OK;
+    const int B = h->cur;
+    std::vector<int32_t> work(h->nl);
+    for (int pass = 0; pass < 2; ++pass) {
+        bool any = false;
+        for (int l = 0; l < h->nl; ++l) {
+            const bool go = pass == 0 ? (h->lbuf[l] == B && h->ltab[l] >= 0) : (h->lbuf[l] != B);
+            work[l] = -1;
+            if (!go) continue;
+            const int dst = pass == 0 ? (B ^ 1) : B;
+            work[l] = (h->ltab[l] + 1) | (h->lbuf[l] ? META_RBUF : 0) | (dst ? META_WBUF : 0);
+            any = true;
+        }
+        if (!any) continue;
+        HIP_TRY(hipMemcpyAsync(h->d_lmeta, work.data(), sizeof(int32_t) * h->nl, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));             // `work` is pageable host memory
+        const dim3 grid(grid_for(h->n), (h->nl + MAT_LMS - 1) / MAT_LMS);
+        PF_DISPATCH(h,
+                    hipLaunchKernelGGL(pf_materialise_kernel<T>, grid, dim3(256), 0, h->stream, (T*)h->lm[0], (T*)h->lm[1],
+                                       (const int32_t*)h->d_tab[h->tside], h->n, h->nl, (const int32_t*)h->d_lmeta),
+                    hipLaunchKernelGGL(pf_materialise_kernel<T>, grid, dim3(256), 0, h->stream, (T*)h->lm[0], (T*)h->lm[1],
+                                       (const int32_t*)h->d_tab[h->tside], h->n, h->nl, (const int32_t*)h->d_lmeta));
+        HIP_TRY(hipGetLastError());
+        for (int l = 0; l < h->nl; ++l)
+            if (work[l] >= 0) {
+                pf_release_table(h, l);
+                h->lbuf[l] = (int8_t)(pass == 0 ? (B ^ 1) : B);
+            }
+    }
+    h->lazy_dirty = 0;
+    return SLAM_OK;
+}
+
+// The lazy resampling step itself (whole filter local, d_anc = global = local ancestor ids).  Returns 1 in *done if it
+// was performed, 0 if the caller must take the eager path (table pool exhausted).
+static int pf_resample_lazy(slam_pf* h, const int32_t* d_anc, int* done) {
+    *done = 0;
+    TabList tl;
+    tl.count = 0;
+    tl.fresh = -1;
+    int identity = 0;
+    for (int l = 0; l < h->nl; ++l) identity += h->ltab[l] < 0;
+    int free_idx = -1;
+    for (int t = 0; t < PF_TAB_MAX; ++t) {
+        if (h->tref[t] > 0) tl.idx[tl.count++] = (int16_t)t;
+        else if (free_idx < 0) free_idx = t;
+    }
+    if (identity && free_idx < 0) return SLAM_OK;            // no table left: eager path (which resets all of this)
+    if (identity) tl.fresh = free_idx;
+    const int nxt = h->pcur ^ 1;
+    PF_DISPATCH(h,
+                hipLaunchKernelGGL(pf_pose_gather_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream,
+                                   (const T*)h->pose[h->pcur], (T*)h->pose[nxt], h->n, d_anc),
+                hipLaunchKernelGGL(pf_pose_gather_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream,
+                                   (const T*)h->pose[h->pcur], (T*)h->pose[nxt], h->n, d_anc));
+    hipLaunchKernelGGL(pf_compose_kernel, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (const int32_t*)h->d_tab[h->tside],
+                       h->d_tab[h->tside ^ 1], h->n, d_anc, tl);
+    HIP_TRY(hipGetLastError());
+    h->pcur = nxt;
+    h->tside ^= 1;
+    if (identity) {
+        for (int l = 0; l < h->nl; ++l)
+            if (h->ltab[l] < 0) h->ltab[l] = (int16_t)free_idx;
+        h->tref[free_idx] = identity;
+    }
+    h->lazy_dirty = 1;
+    *done = 1;
+    return SLAM_OK;
+}
+
 extern "C" int slam_pf_set_pose(slam_pf_t h, const double pose[3]) {
     ARG_CHECK(h != nullptr && pose != nullptr, "null argument");
     HIP_TRY(hipSetDevice(h->device));
@@ -896,9 +1081,9 @@ extern "C" int slam_pf_set_pose(slam_pf_t h, const double pose[3]) {
     const double lw = -log((double)h->n_global);
     PF_DISPATCH(h,
                 hipLaunchKernelGGL(pf_set_pose_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream,
-                                   (T*)h->pose[h->cur], (T*)h->logw, h->n, (T)pose[0], (T)pose[1], (T)pose[2], (T)lw),
+                                   (T*)h->pose[h->pcur], (T*)h->logw, h->n, (T)pose[0], (T)pose[1], (T)pose[2], (T)lw),
                 hipLaunchKernelGGL(pf_set_pose_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream,
-                                   (T*)h->pose[h->cur], (T*)h->logw, h->n, (T)pose[0], (T)pose[1], (T)pose[2], (T)lw));
+                                   (T*)h->pose[h->pcur], (T*)h->logw, h->n, (T)pose[0], (T)pose[1], (T)pose[2], (T)lw));
     HIP_TRY(hipGetLastError());
     return SLAM_OK;
 }
@@ -908,6 +1093,7 @@ extern "C" int slam_pf_init_landmarks(slam_pf_t h, const double* lm_xy, int nl, 
     ARG_CHECK(nl >= 0 && nl <= h->nl, "more landmarks than capacity");
     if (nl == 0) return SLAM_OK;
     HIP_TRY(hipSetDevice(h->device));
+    { const int rcm = pf_materialise(h); if (rcm) return rcm; }
     double* d_xy = nullptr;
     HIP_TRY(hipMalloc((void**)&d_xy, sizeof(double) * 2 * nl));
     HIP_TRY(hipMemcpyAsync(d_xy, lm_xy, sizeof(double) * 2 * nl, hipMemcpyHostToDevice, h->stream));
@@ -928,9 +1114,9 @@ extern "C" int slam_pf_predict(slam_pf_t h, double V, double G, double wheelbase
     HIP_TRY(hipSetDevice(h->device));
     const double sV = sqrt(Q[0]), sG = sqrt(Q[3]);
     PF_DISPATCH(h,
-                hipLaunchKernelGGL(pf_predict_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->pose[h->cur],
+                hipLaunchKernelGGL(pf_predict_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->pose[h->pcur],
                                    h->n, h->first, h->step, h->seed, (T)V, (T)G, (T)wheelbase, (T)sV, (T)sG, (T)dt),
-                hipLaunchKernelGGL(pf_predict_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->pose[h->cur],
+                hipLaunchKernelGGL(pf_predict_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->pose[h->pcur],
                                    h->n, h->first, h->step, h->seed, (T)V, (T)G, (T)wheelbase, (T)sV, (T)sG, (T)dt));
     HIP_TRY(hipGetLastError());
     h->step += 1;
@@ -963,23 +1149,39 @@ static int pf_stage(slam_pf* h, const double* z, const int32_t* ids, int m, cons
     const int slot = h->stage_slot;
     h->stage_slot ^= 1;
     if (h->stage_used[slot]) HIP_TRY(hipEventSynchronize(h->stage_ev[slot]));
-    int32_t* hi = h->h_ids + (size_t)slot * h->ocap;
+    int32_t* hi = h->h_ids + (size_t)slot * 2 * PF_OCAP;       // [codes | meta words]
     double* hz = h->h_obs + (size_t)slot * 2 * h->ocap;
     for (int i = 0; i < m; ++i) {
         if (ids) {                                       // (ids == nullptr: unknown correspondences, observations only)
             const int l = ids[i] - 1;
             hi[i] = l | (h->seen[l] == 0 ? NEW_FLAG : h->seen[l] == 2 ? FRESH_FLAG : 0);
             if (!h->seen[l]) h->seen[l] = 2;             // 2: first seen in this call
+            // where the record is read and written: behind a table the update goes to the OTHER buffer (other particles
+            // still read this slot) and the landmark is identity from then on; otherwise it is updated in place
+            const int rb = h->lbuf[l];
+            int wb = rb, tab = 0;
+            if (h->ltab[l] >= 0) {
+                tab = h->ltab[l] + 1;
+                wb = rb ^ 1;
+                pf_release_table(h, l);
+                h->lbuf[l] = (int8_t)wb;
+                if (wb != h->cur) h->lazy_dirty = 1;
+            }
+            if (h->prior[l] < 0) h->prior[l] = tab | (rb ? META_RBUF : 0);
+            hi[PF_OCAP + i] = tab | (rb ? META_RBUF : 0) | (wb ? META_WBUF : 0) | (h->prior[l] << META_PRIOR_SHIFT);
         }
         hz[2 * i] = z[2 * i];
         hz[2 * i + 1] = z[2 * i + 1];
     }
     if (ids)
-        for (int i = 0; i < m; ++i) h->seen[ids[i] - 1] = 1;
+        for (int i = 0; i < m; ++i) {
+            h->seen[ids[i] - 1] = 1;
+            h->prior[ids[i] - 1] = -1;
+        }
     // zero-copy: the kernel reads the pinned slot itself (once per workgroup, into LDS); the caller records the
     // slot's event behind that kernel (pf_stage_done)
     *d_z = h->h_obs_dev + (size_t)slot * 2 * h->ocap;
-    *d_i = h->h_ids_dev + (size_t)slot * h->ocap;
+    *d_i = h->h_ids_dev + (size_t)slot * 2 * PF_OCAP;
     h->stage_last = slot;
     return SLAM_OK;
 }
@@ -1009,11 +1211,11 @@ extern "C" int slam_pf_update_known(slam_pf_t h, const double* z, const int32_t*
     if ((rc = pf_stage(h, z, ids, m, &dz, &di))) return rc;
     const double pend = pf_take_pending(h);              // a deferred normalisation shift is applied on the way
     PF_DISPATCH(h,
-                hipLaunchKernelGGL((pf_step_kernel<T, false, false>), dim3(grid_for(h->n)), dim3(256), (size_t)m * 20, h->stream,
-                                   (T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->first, 0u, h->seed, (T)0, (T)0,
+                hipLaunchKernelGGL((pf_step_kernel<T, false, false>), dim3(grid_for(h->n)), dim3(256), (size_t)m * 24, h->stream,
+                                   (T*)h->pose[h->pcur], (T*)h->lm[0], (T*)h->lm[1], h->d_tab[h->tside], (T*)h->logw, h->n, h->first, 0u, h->seed, (T)0, (T)0,
                                    (T)1, (T)0, (T)0, (T)0, dz, di, m, (T)R[0], (T)R[1], (T)R[2], (T)R[3], (double*)nullptr, (T)pend),
-                hipLaunchKernelGGL((pf_step_kernel<T, false, false>), dim3(grid_for(h->n)), dim3(256), (size_t)m * 20, h->stream,
-                                   (T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->first, 0u, h->seed, (T)0, (T)0,
+                hipLaunchKernelGGL((pf_step_kernel<T, false, false>), dim3(grid_for(h->n)), dim3(256), (size_t)m * 24, h->stream,
+                                   (T*)h->pose[h->pcur], (T*)h->lm[0], (T*)h->lm[1], h->d_tab[h->tside], (T*)h->logw, h->n, h->first, 0u, h->seed, (T)0, (T)0,
                                    (T)1, (T)0, (T)0, (T)0, dz, di, m, (T)R[0], (T)R[1], (T)R[2], (T)R[3], (double*)nullptr, (T)pend));
     HIP_TRY(hipGetLastError());
     return pf_stage_done(h);
@@ -1064,12 +1266,12 @@ extern "C" int slam_pf_step(slam_pf_t h, double V, double G, double wheelbase, c
     const double sV = sqrt(Q[0]), sG = sqrt(Q[3]);
     const double pend = pf_take_pending(h);
     PF_DISPATCH(h,
-                hipLaunchKernelGGL((pf_step_kernel<T, true, true>), dim3(grid_for(h->n)), dim3(256), (size_t)m * 20, h->stream,
-                                   (T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
+                hipLaunchKernelGGL((pf_step_kernel<T, true, true>), dim3(grid_for(h->n)), dim3(256), (size_t)m * 24, h->stream,
+                                   (T*)h->pose[h->pcur], (T*)h->lm[0], (T*)h->lm[1], h->d_tab[h->tside], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
                                    (T)G, (T)wheelbase, (T)sV, (T)sG, (T)dt, dz, di, m, (T)Rz[0], (T)Rz[1], (T)Rz[2], (T)Rz[3],
                                    h->d_part, (T)pend),
-                hipLaunchKernelGGL((pf_step_kernel<T, true, true>), dim3(grid_for(h->n)), dim3(256), (size_t)m * 20, h->stream,
-                                   (T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
+                hipLaunchKernelGGL((pf_step_kernel<T, true, true>), dim3(grid_for(h->n)), dim3(256), (size_t)m * 24, h->stream,
+                                   (T*)h->pose[h->pcur], (T*)h->lm[0], (T*)h->lm[1], h->d_tab[h->tside], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
                                    (T)G, (T)wheelbase, (T)sV, (T)sG, (T)dt, dz, di, m, (T)Rz[0], (T)Rz[1], (T)Rz[2], (T)Rz[3],
                                    h->d_part, (T)pend));
     HIP_TRY(hipGetLastError());
@@ -1101,12 +1303,12 @@ extern "C" int slam_pf_step_proposal(slam_pf_t h, double V, double G, double whe
     if (m && (rc = pf_stage(h, z, ids, m, &dz, &di))) return rc;
     const double pend = pf_take_pending(h);
     PF_DISPATCH(h,
-                hipLaunchKernelGGL(pf_proposal_kernel<T>, dim3(grid_for(h->n)), dim3(256), (size_t)m * 20, h->stream,
-                                   (T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
+                hipLaunchKernelGGL(pf_proposal_kernel<T>, dim3(grid_for(h->n)), dim3(256), (size_t)m * 24, h->stream,
+                                   (T*)h->pose[h->pcur], (T*)h->lm[0], (T*)h->lm[1], h->d_tab[h->tside], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
                                    (T)G, (T)wheelbase, (T)lq00, (T)lq10, (T)lq11, (T)dt, dz, di, m, (T)Rz[0], (T)Rz[1], (T)Rz[2],
                                    (T)Rz[3], h->d_part, (T)pend),
-                hipLaunchKernelGGL(pf_proposal_kernel<T>, dim3(grid_for(h->n)), dim3(256), (size_t)m * 20, h->stream,
-                                   (T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
+                hipLaunchKernelGGL(pf_proposal_kernel<T>, dim3(grid_for(h->n)), dim3(256), (size_t)m * 24, h->stream,
+                                   (T*)h->pose[h->pcur], (T*)h->lm[0], (T*)h->lm[1], h->d_tab[h->tside], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
                                    (T)G, (T)wheelbase, (T)lq00, (T)lq10, (T)lq11, (T)dt, dz, di, m, (T)Rz[0], (T)Rz[1], (T)Rz[2],
                                    (T)Rz[3], h->d_part, (T)pend));
     HIP_TRY(hipGetLastError());
@@ -1126,7 +1328,12 @@ extern "C" int slam_pf_clear_landmarks(slam_pf_t h) {
                 hipLaunchKernelGGL(pf_clear_lm_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->lm[h->cur], h->n, h->nl),
                 hipLaunchKernelGGL(pf_clear_lm_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->lm[h->cur], h->n, h->nl));
     HIP_TRY(hipGetLastError());
-    for (int l = 0; l < h->nl; ++l) h->seen[l] = 0;
+    for (int l = 0; l < h->nl; ++l) {
+        h->seen[l] = 0;
+        pf_release_table(h, l);          // every slot of buffer cur was just overwritten: plain maps again
+        h->lbuf[l] = (int8_t)h->cur;
+    }
+    h->lazy_dirty = 0;
     return SLAM_OK;
 }
 
@@ -1141,6 +1348,7 @@ extern "C" int slam_pf_update_unknown(slam_pf_t h, const double* z, int m, const
     if (m == 0) return SLAM_OK;
     ARG_CHECK(z != nullptr && R != nullptr, "null argument");
     HIP_TRY(hipSetDevice(h->device));
+    { const int rcm = pf_materialise(h); if (rcm) return rcm; }
     const double* dz;
     const int32_t* di;
     const int rc = pf_stage(h, z, nullptr, m, &dz, &di);      // the observation list goes through a staging slot
@@ -1148,10 +1356,10 @@ extern "C" int slam_pf_update_unknown(slam_pf_t h, const double* z, int m, const
     const double pend = pf_take_pending(h);
     PF_DISPATCH(h,
                 hipLaunchKernelGGL(pf_update_unknown_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream,
-                                   (const T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->nl, dz, m, (T)R[0], (T)R[1],
+                                   (const T*)h->pose[h->pcur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->nl, dz, m, (T)R[0], (T)R[1],
                                    (T)R[2], (T)R[3], (T)gate1, (T)gate2, (T)pend, d_assoc),
                 hipLaunchKernelGGL(pf_update_unknown_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream,
-                                   (const T*)h->pose[h->cur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->nl, dz, m, (T)R[0], (T)R[1],
+                                   (const T*)h->pose[h->pcur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->nl, dz, m, (T)R[0], (T)R[1],
                                    (T)R[2], (T)R[3], (T)gate1, (T)gate2, (T)pend, d_assoc));
     HIP_TRY(hipGetLastError());
     return pf_stage_done(h);
@@ -1177,9 +1385,9 @@ static int pf_stats(slam_pf* h, int relative_to_max, double out[7]) {
     { const int rcf = pf_flush_pending(h); if (rcf) return rcf; }
     PF_DISPATCH(h,
                 hipLaunchKernelGGL(pf_stats_kernel<T>, dim3(h->red_blocks), dim3(256), 0, h->stream, (const T*)h->logw,
-                                   (const T*)h->pose[h->cur], h->n, relative_to_max, h->d_part),
+                                   (const T*)h->pose[h->pcur], h->n, relative_to_max, h->d_part),
                 hipLaunchKernelGGL(pf_stats_kernel<T>, dim3(h->red_blocks), dim3(256), 0, h->stream, (const T*)h->logw,
-                                   (const T*)h->pose[h->cur], h->n, relative_to_max, h->d_part));
+                                   (const T*)h->pose[h->pcur], h->n, relative_to_max, h->d_part));
     HIP_TRY(hipGetLastError());
     return pf_fold_and_read(h, relative_to_max, out);
 }
@@ -1266,11 +1474,12 @@ extern "C" int slam_pf_pack(slam_pf_t h, const int32_t* d_local_idx, int cnt, vo
     if (cnt == 0) return SLAM_OK;
     ARG_CHECK(d_local_idx != nullptr && d_records != nullptr, "null argument");
     HIP_TRY(hipSetDevice(h->device));
+    { const int rcm = pf_materialise(h); if (rcm) return rcm; }
     const dim3 grid((cnt + 255) / 256, 3 + 5 * h->nl);
     PF_DISPATCH(h,
-                hipLaunchKernelGGL(pf_pack_kernel<T>, grid, dim3(256), 0, h->stream, (const T*)h->pose[h->cur],
+                hipLaunchKernelGGL(pf_pack_kernel<T>, grid, dim3(256), 0, h->stream, (const T*)h->pose[h->pcur],
                                    (const T*)h->lm[h->cur], h->n, d_local_idx, cnt, (T*)d_records),
-                hipLaunchKernelGGL(pf_pack_kernel<T>, grid, dim3(256), 0, h->stream, (const T*)h->pose[h->cur],
+                hipLaunchKernelGGL(pf_pack_kernel<T>, grid, dim3(256), 0, h->stream, (const T*)h->pose[h->pcur],
                                    (const T*)h->lm[h->cur], h->n, d_local_idx, cnt, (T*)d_records));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1283,26 +1492,44 @@ extern "C" int slam_pf_resample_apply(slam_pf_t h, const int32_t* d_anc, const i
     ARG_CHECK(nremote >= 0, "nremote < 0");
     ARG_CHECK(nremote == 0 || (d_remote_ids != nullptr && d_remote_records != nullptr), "remote buffers missing");
     HIP_TRY(hipSetDevice(h->device));
+    const double lw = -log((double)h->n_global);      // uniform weights again
+    if (nremote == 0 && h->n == h->n_global && !h->lazy_off) {
+        // the whole filter is here: permute the poses, compose the ancestor tables, leave the maps where they are
+        int done = 0;
+        const int rcl = pf_resample_lazy(h, d_anc, &done);
+        if (rcl) return rcl;
+        if (done) {
+            (void)pf_take_pending(h);
+            PF_DISPATCH(h,
+                        hipLaunchKernelGGL(pf_fill_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->logw, h->n, (T)lw),
+                        hipLaunchKernelGGL(pf_fill_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->logw, h->n, (T)lw));
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            return SLAM_OK;
+        }
+    }
+    { const int rcm = pf_materialise(h); if (rcm) return rcm; }
     hipLaunchKernelGGL(pf_src_kernel, dim3(grid_for(h->n)), dim3(256), 0, h->stream, d_anc, h->n, h->first, d_remote_ids,
                        nremote, h->d_src);
-    const int nxt = h->cur ^ 1;
+    const int nxt = h->cur ^ 1, pnxt = h->pcur ^ 1;
     const int nrows = 3 + 5 * h->nl;
     const dim3 grid(grid_for(h->n), (nrows + GATHER_ROWS - 1) / GATHER_ROWS);
     PF_DISPATCH(h,
-                hipLaunchKernelGGL(pf_gather_kernel<T>, grid, dim3(256), 0, h->stream, (const T*)h->pose[h->cur],
-                                   (const T*)h->lm[h->cur], (T*)h->pose[nxt], (T*)h->lm[nxt], h->n, nrows, h->d_src,
+                hipLaunchKernelGGL(pf_gather_kernel<T>, grid, dim3(256), 0, h->stream, (const T*)h->pose[h->pcur],
+                                   (const T*)h->lm[h->cur], (T*)h->pose[pnxt], (T*)h->lm[nxt], h->n, nrows, h->d_src,
                                    (const T*)d_remote_records, nremote),
-                hipLaunchKernelGGL(pf_gather_kernel<T>, grid, dim3(256), 0, h->stream, (const T*)h->pose[h->cur],
-                                   (const T*)h->lm[h->cur], (T*)h->pose[nxt], (T*)h->lm[nxt], h->n, nrows, h->d_src,
+                hipLaunchKernelGGL(pf_gather_kernel<T>, grid, dim3(256), 0, h->stream, (const T*)h->pose[h->pcur],
+                                   (const T*)h->lm[h->cur], (T*)h->pose[pnxt], (T*)h->lm[nxt], h->n, nrows, h->d_src,
                                    (const T*)d_remote_records, nremote));
     (void)pf_take_pending(h);                          // logw is overwritten: a deferred shift is moot
-    const double lw = -log((double)h->n_global);      // uniform weights again
     PF_DISPATCH(h,
                 hipLaunchKernelGGL(pf_fill_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->logw, h->n, (T)lw),
                 hipLaunchKernelGGL(pf_fill_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->logw, h->n, (T)lw));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->cur = nxt;
+    h->pcur = pnxt;
+    for (int l = 0; l < h->nl; ++l) h->lbuf[l] = (int8_t)nxt;      // (materialised above: identity tables, one buffer)
     return SLAM_OK;
 }
 
@@ -1311,7 +1538,8 @@ extern "C" int slam_pf_download(slam_pf_t h, void* pose, void* logw, void* lm) {
     HIP_TRY(hipSetDevice(h->device));
     const size_t n = (size_t)h->n;
     { const int rcf = pf_flush_pending(h); if (rcf) return rcf; }
-    if (pose) HIP_TRY(hipMemcpyAsync(pose, h->pose[h->cur], h->esz * 3 * n, hipMemcpyDeviceToHost, h->stream));
+    if (lm) { const int rcm = pf_materialise(h); if (rcm) return rcm; }
+    if (pose) HIP_TRY(hipMemcpyAsync(pose, h->pose[h->pcur], h->esz * 3 * n, hipMemcpyDeviceToHost, h->stream));
     if (logw) HIP_TRY(hipMemcpyAsync(logw, h->logw, h->esz * n, hipMemcpyDeviceToHost, h->stream));
     if (lm) HIP_TRY(hipMemcpyAsync(lm, h->lm[h->cur], h->esz * 5 * n * (size_t)h->nl, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));

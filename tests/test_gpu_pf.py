@@ -436,3 +436,57 @@ def test_proposal_driver_against_oracle_and_neff_gain(pkg):
     assert np.hypot(*(gpu.mean_pose()[:2] - pose[:2])) < 0.6
     for f in (gpu, one):
         f.shard.close()
+
+
+# ---- lazy resampling ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_lazy_resampling_equals_the_eager_gather(pkg, monkeypatch, dtype):
+    """A filter that lives on one shard resamples lazily: poses are permuted, the maps stay where they are behind
+    composed ancestor tables and move landmark by landmark when next updated (csrc/pf.hip, "lazy resampling").
+    SLAMHIP_PF_EAGER=1 keeps the eager gather of whole particle records.  Both must give the SAME bits, whatever
+    comes in between: landmarks untouched across many resamplings, repeats and first sightings in a call, the
+    FastSLAM-2.0 step, the unknown-correspondence sweep and a record pack (which materialise the maps), and more live
+    tables than the pool holds (one observation per step over 100 landmarks: the eager fallback)."""
+    import torch
+    n, nl, seed = 1500 + 7, 100, 29
+    lm = scene(nl, 41)
+    shards = {}
+    for name, flag in (("lazy", "0"), ("eager", "1")):
+        monkeypatch.setenv("SLAMHIP_PF_EAGER", flag)
+        sh = pkg.PFShard(n, nl, seed, dtype=dtype)
+        sh.set_pose([0.0, 0.0, 0.2])
+        sh.init_landmarks(lm[:90], 0.01, 0.1)                 # 91..100 are first seen later
+        shards[name] = pkg.FastSLAM(sh, None)
+    monkeypatch.delenv("SLAMHIP_PF_EAGER", raising=False)
+    rng = np.random.default_rng(42)
+    pose = np.array([0.0, 0.0, 0.2])
+
+    def same(what):
+        a, b = shards["lazy"].shard.download(), shards["eager"].shard.download()
+        for x, y, part in zip(a, b, ("pose", "logw", "landmarks")):
+            assert np.array_equal(x, y), f"{what}: {part} differ"
+
+    for t in range(90):
+        pose = np.array([pose[0] + 0.3 * math.cos(0.02 + pose[2]), pose[1] + 0.3 * math.sin(0.02 + pose[2]),
+                         pose[2] + 0.3 * math.sin(0.02) / 4.0])
+        if t < 70:                                             # one observation per step: > 64 live tables
+            ids = np.array([(7 * t) % 90 + 1])
+        else:                                                  # several per step, a repeat, first sightings
+            ids = np.array([(3 * t) % 90 + 1, (3 * t + 1) % 90 + 1, (3 * t) % 90 + 1, 91 + t % 10, 91 + t % 10])
+        z = observe(lm, pose, ids, rng)
+        out = []
+        for f in shards.values():
+            out.append(f.step(3.0, 0.02, 4.0, Q, 0.1, z, ids, R, force_resample=(t % 3 != 2), proposal=(t % 5 == 4)))
+        assert out[0] == out[1], f"step {t}"
+        if t % 10 == 9:
+            same(f"step {t}")
+        if t == 75:                                            # a record pack in the lazy state
+            idx = torch.arange(0, 64, dtype=torch.int32, device="cuda")
+            assert torch.equal(shards["lazy"].shard.pack(idx), shards["eager"].shard.pack(idx))
+    # the unknown-correspondence sweep reads every slot: it must see the materialised maps
+    z = observe(lm, pose, np.array([3, 40, 77]), rng)
+    assoc = [f.shard.update_unknown(z, R, 4.0, 25.0, want_assoc=True) for f in shards.values()]
+    assert torch.equal(assoc[0], assoc[1])
+    same("after the unknown-correspondence sweep")
+    for f in shards.values():
+        f.shard.close()
