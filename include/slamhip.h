@@ -240,6 +240,13 @@ int slam_pf_ancestors(slam_pf_t h, const void* d_logw_all, double gmax, double u
  * so each rank knows which of its particles every other rank needs and the record exchange is ONE all-to-all with
  * no request round.  Synchronises. */
 int slam_pf_ancestors_all(slam_pf_t h, const void* d_logw_all, double gmax, double u0, int32_t* d_anc_all);
+/* Resampling of a filter that lives WHOLLY on this shard (n_local == n_global) as one call: cdf of the weights,
+ * systematic-resampling ancestors (offset u0, gmax = the maximum log-weight), then the LAZY step: poses are permuted
+ * and small ancestor tables composed, the particles' maps stay where they are and move landmark by landmark when
+ * next updated (csrc/pf.hip, "lazy resampling"; SLAMHIP_PF_EAGER=1 or an exhausted table pool: the eager gather of
+ * whole records).  Same particles, bit for bit, as slam_pf_copy_logw + slam_pf_ancestors + slam_pf_resample_apply.
+ * Enqueued. */
+int slam_pf_resample_local(slam_pf_t h, double gmax, double u0);
 /* Rows of one particle record: 3 pose rows + 5 rows per landmark (x, y, Pxx, Pxy, Pyy). */
 int slam_pf_record_rows(slam_pf_t h, int* rows);
 /* records[row][c] = state row of local particle d_local_idx[c]  (device buffers, handle dtype):

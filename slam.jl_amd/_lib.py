@@ -106,6 +106,7 @@ SIGNATURES = {
     "slam_pf_weight_stats": (C.c_int, [_h, _dp]),
     "slam_pf_normalize": (C.c_int, [_h, C.c_double, C.c_double]),
     "slam_pf_copy_logw": (C.c_int, [_h, C.c_void_p]),
+    "slam_pf_resample_local": (C.c_int, [_h, C.c_double, C.c_double]),
     "slam_pf_ancestors_all": (C.c_int, [_h, C.c_void_p, C.c_double, C.c_double, C.c_void_p]),
     "slam_pf_ancestors": (C.c_int, [_h, C.c_void_p, C.c_double, C.c_double, C.c_void_p]),
     "slam_pf_record_rows": (C.c_int, [_h, C.POINTER(C.c_int)]),

@@ -75,6 +75,7 @@ struct slam_pf {
     double* d_cdf;       // [n_global]
     double* d_bsum;      // [scan blocks]
     int32_t* d_src;      // [n] gather source: >= 0 local index, < 0: -(recv position + 1)
+    int32_t* d_anc;      // [n] ancestors of slam_pf_resample_local
     int red_blocks;
 };
 
@@ -680,10 +681,11 @@ constexpr int SCAN_BLOCK = 1024;
 // per-block inclusive scan of w = exp(logw - max) (double) + block totals
 template <typename T>
 __global__ __launch_bounds__(SCAN_BLOCK) void pf_scan1_kernel(const T* __restrict__ logw_all, int64_t n, double gmax,
-                                                               double* __restrict__ cdf, double* __restrict__ bsum) {
+                                                               double* __restrict__ cdf, double* __restrict__ bsum, T pend) {
     __shared__ double sh[SCAN_BLOCK];
     const int64_t i = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
-    sh[threadIdx.x] = i < n ? exp((double)logw_all[i] - gmax) : 0.0;
+    // `pend`: a normalisation shift not yet applied to the stored values (rounded as pf_shift_kernel would store it)
+    sh[threadIdx.x] = i < n ? exp((double)(T)(logw_all[i] - pend) - gmax) : 0.0;
     __syncthreads();
     for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
         const double v = threadIdx.x >= off ? sh[threadIdx.x - off] : 0.0;
@@ -846,6 +848,25 @@ __global__ __launch_bounds__(256) void pf_compose_kernel(const int32_t* __restri
     }
 }
 
+// the three per-particle pieces of a lazy resampling step in one launch: poses, tables, uniform weights
+template <typename T>
+__global__ __launch_bounds__(256) void pf_lazy_apply_kernel(const T* __restrict__ pose_old, T* __restrict__ pose_new,
+                                                             const int32_t* __restrict__ tin, int32_t* __restrict__ tout,
+                                                             T* __restrict__ logw, int64_t n, const int32_t* __restrict__ anc,
+                                                             TabList tl, T lw) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int32_t a = anc[p];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) pose_new[(size_t)r * n + p] = pose_old[(size_t)r * n + a];
+    if (tl.fresh >= 0) tout[(size_t)tl.fresh * n + p] = a;
+    for (int i = 0; i < tl.count; ++i) {
+        const size_t t = (size_t)tl.idx[i];
+        tout[t * n + p] = tin[t * n + a];
+    }
+    logw[p] = lw;
+}
+
 // work[l]: -1 nothing to do, else (table + 1) | source buffer << 8 | destination buffer << 9
 constexpr int MAT_LMS = 12;      // landmarks per thread
 template <typename T>
@@ -901,7 +922,7 @@ extern "C" int slam_pf_destroy(slam_pf_t h) {
         if (h->pose[b]) (void)hipFree(h->pose[b]);
         if (h->lm[b]) (void)hipFree(h->lm[b]);
     }
-    void* devs[] = {h->logw, h->d_part, h->d_out, h->d_cdf, h->d_bsum, h->d_src, h->d_tab[0], h->d_tab[1], h->d_lmeta};
+    void* devs[] = {h->logw, h->d_part, h->d_out, h->d_cdf, h->d_bsum, h->d_src, h->d_anc, h->d_tab[0], h->d_tab[1], h->d_lmeta};
     for (void* p : devs)
         if (p) (void)hipFree(p);
     if (h->h_ids) (void)hipHostFree(h->h_ids);
@@ -932,6 +953,7 @@ static int pf_create_impl(slam_pf* h) {
     const size_t nb = ((size_t)h->n_global + SCAN_BLOCK - 1) / SCAN_BLOCK;
     if ((rc = pf_alloc(&h->d_bsum, sizeof(double) * (nb + 1), h->stream))) return rc;
     if ((rc = pf_alloc(&h->d_src, sizeof(int32_t) * n, h->stream))) return rc;
+    if ((rc = pf_alloc(&h->d_anc, sizeof(int32_t) * n, h->stream))) return rc;
     HIP_TRY(hipHostMalloc((void**)&h->h_ids, sizeof(int32_t) * 4 * PF_OCAP, hipHostMallocDefault));
     memset(h->h_ids, 0, sizeof(int32_t) * 4 * PF_OCAP);
     for (int b = 0; b < 2; ++b)
@@ -984,7 +1006,7 @@ extern "C" int slam_pf_create(slam_pf_t* out, int dtype, int64_t n_local, int64_
     h->pose[0] = h->pose[1] = h->lm[0] = h->lm[1] = h->logw = nullptr;
     h->h_ids = nullptr; h->h_obs = nullptr; h->ocap = 0;
     h->stage_ev[0] = h->stage_ev[1] = nullptr; h->stage_used[0] = h->stage_used[1] = 0; h->stage_slot = 0;
-    h->d_part = h->d_out = h->h_out = h->d_cdf = h->d_bsum = nullptr; h->d_src = nullptr;
+    h->d_part = h->d_out = h->h_out = h->d_cdf = h->d_bsum = nullptr; h->d_src = nullptr; h->d_anc = nullptr;
     h->seen.assign(max_landmarks, 0);
     const int rc = pf_create_impl(h);
     if (rc) { slam_pf_destroy(h); return rc; }
@@ -1038,7 +1060,7 @@ static int pf_materialise(slam_pf* h) {
 
 // The lazy resampling step itself (whole filter local, d_anc = global = local ancestor ids).  Returns 1 in *done if it
 // was performed, 0 if the caller must take the eager path (table pool exhausted).
-static int pf_resample_lazy(slam_pf* h, const int32_t* d_anc, int* done) {
+static int pf_resample_lazy(slam_pf* h, const int32_t* d_anc, int* done, bool fused_fill = false) {
     *done = 0;
     TabList tl;
     tl.count = 0;
@@ -1053,13 +1075,24 @@ static int pf_resample_lazy(slam_pf* h, const int32_t* d_anc, int* done) {
     if (identity && free_idx < 0) return SLAM_OK;            // no table left: eager path (which resets all of this)
     if (identity) tl.fresh = free_idx;
     const int nxt = h->pcur ^ 1;
-    PF_DISPATCH(h,
-                hipLaunchKernelGGL(pf_pose_gather_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream,
-                                   (const T*)h->pose[h->pcur], (T*)h->pose[nxt], h->n, d_anc),
-                hipLaunchKernelGGL(pf_pose_gather_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream,
-                                   (const T*)h->pose[h->pcur], (T*)h->pose[nxt], h->n, d_anc));
-    hipLaunchKernelGGL(pf_compose_kernel, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (const int32_t*)h->d_tab[h->tside],
-                       h->d_tab[h->tside ^ 1], h->n, d_anc, tl);
+    if (fused_fill) {
+        const double lw = -log((double)h->n_global);
+        PF_DISPATCH(h,
+                    hipLaunchKernelGGL(pf_lazy_apply_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream,
+                                       (const T*)h->pose[h->pcur], (T*)h->pose[nxt], (const int32_t*)h->d_tab[h->tside],
+                                       h->d_tab[h->tside ^ 1], (T*)h->logw, h->n, d_anc, tl, (T)lw),
+                    hipLaunchKernelGGL(pf_lazy_apply_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream,
+                                       (const T*)h->pose[h->pcur], (T*)h->pose[nxt], (const int32_t*)h->d_tab[h->tside],
+                                       h->d_tab[h->tside ^ 1], (T*)h->logw, h->n, d_anc, tl, (T)lw));
+    } else {
+        PF_DISPATCH(h,
+                    hipLaunchKernelGGL(pf_pose_gather_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream,
+                                       (const T*)h->pose[h->pcur], (T*)h->pose[nxt], h->n, d_anc),
+                    hipLaunchKernelGGL(pf_pose_gather_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream,
+                                       (const T*)h->pose[h->pcur], (T*)h->pose[nxt], h->n, d_anc));
+        hipLaunchKernelGGL(pf_compose_kernel, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (const int32_t*)h->d_tab[h->tside],
+                           h->d_tab[h->tside ^ 1], h->n, d_anc, tl);
+    }
     HIP_TRY(hipGetLastError());
     h->pcur = nxt;
     h->tside ^= 1;
@@ -1439,9 +1472,9 @@ static int pf_ancestors_impl(slam_pf_t h, const void* d_logw_all, double gmax, d
     const int nb = (int)((h->n_global + SCAN_BLOCK - 1) / SCAN_BLOCK);
     PF_DISPATCH(h,
                 hipLaunchKernelGGL(pf_scan1_kernel<T>, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, (const T*)d_logw_all,
-                                   h->n_global, gmax, h->d_cdf, h->d_bsum),
+                                   h->n_global, gmax, h->d_cdf, h->d_bsum, (T)0),
                 hipLaunchKernelGGL(pf_scan1_kernel<T>, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, (const T*)d_logw_all,
-                                   h->n_global, gmax, h->d_cdf, h->d_bsum));
+                                   h->n_global, gmax, h->d_cdf, h->d_bsum, (T)0));
     hipLaunchKernelGGL(pf_scan2_kernel, dim3(1), dim3(256), 0, h->stream, h->d_bsum, nb);
     hipLaunchKernelGGL(pf_ancestor_kernel, dim3(grid_for(count)), dim3(256), 0, h->stream, h->d_cdf, h->d_bsum, nb, h->n_global,
                        first, count, u0, d_anc);
@@ -1460,6 +1493,37 @@ extern "C" int slam_pf_ancestors(slam_pf_t h, const void* d_logw_all, double gma
 extern "C" int slam_pf_ancestors_all(slam_pf_t h, const void* d_logw_all, double gmax, double u0, int32_t* d_anc_all) {
     ARG_CHECK(h != nullptr, "null handle");
     return pf_ancestors_impl(h, d_logw_all, gmax, u0, d_anc_all, 0, h->n_global);
+}
+
+/* Resampling of a filter that lives WHOLLY on this shard, as one call: cdf of the stored weights (a pending
+ * normalisation shift is applied on the fly), ancestors, then the lazy step -- poses, ancestor tables, uniform weights in
+ * one kernel -- or, when the table pool is exhausted or SLAMHIP_PF_EAGER=1, the eager gather.  Same particles, bit for
+ * bit, as slam_pf_copy_logw + slam_pf_ancestors + slam_pf_resample_apply.  gmax: the maximum of the (normalised)
+ * log-weights.  Enqueued. */
+extern "C" int slam_pf_resample_local(slam_pf_t h, double gmax, double u0) {
+    ARG_CHECK(h != nullptr, "null handle");
+    ARG_CHECK(h->n == h->n_global, "slam_pf_resample_local needs the whole filter on this shard");
+    ARG_CHECK(u0 >= 0.0 && u0 < 1.0, "u0 must be in [0, 1)");
+    HIP_TRY(hipSetDevice(h->device));
+    const double pend = pf_take_pending(h);
+    const int nb = (int)((h->n_global + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    PF_DISPATCH(h,
+                hipLaunchKernelGGL(pf_scan1_kernel<T>, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, (const T*)h->logw, h->n_global,
+                                   gmax, h->d_cdf, h->d_bsum, (T)pend),
+                hipLaunchKernelGGL(pf_scan1_kernel<T>, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, (const T*)h->logw, h->n_global,
+                                   gmax, h->d_cdf, h->d_bsum, (T)pend));
+    hipLaunchKernelGGL(pf_scan2_kernel, dim3(1), dim3(256), 0, h->stream, h->d_bsum, nb);
+    hipLaunchKernelGGL(pf_ancestor_kernel, dim3(grid_for(h->n)), dim3(256), 0, h->stream, h->d_cdf, h->d_bsum, nb, h->n_global,
+                       (int64_t)0, h->n, u0, h->d_anc);
+    HIP_TRY(hipGetLastError());
+    int done = 0;
+    if (!h->lazy_off) {
+        const int rc = pf_resample_lazy(h, h->d_anc, &done, true);
+        if (rc) return rc;
+    }
+    if (done) return SLAM_OK;
+    // eager: the stored weights must not carry the shift any more? they are overwritten by the apply -- nothing to flush
+    return slam_pf_resample_apply(h, h->d_anc, nullptr, 0, nullptr);
 }
 
 extern "C" int slam_pf_record_rows(slam_pf_t h, int* rows) {

@@ -195,6 +195,10 @@ class PFShard:
                                     C.c_void_p(anc.data_ptr())))
         return anc
 
+    def resample_local(self, gmax, u0):
+        """Resampling of a filter that lives wholly on this shard, one library call (slam_pf_resample_local)."""
+        check(lib.slam_pf_resample_local(self._h, float(gmax), float(u0)))
+
     def ancestors_all(self, logw_all, gmax, u0):
         """Global ancestor id of EVERY slot of the filter (n_global int32): identical on every rank."""
         import torch
@@ -427,6 +431,12 @@ class FastSLAM:
         import torch
         sh, comm = self.shard, self.comm
         u0 = philox_uniform(self.resamples, STREAM_RESAMPLE, sh.seed)
+        local = getattr(sh, "resample_local", None)
+        if comm.world == 1 and not self.force_exchange and local is not None and self._gmax_norm is not None:
+            local(self._gmax_norm, u0)                                  # the whole filter on one GPU: one library call
+            self._gmax_norm = None
+            self.resamples += 1
+            return 0
         logw_all = comm.all_gather(sh.logw_tensor(), sh.n_global)      # the all-gather of log-weights
         gmax = self._gmax_norm if self._gmax_norm is not None else float(logw_all.max().item())
         self._gmax_norm = None
