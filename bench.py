@@ -232,6 +232,8 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
             "config": {"workload": f"FastSLAM-1.0 known correspondences, {NP} particles x {NL} landmarks, {M} obs/step, fp32, "
                                    f"predict + {M} 2x2 EKF updates + weights + Neff all-reduce (+ resample when Neff < 0.75 Np)"},
             "regimes": res, "weak_scaling": weak,
+            "resampling": ("lazy (filter on one GPU: poses permuted, ancestor tables composed, maps moved on their next update)"
+                           if world == 1 else "eager gather of whole particle records + record exchange (sharded filter)"),
             "roofline": {"bound": "hbm", "achieved": NP * bytes_per / t_step / 1e9, "peak": HBM_PEAK_GBPS * world,
                          "unit": "GB/s", "frac": NP * bytes_per / t_step / 1e9 / (HBM_PEAK_GBPS * world), "traffic": None,
                          "algorithmic_bytes_per_particle_step": bytes_per, "regime": "no_resample (one fused sweep "
