@@ -295,6 +295,7 @@ __device__ __forceinline__ void dd_tile(DdCtx& c, int2 tile, int2 next, smem_t& 
 // register covers 32 consecutive rows of one column = a full 128-byte line per half-wave, so nothing has to pass
 // through LDS), acc is cleared and the k-loop of the next tile is already fed.  Compared with dd_tile this removes
 // two of the six barriers per tile, the per-wave LDS transposes, and the pipeline drain at the tile boundary.
+template <int AUX = 2>        // 2 = non-temporal: the P tile is streamed (see dd_stream_b)
 __device__ __forceinline__ void load_p_mfma(const DdCtx& c, int R0, int C0, float (&pold)[2][16]) {
     const auto rs = band_rsrc(c.P + (size_t)C0 * c.ld, c.ld);
     const int voff = (4 * c.lh * c.ld + c.l31) * 4;
@@ -303,10 +304,11 @@ __device__ __forceinline__ void load_p_mfma(const DdCtx& c, int R0, int C0, floa
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int soff = ((32 * c.wc + 8 * (r >> 2) + (r & 3)) * c.ld + R0 + 64 * c.wr + 32 * rb) * 4;
-            pold[rb][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+            pold[rb][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, AUX));
         }
 }
 
+template <int AUX = 2>
 __device__ __forceinline__ void store_p_mfma(const DdCtx& c, int R0, int C0, const float (&pold)[2][16], f32x16 (&acc)[2]) {
     const auto rs = band_rsrc(c.P + (size_t)C0 * c.ld, c.ld);
     const int voff = (4 * c.lh * c.ld + c.l31) * 4;
@@ -315,7 +317,7 @@ __device__ __forceinline__ void store_p_mfma(const DdCtx& c, int R0, int C0, con
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int soff = ((32 * c.wc + 8 * (r >> 2) + (r & 3)) * c.ld + R0 + 64 * c.wr + 32 * rb) * 4;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pold[rb][r] - acc[rb][r]), rs, voff, soff, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pold[rb][r] - acc[rb][r]), rs, voff, soff, AUX);
             acc[rb][r] = 0.0f;
         }
 }
@@ -482,7 +484,10 @@ __device__ __forceinline__ void mfma_chunk_b(const DdCtx& c, const char* sm, int
 // As dd_stream: processes list[slot], list[slot + nper], ... while they are off-diagonal; NCH = kp / 16 (>= 2).  On
 // entry gx/gy hold the request for chunk 0 of the first tile.  On return `slot` is the first unprocessed position;
 // nothing is in flight for it (the diagonal tiles that follow use the fp32 pipeline and request their own panels).
-template <bool DBG, int NCH, int POFF>
+// The P tile is streamed: read once, written once per launch.  Its loads and stores carry the non-temporal policy
+// (aux = 2), which leaves the XCD's L2 to the panels (one-box A/B: loads -1.5 %, stores -2 %, both -3.5 % of the
+// kernel's time, and the kernels that follow it gain as much again).
+template <bool DBG, int NCH, int POFF, int AUXL = 2, int AUXS = 2>
 __device__ __forceinline__ void dd_stream_b(DdCtx& c, const int2* __restrict__ list, int L, int nper, int& slot, char* sm,
                                             f32x4& gx, f32x4& gy) {
     auto fetch = [&](int sl) { return sl < L ? list[sl] : make_int2(-1, -1); };
@@ -504,7 +509,7 @@ __device__ __forceinline__ void dd_stream_b(DdCtx& c, const int2* __restrict__ l
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             const int pb = (base + ch) & 1;
-            if (ch == PCH && !(DBG && (c.dbg & 4))) load_p_mfma(c, tile.x * TILE, tile.y * TILE, pold);
+            if (ch == PCH && !(DBG && (c.dbg & 4))) load_p_mfma<AUXL>(c, tile.x * TILE, tile.y * TILE, pold);
             mfma_chunk_b<DBG>(c, sm, pb, acc);
             if (ch < NCH - 1) {
                 fill_lds_b<DBG>(c, sm, pb ^ 1, gx, gy);                  // chunk ch + 1 of this tile
@@ -515,7 +520,7 @@ __device__ __forceinline__ void dd_stream_b(DdCtx& c, const int2* __restrict__ l
                 if (next_off) fill_lds_b<DBG>(c, sm, pb ^ 1, gx, gy);    // chunk 0 of the next tile
                 __syncthreads();
                 if (next_off) request_chunk_b(c, next, 1, gx, gy);
-                if (!(DBG && (c.dbg & 1))) store_p_mfma(c, tile.x * TILE, tile.y * TILE, pold, acc);
+                if (!(DBG && (c.dbg & 1))) store_p_mfma<AUXS>(c, tile.x * TILE, tile.y * TILE, pold, acc);
             }
         }
         slot += nper;
@@ -672,7 +677,7 @@ __global__ __launch_bounds__(256) void downdate_f64_mfma(double* __restrict__ P,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int col = C0 + 32 * wc + 16 * cb + 4 * r + kk, row = R0 + 32 * wr + 16 * rb + li;
-                pold[cb][rb][r] = P[(size_t)col * ld + row];
+                pold[cb][rb][r] = P[(size_t)col * ld + row];       // (non-temporal loads/stores: no change here, 15.8 ms either way)
                 acc[cb][rb][r] = 0.0;
             }
         }
