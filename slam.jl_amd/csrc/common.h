@@ -69,6 +69,8 @@ struct slam_ekf {
     double* Kd;       // [npad][kcap]   row-major, double (Joseph: K = PHt*inv(S))
     void* W1;         // [npad][2*kcap] row-major, dtype (Joseph uses both halves: [K|T])
     void* W2;         // [npad][2*kcap] row-major, dtype (Joseph: [T|K])
+    void* Wimg;       // fp32 handles: W1 split into bf16 (h, m, l), stored as the LDS image of the split-bf16 down-date:
+                      // [npad/128 row blocks][kcap/16 chunks][3 splits][128 rows][16 bf16, 16-byte halves swizzled]
     double* Cmat;     // [kcap][kcap]   row-major, double (C = inv(chol(S)) upper, or inv(S) for Joseph)
     double* Smat;     // [kcap][kcap]   double (Joseph: S);  also global scratch for big k
     double* Mwork;    // [kcap][kcap+1] double, factor scratch when it does not fit LDS

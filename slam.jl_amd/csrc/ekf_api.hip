@@ -116,9 +116,9 @@ int ensure_obs_capacity(slam_ekf* h, int nobs) {
 }
 
 static void free_update_workspace(slam_ekf* h) {
-    dev_free(h->PHt); dev_free(h->PHtS); dev_free(h->Kd); dev_free(h->W1); dev_free(h->W2); dev_free(h->Cmat);
+    dev_free(h->PHt); dev_free(h->PHtS); dev_free(h->Kd); dev_free(h->W1); dev_free(h->W2); dev_free(h->Cmat); dev_free(h->Wimg);
     dev_free(h->Smat); dev_free(h->Mwork); dev_free(h->gvec);
-    h->W1 = h->W2 = nullptr;
+    h->W1 = h->W2 = h->Wimg = nullptr;
     h->PHt = h->PHtS = h->Kd = h->Cmat = h->Smat = h->Mwork = h->gvec = nullptr;
     h->kcap = 0;
 }
@@ -145,6 +145,7 @@ int ensure_update_workspace(slam_ekf* h, int m) {
     if ((rc = dev_alloc_zero(&h->Kd, sizeof(double) * (size_t)h->npad * cap, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->W1, h->esz * (size_t)h->npad * 2 * cap, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->W2, h->esz * (size_t)h->npad * 2 * cap, h->stream))) return rc;
+    if (h->dtype == SLAM_F32 && (rc = dev_alloc_zero(&h->Wimg, (size_t)(h->npad / 128) * (cap / 16) * 3 * 4096, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->Cmat, sizeof(double) * (size_t)cap * cap, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->Smat, sizeof(double) * (size_t)cap * cap, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->Mwork, sizeof(double) * (size_t)cap * (cap + 1), h->stream))) return rc;
@@ -245,7 +246,7 @@ extern "C" int slam_ekf_create(slam_ekf_t* out, int dtype, int max_landmarks, in
     h->stage_ev = nullptr; h->stage_pending = 0;
     h->PHtS = nullptr;
     h->kcap = 0;
-    h->W1 = h->W2 = nullptr;
+    h->W1 = h->W2 = h->Wimg = nullptr;
     h->PHt = h->PHtS = h->Kd = h->Cmat = h->Smat = h->Mwork = h->gvec = nullptr;
     h->tiles = nullptr; h->tiles_T = h->tiles_len = h->tiles_cap = 0;
     h->obsbuf = nullptr; h->idfbuf = nullptr; h->ocap = 0;

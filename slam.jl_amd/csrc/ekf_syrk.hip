@@ -88,6 +88,8 @@ struct DdCtx {       // per-thread constants of the down-date kernel
     const float* X;
     const float* Y;
     int ld, pitch, kp, nchunks, dbg, xflags;
+    const char* img;     // pre-split bf16 image of the panel (split-bf16 path, reference form), or null
+    int img_nch;         // chunks of 16 columns per 128-row block in the image
     int wr, wc, l31, lh, q, cl, srow, sc4;
     unsigned long long t_head, t_wait, t_epi, t_total;     // DBG instantiation only (shader clocks, summed over tiles)
 };
@@ -481,6 +483,103 @@ __device__ __forceinline__ void mfma_chunk_b(const DdCtx& c, const char* sm, int
     }
 }
 
+// ---- the same path fed from a PRE-SPLIT panel -------------------------------------------------------------------
+// In the reference form (X = Y = W1) the W1 kernel also writes the panel already split into bf16 (h, m, l) and laid
+// out as this path's LDS image: [row block of 128][chunk of 16 columns][h|m|l][128 rows][32 bytes], the two 16-byte
+// halves of a row exchanged when (row >> 3) is odd -- with a 32-byte pitch that swizzle makes the fragment's
+// ds_read_b128 conflict-free (the four 16-lane groups of the instruction each cover all 64 banks once).  A chunk
+// of a panel is then 12,288 contiguous bytes: the fill is three 16-byte copies per thread, no arithmetic, and the
+// two buffers take 48 KB instead of 72.
+constexpr int IMG_ARR = TILE * 32;              // bytes per [split] array of a chunk
+constexpr int IMG_CHUNK = 3 * IMG_ARR;          // bytes per (row block, chunk)
+typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void request_chunk_p(const DdCtx& c, int2 t, int chunk, u32x4b (&g)[3]) {
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(c.img), (short)0, 0x7fffffff, 0x00020000);
+    const int tid = threadIdx.x;
+    const int sx = (t.x * c.img_nch + chunk) * IMG_CHUNK, sy = (t.y * c.img_nch + chunk) * IMG_CHUNK;
+    // pieces tid, tid + 512, tid + 1024 of the 1536 sixteen-byte pieces [X image | Y image]
+    g[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, sx, 0);
+    g[1] = tid < 256 ? __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + 512) * 16, sx, 0)
+                     : __builtin_amdgcn_raw_buffer_load_b128(rs, (tid - 256) * 16, sy, 0);
+    g[2] = __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + 256) * 16, sy, 0);
+}
+
+__device__ __forceinline__ void fill_lds_p(char* sm, int buf, const u32x4b (&g)[3]) {
+    char* base = sm + buf * (2 * IMG_CHUNK) + threadIdx.x * 16;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) *reinterpret_cast<u32x4b*>(base + j * 8192) = g[j];
+}
+
+template <bool DBG>
+__device__ __forceinline__ void mfma_chunk_p(const DdCtx& c, const char* sm, int buf, f32x16 (&acc)[2]) {
+    if (DBG && (c.dbg & 2)) return;
+    // row r of an array sits at r * 32, its k-half h at ((h ^ (r >> 3)) & 1) * 16; all rows here are l31 + multiples of 32
+    const char* base = sm + buf * (2 * IMG_CHUNK) + c.l31 * 32 + ((c.lh ^ (c.l31 >> 3)) & 1) * 16;
+    bf16x8 a[3];
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp) a[sp] = *reinterpret_cast<const bf16x8*>(base + IMG_CHUNK + sp * IMG_ARR + (32 * c.wc) * 32);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        bf16x8 b[3];
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) b[sp] = *reinterpret_cast<const bf16x8*>(base + sp * IMG_ARR + (64 * c.wr + 32 * rb) * 32);
+        if (!(c.xflags & 2)) __builtin_amdgcn_s_setprio(3);
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[rb], 0, 0, 0);      // (m, m)
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[rb], 0, 0, 0);      // (h, l)
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[rb], 0, 0, 0);      // (l, h)
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[rb], 0, 0, 0);      // (h, m)
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[rb], 0, 0, 0);      // (m, h)
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[rb], 0, 0, 0);      // (h, h)
+        if (!(c.xflags & 2)) __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+template <bool DBG, int NCH, int POFF>
+__device__ __forceinline__ void dd_stream_p(DdCtx& c, const int2* __restrict__ list, int L, int nper, int& slot, char* sm) {
+    auto fetch = [&](int sl) { return sl < L ? list[sl] : make_int2(-1, -1); };
+    constexpr int PCH = NCH - POFF > 0 ? NCH - POFF : 0;
+    int2 tile = fetch(slot);
+    int2 next = fetch(slot + nper);
+    f32x16 acc[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
+    float pold[2][16];
+    u32x4b g[3];
+    request_chunk_p(c, tile, 0, g);
+    fill_lds_p(sm, 0, g);
+    __syncthreads();
+    request_chunk_p(c, tile, 1, g);
+    int base = 0;
+    for (;;) {
+        const bool next_off = next.x >= 0 && next.x != next.y;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int pb = (base + ch) & 1;
+            if (ch == PCH && !(DBG && (c.dbg & 4))) load_p_mfma(c, tile.x * TILE, tile.y * TILE, pold);
+            mfma_chunk_p<DBG>(c, sm, pb, acc);
+            if (ch < NCH - 1) {
+                fill_lds_p(sm, pb ^ 1, g);
+                __syncthreads();
+                if (ch + 2 < NCH) request_chunk_p(c, tile, ch + 2, g);
+                else if (next_off) request_chunk_p(c, next, 0, g);
+            } else {
+                if (next_off) fill_lds_p(sm, pb ^ 1, g);
+                __syncthreads();
+                if (next_off) request_chunk_p(c, next, 1, g);
+                if (!(DBG && (c.dbg & 1))) store_p_mfma(c, tile.x * TILE, tile.y * TILE, pold, acc);
+            }
+        }
+        slot += nper;
+        if (!next_off) return;
+        tile = next;
+        next = fetch(slot + nper);
+        base = (base + NCH) & 1;
+    }
+}
+
 // As dd_stream: processes list[slot], list[slot + nper], ... while they are off-diagonal; NCH = kp / 16 (>= 2).  On
 // entry gx/gy hold the request for chunk 0 of the first tile.  On return `slot` is the first unprocessed position;
 // nothing is in flight for it (the diagonal tiles that follow use the fp32 pipeline and request their own panels).
@@ -542,7 +641,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
                                                                  int pitch, int kp, const int2* __restrict__ tiles, int L,
                                                                  const int32_t* __restrict__ status, int dbg,
                                                                  unsigned long long* __restrict__ prof,
-                                                                 const int32_t* __restrict__ dcount, int joseph) {
+                                                                 const int32_t* __restrict__ dcount, int joseph,
+                                                                 const char* __restrict__ img, int img_nch) {
     if (status[0] != 0) return;
     if (dcount) {                     // observe(): the host's kp is an upper bound
         const int k = 2 * dcount[0];
@@ -555,6 +655,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // provably wave-uniform
     DdCtx c;
     c.P = P; c.X = X; c.Y = Y; c.ld = ld; c.pitch = pitch; c.kp = kp; c.dbg = dbg & 0xff; c.xflags = dbg >> 8;
+    c.img = img; c.img_nch = img_nch;
     c.nchunks = (kp + KC - 1) / KC;                           // kp is a multiple of 16: the last chunk may be half
     c.wr = wave & 1;                  // row half of the tile
     c.wc = wave >> 1;                 // column quarter
@@ -582,6 +683,14 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
     if (BF && tile.x != tile.y && kp >= 5 * KB && kp <= 8 * KB && !joseph) {
         // off-diagonal tiles on the bf16 matrix cores (kp = 80, 96, 112 or 128); the diagonal ones follow below
         char* sm = reinterpret_cast<char*>(&smem[0][0][0][0]);
+        if (img) {                     // the W1 kernel left the panel pre-split, as this path's LDS image
+            switch (kp / KB) {
+                case 8: dd_stream_p<DBG, 8, 7>(c, list, L, nper, slot, sm); break;
+                case 7: dd_stream_p<DBG, 7, 6>(c, list, L, nper, slot, sm); break;
+                case 6: dd_stream_p<DBG, 6, 5>(c, list, L, nper, slot, sm); break;
+                default: dd_stream_p<DBG, 5, 4>(c, list, L, nper, slot, sm); break;
+            }
+        } else {
         request_chunk_b(c, tile, 0, gx[0], gy[0]);
         // (the P tile is requested at the start of the tile's second chunk: one-box A/B of offsets NCH-4 / NCH-2 /
         //  NCH-1 gave 0.411 / 0.408 / 0.402 ms)
@@ -590,6 +699,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
             case 7: dd_stream_b<DBG, 7, 6>(c, list, L, nper, slot, sm, gx[0], gy[0]); break;
             case 6: dd_stream_b<DBG, 6, 5>(c, list, L, nper, slot, sm, gx[0], gy[0]); break;
             default: dd_stream_b<DBG, 5, 4>(c, list, L, nper, slot, sm, gx[0], gy[0]); break;
+        }
         }
         tile = slot < L ? list[slot] : make_int2(-1, -1);
         if (tile.x < 0) return;
@@ -799,7 +909,9 @@ int ensure_tile_order(slam_ekf* h, int T) {
 
 }  // namespace
 
-int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int pitch, const int32_t* dcount, int joseph, int k16) {
+int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int pitch, const int32_t* dcount, int joseph, int k16,
+                    const void* img) {
+#define IMGARGS (const char*)img, h->kcap / 16
     const int n = 3 + 2 * h->N;
     const int edge = h->dtype == SLAM_F32 ? TILE : DT;
     const int rc = ensure_tile_order(h, (n + edge - 1) / edge);
@@ -813,11 +925,11 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
         if (h->debug_flags & 32)  // timing experiments on the split-bf16 path (1 no stores, 2 no MFMAs, 4 no P loads, 16 no split)
             hipLaunchKernelGGL((downdate_f32_mfma<true, 4, 3, true>), dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,
                                (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
-                               h->d_status, h->debug_flags & 0x1f, (unsigned long long*)nullptr, dcount, joseph);
+                               h->d_status, h->debug_flags & 0x1f, (unsigned long long*)nullptr, dcount, joseph, IMGARGS);
         else if (h->debug_flags)      // timing experiments only (SLAMHIP_DEBUG): parts of the kernel switched off
             hipLaunchKernelGGL(downdate_f32_mfma<true>, dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,
                                (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
-                               h->d_status, h->debug_flags, (unsigned long long*)h->dd_prof, dcount, joseph);
+                               h->d_status, h->debug_flags, (unsigned long long*)h->dd_prof, dcount, joseph, IMGARGS);
         else if (!(h->xflags & 4) && kp_total > 32 && kp_total <= 128) {     // (observe(): kp_total is an upper bound; the kernel falls back to dd_tile if the real chunk count differs)
             // streaming (tile-boundary-free) path for the off-diagonal tiles, one instantiation per chunk count
             const int nch = (kp_total + KC - 1) / KC;
@@ -826,16 +938,16 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
 #define DD_LAUNCH_STREAM4()                                                                                            \
     hipLaunchKernelGGL((downdate_f32_mfma<false, 4, 3>), dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, \
                        n, (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,       \
-                       h->d_status, h->xflags << 8, (unsigned long long*)nullptr, dcount, joseph)
+                       h->d_status, h->xflags << 8, (unsigned long long*)nullptr, dcount, joseph, IMGARGS)
 #define DD_LAUNCH_STREAM(NCH)                                                                                          \
     hipLaunchKernelGGL((downdate_f32_mfma<false, NCH>), dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, \
                        n, (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,       \
-                       h->d_status, h->xflags << 8, (unsigned long long*)nullptr, dcount, joseph)
+                       h->d_status, h->xflags << 8, (unsigned long long*)nullptr, dcount, joseph, IMGARGS)
             if (nch >= 3 && !joseph && !(h->xflags & 8))           // split-bf16 path (SLAMHIP_X bit 8 switches it off)
                 hipLaunchKernelGGL((downdate_f32_mfma<false, 4, 3, true>), dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream,
                                    (float*)h->P, h->ld, n, (const float*)X, (const float*)Y, pitch, kp_total,
                                    (const int2*)h->tiles, h->tiles_len, h->d_status, h->xflags << 8,
-                                   (unsigned long long*)nullptr, dcount, joseph);
+                                   (unsigned long long*)nullptr, dcount, joseph, IMGARGS);
             else if (nch == 4) DD_LAUNCH_STREAM4();
             else if (nch == 3) DD_LAUNCH_STREAM(3);
             else DD_LAUNCH_STREAM(2);
@@ -845,7 +957,7 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
         else
             hipLaunchKernelGGL(downdate_f32_mfma<false>, dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,
                                (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
-                               h->d_status, h->xflags << 8, (unsigned long long*)nullptr, dcount, joseph);
+                               h->d_status, h->xflags << 8, (unsigned long long*)nullptr, dcount, joseph, IMGARGS);
     } else {
         hipLaunchKernelGGL(downdate_f64_mfma, dim3(8 * h->tiles_len), dim3(256), 0, h->stream, (double*)h->P, h->ld, n,
                            (const double*)X, (const double*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
@@ -853,4 +965,5 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
     }
     HIP_TRY(hipGetLastError());
     return SLAM_OK;
+#undef IMGARGS
 }

@@ -20,7 +20,8 @@
 #include "common.h"
 #include "device_math.h"
 
-int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int pitch, const int32_t* dcount, int joseph, int k16);   // ekf_syrk.hip
+int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int pitch, const int32_t* dcount, int joseph, int k16,
+                    const void* img);   // ekf_syrk.hip
 
 namespace {
 
@@ -786,10 +787,23 @@ __global__ __launch_bounds__(256) void panel_gemm_kernel(const double* __restric
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 constexpr int W1_THREADS = 512;
 
+// three-way bf16 split of an fp32 value (exact: v = h + m + l), round to nearest even at every level
+__device__ __forceinline__ void split_bf16(float v, unsigned short& h, unsigned short& m, unsigned short& l) {
+    typedef __bf16 bf1;
+    const bf1 bh = (bf1)v;
+    const float r1 = v - (float)bh;
+    const bf1 bm = (bf1)r1;
+    const float r2 = r1 - (float)bm;
+    const bf1 bl = (bf1)r2;
+    h = __builtin_bit_cast(unsigned short, bh);
+    m = __builtin_bit_cast(unsigned short, bm);
+    l = __builtin_bit_cast(unsigned short, bl);
+}
+
 template <typename TO, int NCB>      // NCB = kp / 16
 __device__ __forceinline__ void w1_mfma_body(const double* __restrict__ PHt, int pitchA, const double* __restrict__ Cmat,
                                              int pitchC, double* sC, TO* __restrict__ W1, int pitchW, TO* __restrict__ x,
-                                             int n, const double* __restrict__ g) {
+                                             int n, const double* __restrict__ g, char* __restrict__ img, int img_nch) {
     constexpr int kp = 16 * NCB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, kk = lane >> 4;
@@ -835,6 +849,22 @@ __device__ __forceinline__ void w1_mfma_body(const double* __restrict__ PHt, int
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             W1[(size_t)(r0 + 4 * r + kk) * pitchW + 16 * cb + i] = (TO)acc[cb][r];
+    if (img) {
+        // the same panel, split into bf16 (h, m, l) and laid out as the LDS image of the split-bf16 down-date
+        // (ekf_syrk.hip, "PRE-SPLIT panel"): [row block = this workgroup][chunk cb][split][row][32 B, halves swizzled]
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = (r0 & 127) + 4 * r + kk;                       // row inside the 128-row block
+                unsigned short hh, mm, ll;
+                split_bf16((float)acc[cb][r], hh, mm, ll);
+                char* d = img + ((size_t)(blockIdx.x * img_nch + cb) * 3) * 4096 + rr * 32 + ((((i >> 3) ^ (rr >> 3)) & 1) * 16) + (i & 7) * 2;
+                *reinterpret_cast<unsigned short*>(d) = hh;
+                *reinterpret_cast<unsigned short*>(d + 4096) = mm;
+                *reinterpret_cast<unsigned short*>(d + 8192) = ll;
+            }
+    }
     // x += PHt*g  (ekf.jl:74 with W*v = PHt*(C*C'*v)): lane (i, kk) holds a quarter of row i
     double sx = 0.0;
 #pragma unroll
@@ -854,7 +884,8 @@ __global__ __launch_bounds__(W1_THREADS) void w1_mfma_kernel(const double* __res
                                                              TO* __restrict__ W1, int pitchW, TO* __restrict__ x, int n,
                                                              const double* __restrict__ g,
                                                              const int32_t* __restrict__ status,
-                                                             const int32_t* __restrict__ dcount) {
+                                                             const int32_t* __restrict__ dcount, char* __restrict__ img,
+                                                             int img_nch) {
     if (status[0] != 0) return;
     if (dcount) {
         int m = 0, k = 0;
@@ -863,10 +894,10 @@ __global__ __launch_bounds__(W1_THREADS) void w1_mfma_kernel(const double* __res
     }
     extern __shared__ double sC[];                    // [kp][kp], staged inside the body
     // (the barrier is inside the body, after the wave's PHt loads have been issued)
-    if (kp == 32) w1_mfma_body<TO, 2>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g);
-    else if (kp == 64) w1_mfma_body<TO, 4>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g);
-    else if (kp == 96) w1_mfma_body<TO, 6>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g);
-    else w1_mfma_body<TO, 8>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g);
+    if (kp == 32) w1_mfma_body<TO, 2>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g, img, img_nch);
+    else if (kp == 64) w1_mfma_body<TO, 4>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g, img, img_nch);
+    else if (kp == 96) w1_mfma_body<TO, 6>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g, img, img_nch);
+    else w1_mfma_body<TO, 8>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g, img, img_nch);
 }
 
 // x += PHt * g      (ekf.jl:74 with W*v = PHt*(C*C'*v)); 8 lanes per row
@@ -934,13 +965,15 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form, const int32_t*
     HIP_TRY(hipGetLastError());
     const dim3 pg_grid(h->npad / PG_ROWS, (kp + PG_COLS - 1) / PG_COLS);
     int kp_total;
+    bool use_img = false;      // the W1 kernel also leaves the panel pre-split for the split-bf16 down-date (SLAMHIP_X bit 16: off)
     {   // K5
         KTimer t(h, SLAM_K_W1);
+        use_img = !joseph && kp <= 128 && h->dtype == SLAM_F32 && h->Wimg && !(h->xflags & 16);
         if (!joseph && kp <= 128) {
             // W1 = PHt*C and x += PHt*g on the fp64 matrix cores
             hipLaunchKernelGGL(w1_mfma_kernel<T>, dim3(h->npad / 128), dim3(W1_THREADS), (size_t)kp * kp * sizeof(double),
                                h->stream, (const double*)h->PHt, pitchA, (const double*)h->Cmat, pitchA, kp, W1, pitchW, x, n,
-                               (const double*)h->gvec, h->d_status, dcount);
+                               (const double*)h->gvec, h->d_status, dcount, use_img ? (char*)h->Wimg : (char*)nullptr, h->kcap / 16);
             kp_total = round_up(k, 16);
         } else if (!joseph) {
             // W1 = PHt*C
@@ -964,7 +997,8 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form, const int32_t*
                                h->gvec, h->d_status, dcount);
     }
     HIP_TRY(hipGetLastError());
-    return launch_downdate(h, kp_total, W1, joseph ? (const void*)W2 : (const void*)W1, pitchW, dcount, joseph ? 1 : 0, round_up(k, 16));
+    return launch_downdate(h, kp_total, W1, joseph ? (const void*)W2 : (const void*)W1, pitchW, dcount, joseph ? 1 : 0, round_up(k, 16),
+                           use_img ? h->Wimg : nullptr);
 }
 
 }  // namespace
