@@ -21,59 +21,6 @@ struct PredictParams {   // written by the pose kernel, read by the strip kernel
 // One thread: new pose and P_vv (ekf.jl:24-32, 39-41), and the two scalars the
 // strip needs.  Runs BEFORE the strip kernel on the same stream, so the strip
 // never races with the write of x[2].
-template <typename T>
-__global__ void predict_pose_kernel(T* __restrict__ x, T* __restrict__ P, int ld, double v, double g, double w,
-                                    double Q0, double Q1, double Q2, double Q3, double dt, double* __restrict__ params) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const double phi = (double)x[2];
-    const double s = sin(g + phi), c = cos(g + phi);
-    const double vts = v * dt * s, vtc = v * dt * c;
-    const double Gv[3][3] = {{1.0, 0.0, -vts}, {0.0, 1.0, vtc}, {0.0, 0.0, 1.0}};
-    const double Gu[3][2] = {{dt * c, -vts}, {dt * s, vtc}, {dt * sin(g) / w, v * dt * cos(g) / w}};
-    const double Q[2][2] = {{Q0, Q2}, {Q1, Q3}};   // column-major input
-    double Pvv[3][3], GP[3][3], GQ[3][2], out[3][3];
-    for (int r = 0; r < 3; ++r)
-        for (int cc = 0; cc < 3; ++cc) Pvv[r][cc] = (double)P[(size_t)cc * ld + r];
-    for (int r = 0; r < 3; ++r)
-        for (int cc = 0; cc < 3; ++cc)
-            GP[r][cc] = Gv[r][0] * Pvv[0][cc] + Gv[r][1] * Pvv[1][cc] + Gv[r][2] * Pvv[2][cc];
-    for (int r = 0; r < 3; ++r)
-        for (int cc = 0; cc < 2; ++cc) GQ[r][cc] = Gu[r][0] * Q[0][cc] + Gu[r][1] * Q[1][cc];
-    for (int r = 0; r < 3; ++r)
-        for (int cc = 0; cc < 3; ++cc)
-            out[r][cc] = (GP[r][0] * Gv[cc][0] + GP[r][1] * Gv[cc][1] + GP[r][2] * Gv[cc][2]) +
-                         (GQ[r][0] * Gu[cc][0] + GQ[r][1] * Gu[cc][1]);
-    for (int r = 0; r < 3; ++r)
-        for (int cc = 0; cc < 3; ++cc) P[(size_t)cc * ld + r] = (T)out[r][cc];
-    const double x0 = (double)x[0], x1 = (double)x[1];
-    x[0] = (T)(x0 + vtc);
-    x[1] = (T)(x1 + vts);
-    x[2] = (T)mpi_to_pi_d(phi + v * dt * sin(g) / w);
-    params[0] = vts;
-    params[1] = vtc;
-}
-
-// P_vm <- Gv * P_vm and its mirror (ekf.jl:33-36).  Thread t owns map row f = 3+t.
-template <typename T>
-__global__ __launch_bounds__(256) void predict_strip_kernel(T* __restrict__ P, int ld, int n,
-                                                             const double* __restrict__ params) {
-    const int f = 3 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n) return;
-    const double vts = params[0], vtc = params[1];
-    const double p0 = (double)P[(size_t)0 * ld + f];
-    const double p1 = (double)P[(size_t)1 * ld + f];
-    const double p2 = (double)P[(size_t)2 * ld + f];
-    const T n0 = (T)(p0 - vts * p2);     // Gv = [1 0 -vts; 0 1 vtc; 0 0 1]
-    const T n1 = (T)(p1 + vtc * p2);
-    const T n2 = (T)p2;
-    P[(size_t)0 * ld + f] = n0;          // column strip  P[f, 0:3]
-    P[(size_t)1 * ld + f] = n1;
-    P[(size_t)2 * ld + f] = n2;
-    T* row = P + (size_t)f * ld;         // row strip     P[0:3, f]
-    row[0] = n0;
-    row[1] = n1;
-    row[2] = n2;
-}
 
 // add_features: thread t owns old state index c = t (0 .. n0-1) and writes, for
 // every new feature a, the 2 x 1 cross block P[fa:fa+1, c] = Gv_a * P[0:3, c] and its
@@ -231,26 +178,79 @@ int launch_mirror(slam_ekf* h) {
     return SLAM_OK;
 }
 
+namespace {
+
+// E1 as ONE launch (the reference's sim! calls predict nine times per observation step: launches are what it costs).
+// Every workgroup needs the PRE-update heading for the strip; the pose and P_vv are rewritten by whichever
+// workgroup arrives LAST at the counter, i.e. after every workgroup has read x[2].  Nothing is published between
+// workgroups (the strip and the pose block are disjoint), so the arrival is a relaxed atomic without fences.
+template <typename T>
+__global__ __launch_bounds__(256) void predict_kernel(T* __restrict__ x, T* __restrict__ P, int ld, int n, double v, double g,
+                                                       double w, double Q0, double Q1, double Q2, double Q3, double dt,
+                                                       int32_t* __restrict__ arrive) {
+    const double phi = (double)x[2];
+    const double sn = sin(g + phi), cs = cos(g + phi);
+    const double vts = v * dt * sn, vtc = v * dt * cs;
+    const int f = 3 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < n) {
+        const double p0 = (double)P[(size_t)0 * ld + f];
+        const double p1 = (double)P[(size_t)1 * ld + f];
+        const double p2 = (double)P[(size_t)2 * ld + f];
+        const T n0 = (T)(p0 - vts * p2);     // Gv = [1 0 -vts; 0 1 vtc; 0 0 1]
+        const T n1 = (T)(p1 + vtc * p2);
+        const T n2 = (T)p2;
+        P[(size_t)0 * ld + f] = n0;          // column strip  P[f, 0:3]
+        P[(size_t)1 * ld + f] = n1;
+        P[(size_t)2 * ld + f] = n2;
+        T* row = P + (size_t)f * ld;         // row strip     P[0:3, f]
+        row[0] = n0;
+        row[1] = n1;
+        row[2] = n2;
+    }
+    __shared__ int last;
+    __syncthreads();                         // every thread of the workgroup has its heading
+    if (threadIdx.x == 0)
+        last = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!last || threadIdx.x != 0) return;
+    __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // re-armed
+    const double Gv[3][3] = {{1.0, 0.0, -vts}, {0.0, 1.0, vtc}, {0.0, 0.0, 1.0}};
+    const double Gu[3][2] = {{dt * cs, -vts}, {dt * sn, vtc}, {dt * sin(g) / w, v * dt * cos(g) / w}};
+    const double Q[2][2] = {{Q0, Q2}, {Q1, Q3}};   // column-major input
+    double Pvv[3][3], GP[3][3], GQ[3][2], out[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 3; ++cc) Pvv[r][cc] = (double)P[(size_t)cc * ld + r];
+    for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 3; ++cc)
+            GP[r][cc] = Gv[r][0] * Pvv[0][cc] + Gv[r][1] * Pvv[1][cc] + Gv[r][2] * Pvv[2][cc];
+    for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 2; ++cc) GQ[r][cc] = Gu[r][0] * Q[0][cc] + Gu[r][1] * Q[1][cc];
+    for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 3; ++cc)
+            out[r][cc] = (GP[r][0] * Gv[cc][0] + GP[r][1] * Gv[cc][1] + GP[r][2] * Gv[cc][2]) +
+                         (GQ[r][0] * Gu[cc][0] + GQ[r][1] * Gu[cc][1]);
+    for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 3; ++cc) P[(size_t)cc * ld + r] = (T)out[r][cc];
+    const double x0 = (double)x[0], x1 = (double)x[1];
+    x[0] = (T)(x0 + vtc);
+    x[1] = (T)(x1 + vts);
+    x[2] = (T)mpi_to_pi_d(phi + v * dt * sin(g) / w);
+}
+
+}  // namespace
+
 int launch_predict(slam_ekf* h, double v, double g, double w, const double Q[4], double dt) {
     const int n = 3 + 2 * h->N;
-    double* params = h->d_small + 32;
     {
         KTimer t(h, SLAM_K_PREDICT);
+        const int blocks = h->N > 0 ? (2 * h->N + 255) / 256 : 1;
+        int32_t* arrive = h->d_count + 3;
         if (h->dtype == SLAM_F32)
-            hipLaunchKernelGGL(predict_pose_kernel<float>, dim3(1), dim3(64), 0, h->stream, (float*)h->x, (float*)h->P,
-                               h->ld, v, g, w, Q[0], Q[1], Q[2], Q[3], dt, params);
+            hipLaunchKernelGGL(predict_kernel<float>, dim3(blocks), dim3(256), 0, h->stream, (float*)h->x, (float*)h->P, h->ld, n,
+                               v, g, w, Q[0], Q[1], Q[2], Q[3], dt, arrive);
         else
-            hipLaunchKernelGGL(predict_pose_kernel<double>, dim3(1), dim3(64), 0, h->stream, (double*)h->x,
-                               (double*)h->P, h->ld, v, g, w, Q[0], Q[1], Q[2], Q[3], dt, params);
-        if (h->N > 0) {
-            const int blocks = (2 * h->N + 255) / 256;
-            if (h->dtype == SLAM_F32)
-                hipLaunchKernelGGL(predict_strip_kernel<float>, dim3(blocks), dim3(256), 0, h->stream, (float*)h->P,
-                                   h->ld, n, params);
-            else
-                hipLaunchKernelGGL(predict_strip_kernel<double>, dim3(blocks), dim3(256), 0, h->stream, (double*)h->P,
-                                   h->ld, n, params);
-        }
+            hipLaunchKernelGGL(predict_kernel<double>, dim3(blocks), dim3(256), 0, h->stream, (double*)h->x, (double*)h->P, h->ld,
+                               n, v, g, w, Q[0], Q[1], Q[2], Q[3], dt, arrive);
     }
     HIP_TRY(hipGetLastError());
     return SLAM_OK;
