@@ -490,3 +490,55 @@ def test_lazy_resampling_equals_the_eager_gather(pkg, monkeypatch, dtype):
     same("after the unknown-correspondence sweep")
     for f in shards.values():
         f.shard.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_lazy_resampling_random_operation_sequences(pkg, monkeypatch, seed):
+    """Random programs over the particle-filter entry points -- known-id steps with random (repeating, sometimes first
+    seen) landmark lists, FastSLAM-2.0 steps, separate predict / update_known calls, forced and skipped resamplings,
+    unknown-correspondence steps, packs, downloads, landmark re-initialisation -- run on a lazy and on an eager shard
+    (SLAMHIP_PF_EAGER=1): the states must stay bit-identical."""
+    import torch
+    rs = np.random.default_rng(1000 + seed)
+    n, nl = 700 + 13 * seed, 40
+    lm = scene(nl, 50 + seed)
+    f = {}
+    for name, flag in (("lazy", "0"), ("eager", "1")):
+        monkeypatch.setenv("SLAMHIP_PF_EAGER", flag)
+        sh = pkg.PFShard(n, nl, 77 + seed, dtype="f64" if seed % 2 else "f32")
+        sh.set_pose([0.0, 0.0, 0.2])
+        sh.init_landmarks(lm[:30], 0.01, 0.1)
+        f[name] = pkg.FastSLAM(sh, None)
+    monkeypatch.delenv("SLAMHIP_PF_EAGER", raising=False)
+    pose = np.array([0.0, 0.0, 0.2])
+    for t in range(120):
+        pose = np.array([pose[0] + 0.3 * math.cos(0.02 + pose[2]), pose[1] + 0.3 * math.sin(0.02 + pose[2]),
+                         pose[2] + 0.3 * math.sin(0.02) / 4.0])
+        op = rs.integers(0, 10)
+        m = int(rs.integers(1, 7))
+        ids = rs.integers(1, (36 if t > 40 else 30) + 1, m)            # after step 40 also landmarks never seen before
+        z = observe(lm, pose, ids, rs)
+        res = rs.random() < 0.6
+        pick = rs.integers(0, n, 50).astype(np.int32)
+        outs = []
+        for g in f.values():
+            if op <= 5:
+                outs.append(g.step(3.0, 0.02, 4.0, Q, 0.1, z, ids, R, force_resample=res, proposal=(op == 5)))
+            elif op == 6:                                                # the separate entry points
+                g.predict(3.0, 0.02, 4.0, Q, 0.1)
+                g.update_known(z, ids, R)
+                outs.append(g.normalize())
+                if res:
+                    g.resample()
+            elif op == 7:                                                # unknown correspondences (materialises the maps)
+                outs.append(g.step_unknown(3.0, 0.02, 4.0, Q, 0.1, z[:, :3], R, 4.0, 25.0, force_resample=res))
+            elif op == 8:
+                outs.append(g.shard.pack(torch.from_numpy(pick).cuda()).cpu().numpy().tobytes())
+            else:
+                outs.append(tuple(a.tobytes() for a in g.shard.download()))
+        assert outs[0] == outs[1], f"seed {seed} step {t} op {op}"
+    a, b = f["lazy"].shard.download(), f["eager"].shard.download()
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    for g in f.values():
+        g.shard.close()
