@@ -442,6 +442,12 @@ def main():
             "kernel_ms_per_step_note": f"{ndiag} extra steps after the timed region with every kernel bracketed by events",
             "factor_phases_us": dict(zip(["innovation", "build_S", "symmetrise", "eliminate", "y_g", "emit_C"], phases)),
         }
+        # the gating sweep (K1): 12 state values per landmark read once per sweep, nz * N pairs evaluated
+        g_ms = tim_all["gate"][0] / max(ndiag, 1)
+        if g_ms > 0:
+            out["gating_sweep"] = {"ms": g_ms, "algorithmic_bytes": 12 * esz * N, "achieved_GBps": 12 * esz * N / (g_ms * 1e-3) / 1e9,
+                                   "pairs_per_s": nz * N / (g_ms * 1e-3), "bound": "latency (one launch; HBM floor %.2f us)" %
+                                   (12 * esz * N / (HBM_PEAK_GBPS * 1e9) * 1e6)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(x, P, zs, args.cpu_budget)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
