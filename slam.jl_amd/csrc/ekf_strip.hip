@@ -14,10 +14,6 @@
 
 namespace {
 
-struct PredictParams {   // written by the pose kernel, read by the strip kernel
-    double vts, vtc;
-};
-
 // add_features: thread t owns old state index c = t (0 .. n0-1) and writes, for
 // every new feature a, the 2 x 1 cross block P[fa:fa+1, c] = Gv_a * P[0:3, c] and its
 // mirror.  P[0:3, c] is read as P[c, 0:3] (symmetric).  Block 0 additionally writes
