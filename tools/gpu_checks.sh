@@ -10,6 +10,6 @@ rc=$?
 echo "bench exit $rc" >> gpurun_out/bench.log
 if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r01zc -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r01zd -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1
 echo "rocprof exit $?" >> $GRAFT_REPO_ROOT/gpurun_out/rocprof.log
 for f in $GRAFT_REPO_ROOT/gpurun_out/smoke.log $GRAFT_REPO_ROOT/gpurun_out/pytest_gpu.log $GRAFT_REPO_ROOT/gpurun_out/bench.log; do echo "== $f"; tail -n 5 $f; done
