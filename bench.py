@@ -240,6 +240,41 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
                          "kernel + fold + one scalar read-back per step; the sweep itself runs at ~3.4 TB/s)"}}
 
 
+def spawn_ranks(n):
+    """One child process per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, the same command line; children
+    are plain subprocesses (never an exec of this process).  Returns the exit code for the parent."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    # a rank that dies must not leave the others waiting in a collective: end them (exact PIDs) as soon as one fails
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    out = procs[0].stdout.read() if procs[0].stdout else ""       # (one JSON line: far below the pipe's capacity)
+    codes = [p.wait() for p in procs]
+    if out:
+        sys.stdout.write(out)
+        sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -257,6 +292,12 @@ def main():
                     help="untimed device warm-up before the W warm-up steps: a GPU coming out of idle needs ~40 ms of load "
                          "to reach its sustained clocks (tools/step_trend.py: 0.63 -> 0.54 ms per step over the first 60 steps)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks here (one process per GPU, fresh children, nothing in
+        # this process has touched the GPU), relay rank 0's JSON line, fail if any rank fails.  Under
+        # torch.distributed.run the ranks already exist (WORLD_SIZE is set) and this is skipped.
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist

@@ -82,6 +82,12 @@ int slam_ekf_set_state(slam_ekf_t h, const void* x, const void* P, int n, int ld
 int slam_ekf_set_state_device(slam_ekf_t h, const void* d_x, const void* d_P, int n, int ldP);
 /* Download; either pointer may be NULL.  Reads of state.x / state.cov. */
 int slam_ekf_get_state(slam_ekf_t h, void* x, void* P, int n, int ldP);
+/* state.cov[r0+1 : r0+nr, c0+1 : c0+nc] (0-based r0, c0 here) into a column-major host buffer of the handle's
+ * dtype with leading dimension ld_out >= nr, and diag(state.cov) (n values): the way to look at parts of a
+ * covariance that is too large to download (80 GB at N = 50k fp64; the reference ships the whole matrix per step,
+ * sim/browser/wsserver.jl:36).  Elements come from the symmetric view, whichever triangle holds them. */
+int slam_ekf_get_block(slam_ekf_t h, int r0, int c0, int nr, int nc, void* out, int ld_out);
+int slam_ekf_get_diag(slam_ekf_t h, void* out);
 int slam_ekf_get_pose(slam_ekf_t h, double pose[3]);       /* state.x[1:3]          */
 int slam_ekf_num_landmarks(slam_ekf_t h, int* N);          /* (length(x)-3)/2       */
 int slam_ekf_dtype(slam_ekf_t h, int* dtype);
@@ -131,7 +137,7 @@ int slam_ekf_update(slam_ekf_t h, const double* zf, const int32_t* idf, int m,
  * Returns SLAM_E_CAPACITY (state unchanged) if N + nn > max_landmarks.  Enqueued. */
 int slam_ekf_augment(slam_ekf_t h, const double* zn, int nn, const double R[4]);
 
-/* One observation step of sim!  (src/sim.jl:114-120):  associate -> update -> add_features
+/* One observation step of sim!  (sim/ekfslam-sim.jl:114-120):  associate -> update -> add_features
  * in ONE call, same results as the three calls above in sequence.  The association
  * vector (meaning as in slam_ekf_associate) is compacted into the update's inputs on
  * the device and the update kernels read the matched count from device memory, so

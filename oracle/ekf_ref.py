@@ -278,7 +278,8 @@ def association_table_sparse(x, P, z, R):
     nz = z.shape[1]
     if Nf == 0:
         return np.zeros((nz, 0)), np.zeros((nz, 0))
-    zp, S = _landmark_S(x, np.asarray(P), np.asarray(R, dtype=np.float64), np.arange(1, Nf + 1))
+    zp, S = _landmark_S(x, P if isinstance(P, LowRankCov) else np.asarray(P), np.asarray(R, dtype=np.float64),
+                        np.arange(1, Nf + 1))
     det = S[:, 0, 0] * S[:, 1, 1] - S[:, 0, 1] * S[:, 1, 0]
     logdet = np.log(det)
     v0 = z[0][:, None] - zp[None, :, 0]
@@ -362,6 +363,50 @@ def update_sparse(x, P, z, R, idf, inplace=False):
         P -= W1 @ W1.T
         return xn, P
     return xn, P - W1 @ W1.T
+
+
+class LowRankCov:
+    """P = A A' + d I as an indexable VIEW that never forms the n x n matrix: test infrastructure for BASELINE.json's
+    N = 50k configuration (80 GB in fp64), where the GPU state is built from the same factor.  Supports exactly the
+    index patterns of the sparse oracle: (slice | index array) x (slice | index array); two index arrays pair up
+    element by element like NumPy's, anything with a slice is an outer block."""
+
+    def __init__(self, A, d):
+        self.A = np.asarray(A, dtype=np.float64)
+        self.d = float(d)
+        self.shape = (self.A.shape[0], self.A.shape[0])
+
+    def _idx(self, k):
+        n = self.shape[0]
+        if isinstance(k, slice):
+            return np.arange(*k.indices(n)), True
+        return np.asarray(k, dtype=np.int64).reshape(-1), False
+
+    def __getitem__(self, key):
+        r, rs = self._idx(key[0])
+        c, cs = self._idx(key[1])
+        if not rs and not cs:                                   # P[f, g]: element by element
+            return np.einsum("ij,ij->i", self.A[r], self.A[c]) + self.d * (r == c)
+        return self.A[r] @ self.A[c].T + self.d * (r[:, None] == c[None, :])
+
+    def diagonal(self):
+        return np.einsum("ij,ij->i", self.A, self.A) + self.d
+
+
+def update_joseph_factors(x, P, z, R, idf):
+    """The Joseph-form update of update_joseph_sparse WITHOUT forming P+:  returns (x+, K, T) with
+    P+ = P - K T' - T K'.  P may be a LowRankCov (only the pose columns and the observed landmarks' columns
+    of P are read)."""
+    z = np.asarray(z, dtype=np.float64).reshape(2, -1)
+    v, A, S = _update_front(x, P, z, R, idf)
+    K = np.linalg.solve(S, A.T).T
+    T = A - 0.5 * K @ S
+    return np.asarray(x, dtype=np.float64) + K @ v, K, T
+
+
+def joseph_block(P, K, T, rows, cols):
+    """P+[rows, cols] from the factors of update_joseph_factors."""
+    return P[rows, cols] - K[rows] @ T[cols].T - T[rows] @ K[cols].T
 
 
 def update_joseph_sparse(x, P, z, R, idf):

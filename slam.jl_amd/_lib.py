@@ -11,6 +11,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslamhip.so")
+# measurement tooling only (tools/gpu_exp.sh): the experiments build of the SAME sources, `make -C csrc exp`
+if os.environ.get("SLAMHIP_LIBRARY"):
+    LIB_PATH = os.path.abspath(os.environ["SLAMHIP_LIBRARY"])
 
 SLAM_OK = 0
 SLAM_E_BADARG = -1
@@ -72,6 +75,8 @@ SIGNATURES = {
     "slam_ekf_set_state": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "slam_ekf_set_state_device": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "slam_ekf_get_state": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "slam_ekf_get_block": (C.c_int, [_h, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "slam_ekf_get_diag": (C.c_int, [_h, C.c_void_p]),
     "slam_ekf_get_pose": (C.c_int, [_h, _dp]),
     "slam_ekf_num_landmarks": (C.c_int, [_h, C.POINTER(C.c_int)]),
     "slam_ekf_dtype": (C.c_int, [_h, C.POINTER(C.c_int)]),

@@ -135,6 +135,7 @@ struct KTimer {
 
 // ---- kernel launchers (one per .hip file) -----------------------------------
 int launch_ellipses(slam_ekf* h, double* d_out);     // [N + 1][5]: vehicle, then the landmarks
+int launch_block_gather(slam_ekf* h, int r0, int c0, int nr, int nc, int diag, void* d_out);   // dense nr x nc copy of P[r0.., c0..] (symmetric view)
 int launch_mirror(slam_ekf* h);     // make the tiles above the diagonal valid (before a download)
 int launch_predict(slam_ekf* h, double v, double g, double w, const double Q[4], double dt);
 int launch_augment(slam_ekf* h, int nn, const double R[4], const double* zn_dev);   // zn already on the device (obsbuf or znbuf)

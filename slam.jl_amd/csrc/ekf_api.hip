@@ -256,7 +256,11 @@ extern "C" int slam_ekf_create(slam_ekf_t* out, int dtype, int max_landmarks, in
     h->znbuf = nullptr; h->d_count = nullptr; h->h_flag = nullptr; h->h_flag_dev = nullptr; h->obs_seq = 0;
     h->d_status = h->h_status = nullptr;
     h->async_updates = 0; h->deferred = 0; h->pending_status = 0; h->debug_stamps = 0;
+    h->debug_flags = 0;
+#ifdef SLAMHIP_EXPERIMENTS
+    // timing experiments on the down-date that give WRONG RESULTS: only in the separate `make exp` library
     h->debug_flags = getenv("SLAMHIP_DEBUG") ? atoi(getenv("SLAMHIP_DEBUG")) : 0;
+#endif
     h->dd_prof = nullptr;
     h->xflags = getenv("SLAMHIP_X") ? atoi(getenv("SLAMHIP_X")) : 0;
     h->factor_blocked = !(getenv("SLAMHIP_FACTOR") && !strcmp(getenv("SLAMHIP_FACTOR"), "scalar"));
@@ -318,6 +322,44 @@ extern "C" int slam_ekf_get_state(slam_ekf_t h, void* x, void* P, int n, int ldP
                                  hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return SLAM_OK;
+}
+
+// A block / the diagonal of the covariance without downloading it (80 GB at N = 50k): gathered on the device through
+// the symmetric view, one dense copy to the host.
+static int get_gathered(slam_ekf* h, int r0, int c0, int nr, int nc, int diag, void* out, int ld_out) {
+    HIP_TRY(hipSetDevice(h->device));
+    void* d_tmp = nullptr;
+    HIP_TRY(hipMalloc(&d_tmp, h->esz * (size_t)nr * nc));
+    int rc = launch_block_gather(h, r0, c0, nr, nc, diag, d_tmp);
+    if (rc == SLAM_OK) {
+        hipError_t e = hipMemcpy2DAsync(out, h->esz * (size_t)ld_out, d_tmp, h->esz * (size_t)nr, h->esz * (size_t)nr, (size_t)nc,
+                                        hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) {
+            slam_set_error("HIP error while reading a covariance block: %s", hipGetErrorString(e));
+            rc = SLAM_E_HIP;
+        }
+    }
+    (void)hipFree(d_tmp);
+    return rc;
+}
+
+extern "C" int slam_ekf_get_block(slam_ekf_t h, int r0, int c0, int nr, int nc, void* out, int ld_out) {
+    ARG_CHECK(h != nullptr, "null handle");
+    const int n = 3 + 2 * h->N;
+    ARG_CHECK(nr >= 0 && nc >= 0, "negative block size");
+    if (nr == 0 || nc == 0) return SLAM_OK;
+    ARG_CHECK(out != nullptr, "out is null");
+    ARG_CHECK(r0 >= 0 && c0 >= 0 && r0 + nr <= n && c0 + nc <= n, "block outside the n x n covariance (Julia: BoundsError)");
+    ARG_CHECK(ld_out >= nr, "ld_out < nr");
+    ARG_CHECK((size_t)nr * nc <= ((size_t)1 << 28), "block larger than 2^28 elements: read it in pieces");
+    return get_gathered(h, r0, c0, nr, nc, 0, out, ld_out);
+}
+
+extern "C" int slam_ekf_get_diag(slam_ekf_t h, void* out) {
+    ARG_CHECK(h != nullptr && out != nullptr, "null argument");
+    const int n = 3 + 2 * h->N;
+    return get_gathered(h, 0, 0, n, 1, 1, out, n);
 }
 
 extern "C" int slam_ekf_get_pose(slam_ekf_t h, double pose[3]) {
@@ -569,20 +611,25 @@ extern "C" int slam_ekf_observe(slam_ekf_t h, const double* z, int nz, const dou
         assoc[i] = h->h_assoc[i];
         nn += assoc[i] < 0;
     }
+    int cap_rc = SLAM_OK;
     if (nn) {
-        if (h->N + nn > h->maxN) {
-            slam_set_error("observe: %d + %d landmarks exceed capacity %d (the update was applied, no feature added)", h->N, nn,
-                           h->maxN);
-            return SLAM_E_CAPACITY;
+        if (h->N + nn > h->maxN) cap_rc = SLAM_E_CAPACITY;          // reported below, behind the update's own status
+        else {
+            if ((rc = launch_augment(h, nn, R, h->znbuf))) return rc;
+            h->N += nn;
         }
-        if ((rc = launch_augment(h, nn, R, h->znbuf))) return rc;
-        h->N += nn;
     }
-    if (h->async_updates) {
-        h->pending_status = 1;
-        return SLAM_OK;
+    // The update is already queued: its status is collected (or left pending in async mode) whatever happened to
+    // the new features.  S not positive definite outranks the capacity overflow: the caller must learn that the
+    // update was NOT applied.
+    if (h->async_updates) h->pending_status = 1;
+    else if ((rc = read_status(h, 0))) return rc;
+    if (cap_rc) {
+        slam_set_error("observe: %d + %d landmarks exceed capacity %d (the update was applied, no feature added)", h->N, nn,
+                       h->maxN);
+        return cap_rc;
     }
-    return read_status(h, 0);
+    return SLAM_OK;
 }
 
 // ---- stream / timing -----------------------------------------------------------------

@@ -145,7 +145,31 @@ __global__ __launch_bounds__(256) void ellipse_kernel(const T* __restrict__ x, c
     o[4] = atan2(u1, u0);
 }
 
+// slam_ekf_get_block / slam_ekf_get_diag: element (r, c) of the SYMMETRIC matrix, wherever it is maintained (sym_at),
+// gathered into a dense column-major nr x nc buffer (nc = 1, diag = 1: the diagonal).  Consecutive threads walk rows.
+template <typename T>
+__global__ __launch_bounds__(256) void block_gather_kernel(const T* __restrict__ P, int ld, int tile_log2, int r0, int c0, int nr,
+                                                            int nc, int diag, T* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= nr || j >= nc) return;
+    const int r = r0 + i, c = diag ? r : c0 + j;
+    out[(size_t)j * nr + i] = sym_at(P, ld, tile_log2, r, c);
+}
+
 }  // namespace
+
+int launch_block_gather(slam_ekf* h, int r0, int c0, int nr, int nc, int diag, void* d_out) {
+    const dim3 grid((nr + 255) / 256, nc);
+    if (h->dtype == SLAM_F32)
+        hipLaunchKernelGGL(block_gather_kernel<float>, grid, dim3(256), 0, h->stream, (const float*)h->P, h->ld, 7, r0, c0, nr, nc,
+                           diag, (float*)d_out);
+    else
+        hipLaunchKernelGGL(block_gather_kernel<double>, grid, dim3(256), 0, h->stream, (const double*)h->P, h->ld, 6, r0, c0, nr,
+                           nc, diag, (double*)d_out);
+    HIP_TRY(hipGetLastError());
+    return SLAM_OK;
+}
 
 int launch_ellipses(slam_ekf* h, double* d_out) {
     const int cnt = h->N + 1;

@@ -922,6 +922,7 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
         int per_xcd = 2 * h->num_cus / 8;
         if (per_xcd > h->tiles_len) per_xcd = h->tiles_len;
         if (per_xcd < 1) per_xcd = 1;
+#ifdef SLAMHIP_EXPERIMENTS
         if (h->debug_flags & 32)  // timing experiments on the split-bf16 path (1 no stores, 2 no MFMAs, 4 no P loads, 16 no split)
             hipLaunchKernelGGL((downdate_f32_mfma<true, 4, 3, true>), dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,
                                (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
@@ -930,7 +931,9 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
             hipLaunchKernelGGL(downdate_f32_mfma<true>, dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,
                                (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
                                h->d_status, h->debug_flags, (unsigned long long*)h->dd_prof, dcount, joseph, IMGARGS);
-        else if (!(h->xflags & 4) && kp_total > 32 && kp_total <= 128) {     // (observe(): kp_total is an upper bound; the kernel falls back to dd_tile if the real chunk count differs)
+        else
+#endif
+        if (!(h->xflags & 4) && kp_total > 32 && kp_total <= 128) {     // (observe(): kp_total is an upper bound; the kernel falls back to dd_tile if the real chunk count differs)
             // streaming (tile-boundary-free) path for the off-diagonal tiles, one instantiation per chunk count
             const int nch = (kp_total + KC - 1) / KC;
 // (P tile requested three chunks before the epilogue at four chunks per tile, two otherwise: one-box A/B, tools/gpu_abx.sh:

@@ -193,6 +193,18 @@ class EKFSlamState(SlamState):
             return P
         return x, P
 
+    def get_block(self, r0, c0, nr, nc):
+        """cov[r0:r0+nr, c0:c0+nc] (0-based) without downloading the matrix (slam_ekf_get_block)."""
+        out = np.empty((int(nr), int(nc)), dtype=self.np_dtype, order="F")
+        check(lib.slam_ekf_get_block(self._h, int(r0), int(c0), int(nr), int(nc), out.ctypes.data, max(int(nr), 1)))
+        return out
+
+    def diag(self):
+        """diag(cov) (slam_ekf_get_diag)."""
+        out = np.empty(self.n, dtype=self.np_dtype)
+        check(lib.slam_ekf_get_diag(self._h, out.ctypes.data))
+        return out
+
     def device_ptrs(self):
         """(x_ptr, P_ptr, ld, stream_ptr) raw device addresses for zero-copy interop."""
         dx, dP, st = C.c_void_p(), C.c_void_p(), C.c_void_p()
@@ -299,7 +311,7 @@ class EKFSlamState(SlamState):
         check(lib.slam_ekf_augment(self._h, _ptr(zp), zp.shape[0], _ptr(r)))
 
     def observe(self, z, R, gate1, gate2, form="cholesky"):
-        """associate -> update -> add_features (src/sim.jl:114-120) in one library call with no host
+        """associate -> update -> add_features (sim/ekfslam-sim.jl:114-120) in one library call with no host
         round trip between the gating and the update.  Returns the association vector
         (see associate_vector); the state afterwards equals the three calls in sequence."""
         zp = _obs(z)

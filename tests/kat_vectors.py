@@ -1,0 +1,102 @@
+"""Hand-derived known answers KAT-8 .. KAT-10 (closed forms worked on paper from the reference's formulas,
+never by running the oracle).  Shared by the CPU tests of the oracle (tests/test_oracle_kat.py) and the GPU tests
+through the C ABI (tests/test_gpu_ekf.py).
+
+KAT-8  ``update`` (src/ekf.jl:46-77), one observation.
+    x = [0, 0, 0, 10, 0] (pose at the origin, heading 0, landmark 1 at (10, 0)), P = diag(p1..p5), R = diag(r1, r2),
+    z = (10.5, 0.02).  From KAT-1, H = [[-1, 0, 0, 1, 0], [0, -0.1, -1, 0, 0.1]]: row 1 touches the state indices
+    {0, 3}, row 2 touches {1, 2, 4}, and P is diagonal, so the two measurement rows decouple:
+        S = diag(s1, s2),   s1 = p1 + p4 + r1,   s2 = 0.01 p2 + p3 + 0.01 p5 + r2
+        c1 = P h1' = [-p1, 0, 0, p4, 0]',        c2 = P h2' = [0, -0.1 p2, -p3, 0, 0.1 p5]'
+        v = (0.5, 0.02)
+        K = [c1 / s1, c2 / s2],   x+ = x + c1 v1 / s1 + c2 v2 / s2
+        P+ = P - c1 c1' / s1 - c2 c2' / s2           (= P - W1 W1' with W1 = P H' inv(chol(S)), ekf.jl:67-75)
+
+KAT-9  ``update`` with TWO stacked observations of the same landmark (rows are simply stacked).
+    Same x, P, R; z_a = (10.5, 0.02), z_b = (9.8, -0.01).  The stacked Jacobian is [H; H]; the range rows (1, 3)
+    and the bearing rows (2, 4) still decouple.  For one pair of identical rows h with prior variance a = h P h' and
+    noise r:   S = a 11' + r I,   S^-1 = (I - a/(r + 2a) 11') / r,   so
+        [h; h]' S^-1 [h; h] = h'h * 2 / (r + 2a)      and      P [h; h]' S^-1 = c 1' / (r + 2a),   c = P h'
+    giving   P+ = P - 2 c1 c1' / (r1 + 2 a1) - 2 c2 c2' / (r2 + 2 a2)
+             x+ = x + c1 (v1a + v1b) / (r1 + 2 a1) + c2 (v2a + v2b) / (r2 + 2 a2)
+    with a1 = p1 + p4, a2 = 0.01 p2 + p3 + 0.01 p5 (two measurements of noise r are one of noise r/2 at the mean).
+
+KAT-10 ``add_features`` (src/ekf.jl:84-122) with a NON-ZERO vehicle covariance and an EXISTING landmark (the cross
+    block with the rest of the map, ``rnm``, :115-118).  x = [1, 2, 0.5, 4, 6]; new observation (r, b) = (2, pi/2 - 0.5),
+    so phi + b = pi/2, s = 1, c = 0:
+        new landmark at (xv + r c, yv + r s) = (1, 4)
+        Gv = [[1, 0, -r s], [0, 1, r c]] = [[1, 0, -2], [0, 1, 0]]      Gz = [[c, -r s], [s, r c]] = [[0, -2], [1, 0]]
+    With Pvv = [[a, d, e], [d, b, f], [e, f, g]], Pvm = [[h1, h2], [i1, i2], [j1, j2]] and R = diag(r1, r2):
+        P_fv = Gv Pvv       = [[a - 2e, d - 2f, e - 2g], [d, b, f]]
+        P_ff = Gv Pvv Gv' + Gz R Gz' = [[a - 4e + 4g + 4 r2, d - 2f], [d - 2f, b + r1]]
+        P_fm = Gv Pvm       = [[h1 - 2 j1, h2 - 2 j2], [i1, i2]]
+    and the old 5 x 5 block is unchanged.
+"""
+import math
+
+import numpy as np
+
+R = np.array([[0.1 ** 2, 0.0], [0.0, (math.pi / 180) ** 2]])
+
+# ---- KAT-8 / KAT-9 ------------------------------------------------------------------------------------------
+X8 = np.array([0.0, 0.0, 0.0, 10.0, 0.0])
+P8 = np.array([0.5, 0.4, 0.02, 1.0, 2.0])           # diag(P)
+Z8A = np.array([10.5, 0.02])
+Z8B = np.array([9.8, -0.01])
+
+
+def _c12():
+    p1, p2, p3, p4, p5 = P8
+    c1 = np.array([-p1, 0.0, 0.0, p4, 0.0])
+    c2 = np.array([0.0, -0.1 * p2, -p3, 0.0, 0.1 * p5])
+    a1 = p1 + p4
+    a2 = 0.01 * p2 + p3 + 0.01 * p5
+    return c1, c2, a1, a2
+
+
+def kat8():
+    """(x, P, z (2 x 1), idf, x_plus, P_plus)"""
+    c1, c2, a1, a2 = _c12()
+    s1, s2 = a1 + R[0, 0], a2 + R[1, 1]
+    v1, v2 = Z8A[0] - 10.0, Z8A[1] - 0.0
+    xp = X8 + c1 * v1 / s1 + c2 * v2 / s2
+    Pp = np.diag(P8) - np.outer(c1, c1) / s1 - np.outer(c2, c2) / s2
+    return X8.copy(), np.diag(P8), Z8A.reshape(2, 1), np.array([[1]]), xp, Pp
+
+
+def kat9():
+    """(x, P, z (2 x 2), idf, x_plus, P_plus): both observations belong to landmark 1"""
+    c1, c2, a1, a2 = _c12()
+    g1, g2 = R[0, 0] + 2.0 * a1, R[1, 1] + 2.0 * a2
+    v1 = (Z8A[0] - 10.0) + (Z8B[0] - 10.0)
+    v2 = Z8A[1] + Z8B[1]
+    xp = X8 + c1 * v1 / g1 + c2 * v2 / g2
+    Pp = np.diag(P8) - 2.0 * np.outer(c1, c1) / g1 - 2.0 * np.outer(c2, c2) / g2
+    return X8.copy(), np.diag(P8), np.stack([Z8A, Z8B], axis=1), np.array([[1, 1]]), xp, Pp
+
+
+# ---- KAT-10 -------------------------------------------------------------------------------------------------
+def kat10():
+    """(x, P, zn (2 x 1), x_plus, P_plus)"""
+    a, b, g, d, e, f = 0.30, 0.20, 0.01, 0.05, 0.02, -0.01
+    h1, h2, i1, i2, j1, j2 = 0.03, -0.02, 0.01, 0.04, 0.005, -0.003
+    x = np.array([1.0, 2.0, 0.5, 4.0, 6.0])
+    P = np.array([[a, d, e, h1, h2],
+                  [d, b, f, i1, i2],
+                  [e, f, g, j1, j2],
+                  [h1, i1, j1, 0.5, 0.1],
+                  [h2, i2, j2, 0.1, 0.4]])
+    zn = np.array([[2.0], [math.pi / 2 - 0.5]])
+    r1, r2 = R[0, 0], R[1, 1]
+    xp = np.concatenate([x, [1.0, 4.0]])
+    Pfv = np.array([[a - 2 * e, d - 2 * f, e - 2 * g], [d, b, f]])
+    Pff = np.array([[a - 4 * e + 4 * g + 4 * r2, d - 2 * f], [d - 2 * f, b + r1]])
+    Pfm = np.array([[h1 - 2 * j1, h2 - 2 * j2], [i1, i2]])
+    Pp = np.zeros((7, 7))
+    Pp[:5, :5] = P
+    Pp[5:, 0:3] = Pfv
+    Pp[0:3, 5:] = Pfv.T
+    Pp[5:, 3:5] = Pfm
+    Pp[3:5, 5:] = Pfm.T
+    Pp[5:, 5:] = Pff
+    return x, P, zn, xp, Pp

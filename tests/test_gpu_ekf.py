@@ -21,6 +21,7 @@ import numpy as np
 import pytest
 
 from oracle import ekf_ref as O
+from tests import kat_vectors as KV
 
 pytestmark = pytest.mark.gpu
 
@@ -251,16 +252,19 @@ def test_observe_equals_the_three_calls(pkg, dtype, form, N, m, nn, ndrop):
     assert np.array_equal(a, ao)
     zf, idf, zn = b_st.associate(z, R, 4.0, 25.0)
     b_st.update(zf, R, idf, form=form)
-    b_st.add_features(zn, R)
-    xa, Pa = a_st.download()
-    xb, Pb = b_st.download()
-    assert a_st.N == b_st.N == N + int(np.sum(ao < 0))
-    assert np.array_equal(xa, xb) and np.array_equal(Pa, Pb), "fused and unfused paths must agree bit for bit"
     zfo, idfo, zno = O.split_assoc(z, ao)
     if form == "cholesky":
         xo2, Po2 = O.update_sparse(xo, Po, zfo, R, idfo)
     else:
         xo2, Po2 = O.update_joseph_sparse(xo, Po, zfo, R, idfo)
+    # the update half at the plain per-call tolerance, BEFORE the new features and their lever arm come in: the fused
+    # call is bit-identical to this path (asserted below), so this pins its update half too
+    check_state(b_st, xo2, Po2, dtype, "update half of observe", fP=2.0 if form == "joseph" else 1.0, prior=Po)
+    b_st.add_features(zn, R)
+    xa, Pa = a_st.download()
+    xb, Pb = b_st.download()
+    assert a_st.N == b_st.N == N + int(np.sum(ao < 0))
+    assert np.array_equal(xa, xb) and np.array_equal(Pa, Pb), "fused and unfused paths must agree bit for bit"
     xo2, Po2 = O.add_features_sparse(xo2, Po2, zno, R)
     check_state(a_st, xo2, Po2, dtype, "observe", fx=4.0, fP=100.0, prior=Po)
     a_st.close()
@@ -277,6 +281,81 @@ def test_observe_edge_cases(pkg):
     with pytest.raises(pkg.SlamHipError):                                     # capacity: 2 + 3 > 4
         st.observe(np.array([[50.0, 60.0, 70.0], [1.0, 2.0, 3.0]]), R, 4.0, 25.0)
     assert st.N == 2
+    st.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("use_async", [False, True])
+def test_observe_capacity_overflow_together_with_a_failed_update(pkg, dtype, use_async):
+    """slam_ekf_observe when BOTH things go wrong in one call: the matched observations give an S that is not positive
+    definite (Julia: chol throws, src/ekf.jl:70) and the new features do not fit the capacity.  The update's status
+    must be collected (not left sticky) and outrank the capacity overflow, and the state must be untouched.
+    R = -eps I with a landmark observed twice: every 2 x 2 S_j = A_j - eps I is still positive definite (the gating
+    works as usual), but the stacked S = [[A - eps I, A], [A, A - eps I]] has the eigenvalues of -eps I."""
+    rng = np.random.default_rng(4)
+    x, P = random_state(rng, 6)
+    st = pkg.EKFSlamState(x, P, dtype=dtype, max_landmarks=7)
+    x0, P0 = st.download()
+    xo = x0.astype(np.float64)
+    Rbad = -1e-5 * np.eye(2)
+    zp, _ = O.predict_observation(xo, 3)
+    z = np.stack([zp + [0.01, 0.0005], zp - [0.01, 0.0005], [700.0, 0.1], [800.0, -0.2]], axis=1)    # 2 matched + 2 new: 6 + 2 > 7
+    nis, nd = O.association_table_sparse(xo, np.array(P0, dtype=np.float64), z, Rbad)
+    assert O.assoc_vector(nis, nd, 4.0, 25.0).tolist() == [3, 3, -1, -1]
+    st.set_async(use_async)
+    if use_async:
+        with pytest.raises(pkg.SlamHipError) as ei:
+            st.observe(z, Rbad, 4.0, 25.0)
+        assert ei.value.code == pkg._lib.SLAM_E_CAPACITY                     # what the call itself knows in async mode ...
+        with pytest.raises(pkg.NotPositiveDefinite):
+            st.sync()                                                        # ... and the deferred status of its update
+        st.sync()
+    else:
+        with pytest.raises(pkg.NotPositiveDefinite):
+            st.observe(z, Rbad, 4.0, 25.0)
+    st.set_async(False)
+    x1, P1 = st.download()
+    assert st.N == 6 and np.array_equal(x0, x1) and np.array_equal(P0, P1)
+    # the status word is clean again: a good call right after succeeds and reports nothing stale
+    a = st.observe(z[:, :1], R, 4.0, 25.0)
+    assert a.tolist() == [3]
+    st.sync()
+    st.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_kat8_to_kat10_through_the_abi(pkg, dtype):
+    """The hand-derived closed forms of tests/kat_vectors.py (update with one and with two stacked observations of the
+    same landmark, add_features with vehicle covariance and an existing landmark) through the C ABI."""
+    tx, tP = (1e-12, 1e-12) if dtype == "f64" else (2e-6, 2e-6)
+    for kat in (KV.kat8, KV.kat9):
+        x, P, z, idf, xp, Pp = kat()
+        for form in ("cholesky", "joseph"):
+            st = pkg.EKFSlamState(x, P, dtype=dtype, max_landmarks=2)
+            st.update(z, KV.R, idf, form=form)
+            xg, Pg = st.download()
+            assert np.allclose(xg, xp, rtol=tx, atol=tx * 10), (kat.__name__, form)
+            assert np.allclose(Pg, Pp, rtol=tP, atol=tP * 2.0), (kat.__name__, form)     # 2.0 = max |P|
+            assert np.array_equal(Pg, Pg.T)
+            st.close()
+        st = pkg.EKFSlamState(x, P, dtype=dtype, max_landmarks=2)                        # the same through observe()
+        a = st.observe(z, KV.R, 4.0, 25.0)
+        assert a.tolist() == [1] * z.shape[1]
+        xg, Pg = st.download()
+        assert np.allclose(xg, xp, rtol=tx, atol=tx * 10) and np.allclose(Pg, Pp, rtol=tP, atol=tP * 2.0)
+        st.close()
+    x, P, zn, xp, Pp = KV.kat10()
+    st = pkg.EKFSlamState(x, P, dtype=dtype, max_landmarks=2)
+    st.add_features(zn, KV.R)
+    xg, Pg = st.download()
+    assert st.N == 2 and np.allclose(xg, xp, rtol=0, atol=tx * 10) and np.allclose(Pg, Pp, rtol=tP, atol=tP * 0.5)
+    assert np.array_equal(Pg, Pg.T)
+    # slam_ekf_get_block / slam_ekf_get_diag read the same matrix piecewise, from either triangle
+    assert np.array_equal(st.get_block(0, 0, 7, 7), Pg) and np.array_equal(st.diag(), np.diag(Pg))
+    assert np.array_equal(st.get_block(5, 1, 2, 4), Pg[5:7, 1:5]) and np.array_equal(st.get_block(1, 5, 4, 2), Pg[1:5, 5:7])
+    with pytest.raises(pkg.SlamHipError) as ei:
+        st.get_block(5, 5, 3, 1)
+    assert ei.value.code == pkg._lib.SLAM_E_BADARG
     st.close()
 
 
@@ -631,4 +710,96 @@ def test_telemetry_ellipses_and_monitor_schema(pkg, dtype):
         pkg.telemetry.to_json(m)
     quiet = pkg.telemetry.monitor_messages(st, [1.0, 2.0, 0.1], st.pose(), timestamp=0.0)
     assert [m["type"] for m in quiet] == ["tracks", "state", "vehicle-ellipse"]      # no update: no lidar, no ellipses
+    st.close()
+
+
+def test_full_size_50k_landmarks_fp64_joseph(pkg):
+    """BASELINE.json config 5 at FULL size: N = 50 000 landmarks (n = 100 003, the covariance is 80 GB of fp64),
+    8 observations, Joseph form.  P = A A' + 0.01 I (A: n x 16) is formed on the device; the oracle works from the
+    factor (O.LowRankCov: only the 19 columns of P the update needs are ever formed on the host) and gives
+    P+ = P - K T' - T K' block by block.  Checked through slam_ekf_get_block / slam_ekf_get_diag:
+      * association decisions identical;
+      * x and sampled blocks of P+ to 1e-9 on the scale of relerr_cov: off-diagonal tiles near and far from the
+        observed landmarks, diagonal tiles (first, the observed landmarks', last = ragged), the pose strip, both
+        triangles (the device maintains only the lower block triangle: the mirror must give the same numbers);
+      * the whole diagonal against the oracle; trace decreases; diagonal tiles bit-exactly symmetric."""
+    import torch
+    N, m = 50000, 8
+    n = 3 + 2 * N
+    free_b, _total = torch.cuda.mem_get_info(0)
+    if free_b < 175e9:
+        pytest.skip("needs ~165 GB of device memory (80 GB state + 80 GB staging)")
+    rng = np.random.default_rng(20240601)
+    L = 100.0 * math.sqrt(N / 35.0)
+    lm = rng.uniform(0, L, (2, N))
+    pose = np.array([L / 2, L / 2, 0.3])
+    x = np.concatenate([pose, (lm + rng.normal(0, 0.1, lm.shape)).T.reshape(-1)])
+    A = rng.normal(0, 0.05, (n, 16))
+    dev = torch.device("cuda", 0)
+    Ad = torch.from_numpy(A).to(dev)
+    Pd = torch.empty((n, n), dtype=torch.float64, device=dev)
+    torch.mm(Ad, Ad.t(), out=Pd)
+    Pd.diagonal().add_(0.01)
+    st = pkg.EKFSlamState(x[:3], np.zeros((3, 3)), dtype="f64", max_landmarks=N)
+    xd = torch.from_numpy(x).to(dev)
+    torch.cuda.synchronize(dev)
+    st.set_state_device(xd.data_ptr(), Pd.data_ptr(), n, n)     # a symmetric matrix: row-major == column-major
+    st.sync()
+    # what the device actually holds (rocBLAS sums in its own order): sampled prior entries against the factor
+    Pv = O.LowRankCov(A, 0.01)
+    assert np.allclose(st.get_block(0, 0, 40, 40), Pv[0:40, 0:40], rtol=1e-13, atol=1e-17)
+    assert np.allclose(st.get_block(n - 70, 11, 70, 30), Pv[n - 70:n, 11:41], rtol=1e-13, atol=1e-17)
+    del Pd, Ad, xd
+    torch.cuda.empty_cache()
+    dx, dy = lm[0] - pose[0], lm[1] - pose[1]
+    fwd = np.flatnonzero(dx * math.cos(pose[2]) + dy * math.sin(pose[2]) > 0)
+    ids = fwd[np.argsort(dx[fwd] ** 2 + dy[fwd] ** 2)[:m]] + 1
+    z = np.vstack([np.hypot(dx[ids - 1], dy[ids - 1]), np.arctan2(dy[ids - 1], dx[ids - 1]) - pose[2]])
+    z = z + rng.normal(0, 1, z.shape) * np.array([[0.1], [math.pi / 180]]) * 0.5
+    prior_diag = Pv.diagonal()
+    assert np.allclose(st.diag(), prior_diag, rtol=1e-13)
+    nis, nd = O.association_table_sparse(x, Pv, z, R)
+    ao = O.assoc_vector(nis, nd, 4.0, 25.0)
+    assert int(np.sum(ao > 0)) >= 6, ao
+    a = st.observe(z, R, 4.0, 25.0, form="joseph")
+    assert np.array_equal(a, ao)
+    zf, idf, _zn = O.split_assoc(z, ao)
+    xn, K, T = O.update_joseph_factors(x, Pv, zf, R, idf)
+    xg = st.download("x")
+    assert relerr(xg, xn) <= 1e-9
+    post_diag = prior_diag - 2.0 * np.einsum("ij,ij->i", K, T)
+    dg = st.diag()
+    s = np.maximum(prior_diag, post_diag)                      # relerr_cov's scale: max(prior, posterior) variance
+    assert np.max(np.abs(dg - post_diag) / s) <= 1e-9
+    assert float(dg.sum()) < float(prior_diag.sum())           # information only removes variance
+    sd = np.sqrt(s)
+
+    def check_block(r0, c0, nr, nc, what):
+        r0, c0 = max(0, min(r0, n - nr)), max(0, min(c0, n - nc))
+        got = st.get_block(r0, c0, nr, nc)
+        want = O.joseph_block(Pv, K, T, slice(r0, r0 + nr), slice(c0, c0 + nc))
+        err = float(np.max(np.abs(got - want) / (sd[r0:r0 + nr, None] * sd[None, c0:c0 + nc])))
+        assert err <= 1e-9, f"{what}: block ({r0}, {c0}) {nr} x {nc}: {err:.3e}"
+        mirror = st.get_block(c0, r0, nc, nr)                  # the same entries read through the other triangle
+        assert np.array_equal(mirror, got.T), what
+        return got
+
+    f_obs = 3 + 2 * (idf.reshape(-1) - 1)
+    check_block(0, 0, 64, 64, "first diagonal tile (pose block)")
+    check_block(0, 0, 3, 256, "pose strip, start")
+    check_block(0, n - 256, 3, 256, "pose strip, end")
+    for f in f_obs[:3]:
+        t0 = (int(f) // 64) * 64
+        g = check_block(t0, t0, 64, 64, "diagonal tile of an observed landmark")
+        assert np.array_equal(g, g.T)
+        check_block(t0 + 64 * 300, t0, 64, 64, "off-diagonal tile in an observed landmark's column band")
+        check_block(t0, 0, 64, 64, "tile (observed landmark rows, pose columns)")
+    last = ((n - 1) // 64) * 64
+    g = check_block(last, last, n - last, n - last, "ragged last diagonal tile")
+    assert np.array_equal(g, g.T)
+    check_block(last, 0, n - last, 64, "ragged last tile row, first column band")
+    check_block(last - 64, last - 128, 128, 128, "blocks straddling the last tile boundaries")
+    for _ in range(12):                                        # tiles far from everything observed
+        r0, c0 = int(rng.integers(0, n - 96)), int(rng.integers(0, n - 96))
+        check_block(r0, c0, 96, 96, "random block")
     st.close()

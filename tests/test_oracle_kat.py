@@ -1,4 +1,4 @@
-"""Known-answer tests that pin the CPU oracle.
+"""Known-answer tests that pin the CPU oracle (KAT-8..KAT-10: tests/kat_vectors.py).
 
 The reference ships no tests or golden vectors and cannot be executed here, so
 these hand-derived values (from the formulas at the cited reference lines) are
@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from oracle import ekf_ref as O
+from tests import kat_vectors as KV
 
 R = np.array([[0.1 ** 2, 0.0], [0.0, (math.pi / 180) ** 2]])
 Q = np.array([[0.5 ** 2, 0.0], [0.0, (3 * math.pi / 180) ** 2]])
@@ -212,3 +213,61 @@ def test_predict_wraps_heading_once():
     P = np.zeros((3, 3))
     O.predict(x, P, 8.0, 0.5, 4.0, Q, 0.025)
     assert -math.pi <= x[2] < -math.pi + 0.03
+
+
+# ---- KAT-8 .. KAT-10: closed forms worked on paper in tests/kat_vectors.py ---------------------------------
+@pytest.mark.parametrize("kat", [KV.kat8, KV.kat9])
+def test_kat8_kat9_update_closed_forms(kat):
+    # src/ekf.jl:46-77: one observation (KAT-8); two stacked observations of the same landmark (KAT-9)
+    x, P, z, idf, xp, Pp = kat()
+    for fn in (O.update, O.update_sparse, O.update_joseph_sparse):
+        xn, Pn = fn(x.copy(), P.copy(), z, KV.R, idf if fn is O.update else idf.reshape(-1))
+        assert np.allclose(xn, xp, rtol=1e-13, atol=1e-15), fn.__name__
+        assert np.allclose(Pn, Pp, rtol=1e-12, atol=1e-15), fn.__name__
+    # the two measurement rows decouple: entries between the state groups {0, 3} and {1, 2, 4} stay exactly zero
+    _, Pn = O.update(x.copy(), P.copy(), z, KV.R, idf)
+    assert np.all(Pp[np.ix_([0, 3], [1, 2, 4])] == 0) and np.allclose(Pn[np.ix_([0, 3], [1, 2, 4])], 0, atol=1e-16)
+    # spot values of KAT-8 (p = (0.5, 0.4, 0.02, 1, 2)): s1 = 1.51, P+[0,0] = 0.5 - 0.25/1.51, P+[0,3] = +0.5/1.51
+    if kat is KV.kat8:
+        assert Pp[0, 0] == pytest.approx(0.5 - 0.25 / 1.51, rel=1e-14) and Pp[0, 3] == pytest.approx(0.5 / 1.51, rel=1e-14)
+        assert xp[3] == pytest.approx(10.0 + 0.5 / 1.51, rel=1e-15)
+
+
+def test_kat10_add_features_with_vehicle_covariance_and_existing_landmark():
+    # src/ekf.jl:84-122 incl. the cross block with the existing map (rnm, :115-118)
+    x, P, zn, xp, Pp = KV.kat10()
+    for fn in (O.add_features, O.add_features_sparse):
+        xn, Pn = fn(x.copy(), P.copy(), zn, KV.R)
+        assert np.allclose(xn, xp, rtol=0, atol=1e-14), fn.__name__
+        assert np.allclose(Pn, Pp, rtol=1e-13, atol=1e-16), fn.__name__
+    assert Pp[5, 3] == pytest.approx(0.03 - 2 * 0.005) and Pp[5, 5] == pytest.approx(0.30 - 0.08 + 0.04 + 4 * KV.R[1, 1])
+
+
+def test_low_rank_covariance_view_equals_the_dense_matrix():
+    """LowRankCov (test infrastructure for the N = 50k configuration: P = A A' + d I is never materialised) must index
+    exactly like the dense matrix in every pattern the sparse oracle uses, and update_joseph_factors must reproduce
+    update_joseph_sparse block by block."""
+    rng = np.random.default_rng(3)
+    N = 40
+    n = 3 + 2 * N
+    A = rng.normal(0, 0.2, (n, 5))
+    Pd = A @ A.T + 0.01 * np.eye(n)
+    Pv = O.LowRankCov(A, 0.01)
+    f = np.array([3, 9, 21])
+    for got, want in ((Pv[0:3, 0:3], Pd[0:3, 0:3]), (Pv[0:3, f], Pd[0:3, f]), (Pv[f, 0:3], Pd[f, 0:3]), (Pv[f, f + 1], Pd[f, f + 1]),
+                      (Pv[:, 0:3], Pd[:, 0:3]), (Pv[:, 7:9], Pd[:, 7:9]), (Pv[5:9, 60:70], Pd[5:9, 60:70])):
+        assert got.shape == want.shape and np.allclose(got, want, rtol=1e-14, atol=1e-17)
+    x = np.concatenate([[50.0, 50.0, 0.3], rng.uniform(10, 90, 2 * N)])
+    ids = np.array([4, 17, 30])
+    z = np.zeros((2, 3))
+    for i, j in enumerate(ids):
+        zp, _ = O.predict_observation(x, j)
+        z[:, i] = zp + rng.normal(0, [0.1, math.pi / 180])
+    nis_d, nd_d = O.association_table_sparse(x, Pd, z, R)
+    nis_v, nd_v = O.association_table_sparse(x, Pv, z, R)
+    assert np.allclose(nis_d, nis_v, rtol=1e-11) and np.allclose(nd_d, nd_v, rtol=1e-11, atol=1e-12)
+    xj, Pj = O.update_joseph_sparse(x, Pd, z, R, ids)
+    xf, K, T = O.update_joseph_factors(x, Pv, z, R, ids)
+    assert np.allclose(xj, xf, rtol=1e-13)
+    rows, cols = slice(10, 30), slice(0, 83)
+    assert np.allclose(O.joseph_block(Pv, K, T, rows, cols), Pj[rows, cols], rtol=1e-11, atol=1e-15)
