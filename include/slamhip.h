@@ -27,6 +27,7 @@
 #ifndef SLAMHIP_H
 #define SLAMHIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -40,6 +41,9 @@ extern "C" {
                                   (Julia: chol throws PosDefException, ekf.jl:70)    */
 #define SLAM_E_HIP        -4   /* HIP runtime error / no usable device               */
 #define SLAM_E_NOMEM      -5   /* device or host allocation failed                   */
+
+#define SLAM_PF_HALTED      1   /* slam_pf_step_auto / slam_pf_flush on a SHARDED filter: a queued step decided to
+                                  resample; the caller exchanges weights and records, then slam_pf_resume           */
 
 #define SLAM_F32 0
 #define SLAM_F64 1
@@ -269,6 +273,45 @@ int slam_pf_mean_pose_sums(slam_pf_t h, double out[4]);
 int slam_pf_download(slam_pf_t h, void* pose, void* logw, void* lm);
 int slam_pf_sync(slam_pf_t h);
 int slam_pf_stream(slam_pf_t h, void** stream);
+
+/* ---- the filter step without the host in the loop ("auto mode") -------------------------------------------------
+ * slam_pf_step_auto: one whole filter step -- slam_pf_step (proposal = 0) or slam_pf_step_proposal (1), the
+ * normalisation, Neff, the decision to resample (force < 0: Neff < neff_frac * n_global; 0 / 1: never / always) and, for
+ * a filter that lives wholly on this shard, the resampling itself (slam_pf_resample_local) -- ENQUEUED: the call
+ * returns at once, steps queue back to back, the statistics, the decision and the bookkeeping of the lazy resampling
+ * stay on the device.  m <= 64.  Same particles as the synchronous calls.  The other slam_pf_* entry points may be
+ * mixed in freely (they wait for the queue first).
+ * Sharded filter (slam_pf_attach_exchange): the ranks' GPUs exchange their three scalars per step through a shared
+ * page of pinned host memory, so steps that do not resample need no host either.  A step that does resample needs the
+ * all-gather of the log-weights and the record exchange, which the caller issues (RCCL): that step HALTS, the steps
+ * queued behind it are skipped on the device, and the next slam_pf_step_auto / slam_pf_flush returns SLAM_PF_HALTED
+ * (nothing enqueued by that call).  The caller then resamples with slam_pf_halt_info + the legacy entry points
+ * (slam_pf_copy_logw, slam_pf_ancestors_all, slam_pf_pack, slam_pf_resample_apply), calls slam_pf_resume -- the
+ * skipped steps are enqueued again from the library's log -- and repeats the call. */
+int slam_pf_step_auto(slam_pf_t h, double V, double G, double wheelbase, const double Q[4], double dt, const double* z,
+                      const int32_t* ids, int m, const double R[4], double neff_frac, int force, int proposal);
+/* Wait for everything queued.  out (may be NULL) = {Neff of the last step, 1 if it resampled, resamplings so far,
+ * steps so far}. */
+int slam_pf_flush(slam_pf_t h, double out[4]);
+int slam_pf_halt_info(slam_pf_t h, double out[2]);      /* {largest normalised log-weight, resamplings so far}        */
+int slam_pf_resume(slam_pf_t h, int64_t resamplings);   /* resamplings: the caller's count after its own resampling   */
+/* The systematic-resampling offset of resampling k is Philox(counter (0, 0, k, 2), key seed): the count is part of the
+ * filter state (slam.jl_amd/pf.py: FastSLAM.resamples). */
+int slam_pf_resample_count(slam_pf_t h, int64_t* count);
+int slam_pf_set_resample_count(slam_pf_t h, int64_t count);
+/* The ranks' shared scalar page (host memory every rank has mapped, >= 2 * world * 64 bytes, zeroed): see above. */
+int slam_pf_attach_exchange(slam_pf_t h, int rank, int world, void* page, size_t bytes);
+/* Diagnostics: 100 MHz wall-clock stamps of the last auto step: kernel start, last workgroup arrived, statistics
+ * folded, decision taken, bookkeeping done, published.  Waits for the queue. */
+int slam_pf_debug_stamps(slam_pf_t h, uint64_t out[8]);
+
+/* ---- SURVEY 8b's whole-filter calls (filter wholly on this shard) --------------------------------------------------
+ * slam_pf_resample: F4 -- normalise, and resample (systematic, slam_pf_resample_local) if Neff < neff_frac * n;
+ * *resampled (may be NULL) tells whether it did.  slam_pf_get_mean_pose: weighted mean [x, y, phi].
+ * slam_pf_get_weights: w = exp(logw) of the local particles (double[n_local]).  Particle.weight, src/common.jl:19. */
+int slam_pf_resample(slam_pf_t h, double neff_frac, int* resampled);
+int slam_pf_get_mean_pose(slam_pf_t h, double pose[3]);
+int slam_pf_get_weights(slam_pf_t h, double* w);
 
 #ifdef __cplusplus
 }

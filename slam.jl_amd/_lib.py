@@ -21,6 +21,7 @@ SLAM_E_CAPACITY = -2
 SLAM_E_NOTPD = -3
 SLAM_E_HIP = -4
 SLAM_E_NOMEM = -5
+SLAM_PF_HALTED = 1
 SLAM_F32, SLAM_F64 = 0, 1
 SLAM_FORM_CHOLESKY, SLAM_FORM_JOSEPH = 0, 1
 KERNEL_IDS = {"gate": 0, "gate_final": 1, "predict": 2, "augment": 3, "pht": 4, "factor": 5, "w1": 6, "syrk": 7}
@@ -121,6 +122,18 @@ SIGNATURES = {
     "slam_pf_download": (C.c_int, [_h, C.c_void_p, C.c_void_p, C.c_void_p]),
     "slam_pf_sync": (C.c_int, [_h]),
     "slam_pf_stream": (C.c_int, [_h, C.POINTER(C.c_void_p)]),
+    "slam_pf_step_auto": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, _dp, C.c_double, _dp, _ip, C.c_int, _dp, C.c_double,
+                                    C.c_int, C.c_int]),
+    "slam_pf_flush": (C.c_int, [_h, _dp]),
+    "slam_pf_halt_info": (C.c_int, [_h, _dp]),
+    "slam_pf_resume": (C.c_int, [_h, C.c_int64]),
+    "slam_pf_resample_count": (C.c_int, [_h, C.POINTER(C.c_int64)]),
+    "slam_pf_set_resample_count": (C.c_int, [_h, C.c_int64]),
+    "slam_pf_attach_exchange": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    "slam_pf_debug_stamps": (C.c_int, [_h, C.POINTER(C.c_uint64)]),
+    "slam_pf_resample": (C.c_int, [_h, C.c_double, C.POINTER(C.c_int)]),
+    "slam_pf_get_mean_pose": (C.c_int, [_h, _dp]),
+    "slam_pf_get_weights": (C.c_int, [_h, _dp]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

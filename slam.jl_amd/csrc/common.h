@@ -91,8 +91,9 @@ struct slam_ekf {
     int32_t obs_seq;
 
     // down-date tile order (ekf_syrk.hip): workgroup b computes tile tiles[b]
-    int2* tiles;
-    int tiles_T, tiles_len, tiles_cap;
+    int2* tiles;         // two orders in one buffer: the super-row order (8 lists of tiles_len), then the band-major
+    int tiles_T, tiles_len, tiles_cap;     // order of the split-bf16 path (8 lists of tilesB_len, at offset tilesB_off)
+    int tilesB_off, tilesB_len;
     int tiles_xlen[8];   // valid entries of each XCD's list
     int diag_off, diag_len, diag_xlen[8];   // fp32: the diagonal tiles, listed after the main lists
 

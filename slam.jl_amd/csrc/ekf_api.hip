@@ -248,7 +248,7 @@ extern "C" int slam_ekf_create(slam_ekf_t* out, int dtype, int max_landmarks, in
     h->kcap = 0;
     h->W1 = h->W2 = h->Wimg = nullptr;
     h->PHt = h->PHtS = h->Kd = h->Cmat = h->Smat = h->Mwork = h->gvec = nullptr;
-    h->tiles = nullptr; h->tiles_T = h->tiles_len = h->tiles_cap = 0;
+    h->tiles = nullptr; h->tiles_T = h->tiles_len = h->tiles_cap = 0; h->tilesB_off = h->tilesB_len = 0;
     h->obsbuf = nullptr; h->idfbuf = nullptr; h->ocap = 0;
     h->h_obs = nullptr; h->h_idf = nullptr; h->h_assoc = nullptr; h->d_assoc = nullptr;
     h->gate_part = nullptr; h->gate_blocks_cap = 0;

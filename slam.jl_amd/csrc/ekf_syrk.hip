@@ -670,7 +670,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int xcd = blockIdx.x & 7;
     const int rk = blockIdx.x >> 3;
     const int nper = gridDim.x >> 3;
-    if (rk >= (nper >> 1) && !(c.xflags & 1)) __builtin_amdgcn_s_sleep(127);                  // ~3.4 us stagger (speed only)
+    // persistent launches only (fewer workgroups than tiles): the second half of the grid starts ~3.4 us late (speed only)
+    if (nper < L && rk >= (nper >> 1) && !(c.xflags & 1)) __builtin_amdgcn_s_sleep(127);
     const int2* list = tiles + (size_t)xcd * L;
     float* sD = &smem[0][0][0][0] + wave * (2 * 32 * SP);                   // per-wave scratches alias the panel buffers
     float* sV = sD + 32 * SP;
@@ -852,29 +853,44 @@ __global__ __launch_bounds__(256) void downdate_f64_mfma(double* __restrict__ P,
 // Tile lists: eight lists of equal length L (padded with -1), laid out [xcd][slot].  XCD x
 // (= workgroup id % 8 under round-robin dispatch) walks super-rows of SR tile rows, largest
 // first, column by column; its workgroups take slots rk, rk + nper, ...  Diagonal tiles come last.
-void build_tile_order(int T, std::vector<int2>& out) {
+// order 0: XCD x walks super-rows of SR tile rows column by column (row panels stay in its L2, every column panel
+//          fetched is used SR times): the order of the persistent kernels (fp32 matrix cores, fp64).
+// order 2: band-major -- column band J outer, tile rows inner -- with tile row I owned by XCD I % 8 (snake order over
+//          16 rows, so the row lengths balance).  All workgroups of the chip then work in the same few column bands
+//          (a band is a nearly contiguous 10 MB of the column-major matrix), every XCD keeps ITS 1/8 of the row
+//          panels (1.9 MB) in its L2 for the whole launch and streams the band's column panel.  The order of the
+//          split-bf16 path (one-box A/B tools/gpu_order.sh: -3 %; with one workgroup per tile: -11 %).
+void build_tile_order(int T, std::vector<int2>& out, int order) {
     constexpr int NX = 8;
     const int SR = getenv("SLAMHIP_SR") ? atoi(getenv("SLAMHIP_SR")) : 4;      // tile rows per super-row (experiment knob)
     const int nsr = (T + SR - 1) / SR;
-    std::vector<long> load(NX, 0);
-    std::vector<std::vector<int>> mine(NX);
-    for (int s = nsr - 1; s >= 0; --s) {
-        const int I0 = s * SR, I1 = std::min(T, I0 + SR);
-        long cnt = 0;
-        for (int I = I0; I < I1; ++I) cnt += I;            // off-diagonal tiles of these rows
-        int best = 0;
-        for (int xcd = 1; xcd < NX; ++xcd)
-            if (load[xcd] < load[best]) best = xcd;
-        load[best] += cnt;
-        mine[best].push_back(s);
-    }
     std::vector<std::vector<int2>> lists(NX);
-    for (int xcd = 0; xcd < NX; ++xcd)
-        for (int s : mine[xcd]) {
+    if (order == 2) {
+        for (int J = 0; J < T; ++J)
+            for (int I = J + 1; I < T; ++I) {
+                const int r = I % (2 * NX);
+                lists[r < NX ? r : 2 * NX - 1 - r].push_back(make_int2(I, J));
+            }
+    } else {
+        std::vector<long> load(NX, 0);
+        std::vector<std::vector<int>> mine(NX);
+        for (int s = nsr - 1; s >= 0; --s) {
             const int I0 = s * SR, I1 = std::min(T, I0 + SR);
-            for (int J = 0; J < I1; ++J)
-                for (int I = std::max(I0, J + 1); I < I1; ++I) lists[xcd].push_back(make_int2(I, J));
+            long cnt = 0;
+            for (int I = I0; I < I1; ++I) cnt += I;            // off-diagonal tiles of these rows
+            int best = 0;
+            for (int xcd = 1; xcd < NX; ++xcd)
+                if (load[xcd] < load[best]) best = xcd;
+            load[best] += cnt;
+            mine[best].push_back(s);
         }
+        for (int xcd = 0; xcd < NX; ++xcd)
+            for (int s : mine[xcd]) {
+                const int I0 = s * SR, I1 = std::min(T, I0 + SR);
+                for (int J = 0; J < I1; ++J)
+                    for (int I = std::max(I0, J + 1); I < I1; ++I) lists[xcd].push_back(make_int2(I, J));
+            }
+    }
     // the T diagonal tiles go to the END of the lists, shortest list first: they fill the ragged last round
     for (int I = 0; I < T; ++I) {
         int best = 0;
@@ -891,19 +907,24 @@ void build_tile_order(int T, std::vector<int2>& out) {
 
 int ensure_tile_order(slam_ekf* h, int T) {
     if (h->tiles && h->tiles_T == T) return SLAM_OK;
-    std::vector<int2> order;
-    build_tile_order(T, order);
+    std::vector<int2> order, orderB;
+    build_tile_order(T, order, 0);
+    build_tile_order(T, orderB, 2);
+    const size_t total = order.size() + orderB.size();
     HIP_TRY(hipStreamSynchronize(h->stream));          // earlier down-dates may still read the old list
-    if ((int)order.size() > h->tiles_cap) {
+    if ((int)total > h->tiles_cap) {
         if (h->tiles) (void)hipFree(h->tiles);
         h->tiles = nullptr;
         h->tiles_cap = 0;
-        HIP_TRY(hipMalloc((void**)&h->tiles, sizeof(int2) * order.size()));
-        h->tiles_cap = (int)order.size();
+        HIP_TRY(hipMalloc((void**)&h->tiles, sizeof(int2) * total));
+        h->tiles_cap = (int)total;
     }
     HIP_TRY(hipMemcpy(h->tiles, order.data(), sizeof(int2) * order.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->tiles + order.size(), orderB.data(), sizeof(int2) * orderB.size(), hipMemcpyHostToDevice));
     h->tiles_T = T;
     h->tiles_len = (int)order.size() / 8;          // L: entries per XCD list
+    h->tilesB_off = (int)order.size();
+    h->tilesB_len = (int)orderB.size() / 8;
     return SLAM_OK;
 }
 
@@ -918,6 +939,7 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
     if (rc) return rc;
     KTimer t(h, SLAM_K_SYRK);
     if (h->dtype == SLAM_F32) {
+        // persistent: two workgroups per CU (VGPR- and LDS-limited residency), never more than there are tiles
         // persistent: two workgroups per CU (VGPR- and LDS-limited residency), never more than there are tiles
         int per_xcd = 2 * h->num_cus / 8;
         if (per_xcd > h->tiles_len) per_xcd = h->tiles_len;
@@ -946,11 +968,23 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
     hipLaunchKernelGGL((downdate_f32_mfma<false, NCH>), dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, \
                        n, (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,       \
                        h->d_status, h->xflags << 8, (unsigned long long*)nullptr, dcount, joseph, IMGARGS)
-            if (nch >= 3 && !joseph && !(h->xflags & 8))           // split-bf16 path (SLAMHIP_X bit 8 switches it off)
-                hipLaunchKernelGGL((downdate_f32_mfma<false, 4, 3, true>), dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream,
-                                   (float*)h->P, h->ld, n, (const float*)X, (const float*)Y, pitch, kp_total,
-                                   (const int2*)h->tiles, h->tiles_len, h->d_status, h->xflags << 8,
-                                   (unsigned long long*)nullptr, dcount, joseph, IMGARGS);
+            if (nch >= 3 && !joseph && !(h->xflags & 8)) {         // split-bf16 path (SLAMHIP_X bit 8 switches it off)
+                // HBM-bound: ONE workgroup per tile, handed out by the hardware dispatcher in the band-major order.
+                // Measured against the persistent grid of 2 workgroups per CU walking the super-row lists (one-box
+                // A/B, tools/gpu_r2b.sh): 0.341 against 0.386 ms.  A static split ends with its slowest workgroup (the
+                // CUs do not get equal shares of the memory system; tools/micro_tilewalk.hip shows the same 17 % on a
+                // bare read + rewrite of the tiles); the dispatcher keeps every CU busy to the end.  SLAMHIP_WGS =
+                // workgroups per XCD list (64 = two per CU) and SLAMHIP_ORDER=0 restore the old launch for A/B runs.
+                const bool bandB = !(getenv("SLAMHIP_ORDER") && atoi(getenv("SLAMHIP_ORDER")) == 0);
+                const int2* lst = bandB ? (const int2*)h->tiles + h->tilesB_off : (const int2*)h->tiles;
+                const int L = bandB ? h->tilesB_len : h->tiles_len;
+                int wgs = getenv("SLAMHIP_WGS") ? atoi(getenv("SLAMHIP_WGS")) : L;
+                if (wgs > L) wgs = L;
+                if (wgs < 1) wgs = 1;
+                hipLaunchKernelGGL((downdate_f32_mfma<false, 4, 3, true>), dim3(8 * wgs), dim3(NTHREADS), 0, h->stream,
+                                   (float*)h->P, h->ld, n, (const float*)X, (const float*)Y, pitch, kp_total, lst, L,
+                                   h->d_status, h->xflags << 8, (unsigned long long*)nullptr, dcount, joseph, IMGARGS);
+            }
             else if (nch == 4) DD_LAUNCH_STREAM4();
             else if (nch == 3) DD_LAUNCH_STREAM(3);
             else DD_LAUNCH_STREAM(2);

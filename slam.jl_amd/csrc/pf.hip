@@ -32,6 +32,49 @@
 // bit whatever the compiler would otherwise fuse across the predict/update boundary.  The kernels are HBM-bound.
 #pragma clang fp contract(off)
 
+// ---- auto mode: device-resident control block, its pinned mirror, and the host's log of queued steps ----------
+constexpr int PF_CTL_TABS = 64;             // = PF_TAB_MAX (asserted below)
+constexpr int PF_CTL_MAXOBS = 64;           // = PF_AUTO_MAXOBS
+
+struct PfCtl {                   // device memory; written by the LAST workgroup of a step kernel, read by later kernels
+    double shift_next;           // normalisation shift the next kernel that reads logw subtracts on the way
+    double shift_scan;           // shift of the step that decided to resample (the cdf is formed through it)
+    double gmax_norm;            // largest normalised log-weight of that step, as the storage type holds it
+    double u0;                   // systematic-resampling offset of that step
+    double stats[8];             // {max, sum w, sum w^2, sum w x, sum w y, sum w sin, sum w cos, Neff}, w = exp(logw - max)
+    long long seq;               // last completed step
+    long long resample_seq;      // the step whose (lazy) resampling the conditional kernels apply
+    long long halt_seq;          // != 0: that step wants a resampling the device cannot do; later steps are skipped
+    int32_t arrive;              // arrival counter of the step kernel's workgroups
+    int32_t error;               // 1: the scalar exchange between the ranks timed out
+    int32_t nresamples;          // resamplings so far
+    int32_t pcur, tside;         // live pose buffer / ancestor-table side
+    int32_t identity;            // landmarks without an ancestor table
+    int32_t tl_count, tl_fresh;  // the pending lazy resampling: live tables to compose, index of the fresh one (-1: none)
+    int32_t tl_idx[PF_CTL_TABS];
+    int32_t tref[PF_CTL_TABS];   // landmarks referring to each table
+    unsigned long long stamps[8];    // diagnostics: 100 MHz wall-clock stamps of the last step (kernel start, tail phases)
+};
+
+struct PfMirror {                // pinned host memory, written with system-scope stores: read by the host without a sync
+    long long done_seq;          // last completed (not skipped) step
+    long long halt_seq;
+    long long resampled_seq;     // last step that resampled (on the device)
+    long long nresamples;
+    double neff;
+    double stats[8];
+    long long error;
+};
+
+struct PfStepRec {               // one queued slam_pf_step_auto call, kept until the device confirms it
+    long long seq;
+    uint32_t rng_step;
+    int m, force, proposal;
+    double V, G, wheelbase, Q[4], dt, R[4], neff_frac;
+    double z[2 * PF_CTL_MAXOBS];
+    int32_t ids[PF_CTL_MAXOBS];
+};
+
 struct slam_pf {
     int dtype, device;
     size_t esz;
@@ -77,12 +120,33 @@ struct slam_pf {
     int32_t* d_src;      // [n] gather source: >= 0 local index, < 0: -(recv position + 1)
     int32_t* d_anc;      // [n] ancestors of slam_pf_resample_local
     int red_blocks;
+    // ---- auto mode (slam_pf_step_auto): the per-step statistics, the Neff decision, the lazy-resampling bookkeeping
+    // and the resampling itself stay on the device; the host only enqueues.  See "auto mode" below.
+    PfCtl* d_ctl;                // device control block
+    int32_t* d_lmstate;          // [nl] per-landmark state word (table + 1 | buffer << 8 | seen << 9)
+    PfMirror* h_mir;             // pinned: what the host may look at without synchronising
+    PfMirror* h_mir_dev;
+    double* h_auto_obs;          // pinned [PF_LOG][2 * PF_AUTO_MAXOBS]: observation slots of the queued steps
+    int32_t* h_auto_ids;         // pinned [PF_LOG][PF_AUTO_MAXOBS]
+    double* h_auto_obs_dev;
+    int32_t* h_auto_ids_dev;
+    int auto_on;                 // the device copy of the bookkeeping is the live one
+    long long auto_seq;          // last step enqueued
+    long long nresamples;        // resamplings so far (drives the systematic-resampling offset)
+    std::vector<PfStepRec> log;       // queued steps not yet confirmed by the device (replayed after a halt)
+    double* d_xchg;              // device address of the ranks' shared scalar page (sharded filter), or null
+    void* xchg_host;
+    int xchg_rank, xchg_world;
+    double last_out[4];          // {Neff, resampled?, resamplings, step} of the last confirmed step
+    int halted;                  // a sharded filter's step wants a resampling: the caller exchanges, then slam_pf_resume
+    double halt_gmax;            // largest normalised log-weight of the halted step
+    long long last_resampled_seq;
 };
 
 namespace {
 
 // ---- Philox4x32-10 -------------------------------------------------------------------------------
-__device__ inline void philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+__host__ __device__ inline void philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                               uint32_t (&out)[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -178,6 +242,10 @@ constexpr int META_PRIOR_SHIFT = 10;        // bits 10..18: table + 1 and buffer
                                             // (the FastSLAM-2.0 proposal reads every observation against the prior map)
 constexpr int PF_OCAP = 1024;               // observations per call; the meta words sit PF_OCAP ints behind the codes
 constexpr int PF_TAB_MAX = 64;              // live ancestor tables before the maps are materialised
+constexpr int PF_AUTO_MAXOBS = 64;          // observations per slam_pf_step_auto call (planned per workgroup in LDS)
+constexpr int PF_LOG = 32;                  // steps the host may run ahead of the device
+constexpr int32_t LS_TAB = 0xff, LS_BUF = 1 << 8, LS_SEEN = 1 << 9;     // per-landmark state word of the auto mode
+static_assert(PF_CTL_TABS == PF_TAB_MAX && PF_CTL_MAXOBS == PF_AUTO_MAXOBS, "control-block sizes");
 
 // One landmark record of one particle (5 strided values).
 template <typename T>
@@ -198,7 +266,9 @@ __device__ __forceinline__ void fold_partials(const double* __restrict__ part, i
 // Per-block weight statistics with the block's OWN maximum as the shift (one pass; pf_fold_kernel rescales):
 // part[b] = {m_b, sum e, sum e^2, sum e x, sum e y, sum e sin(phi), sum e cos(phi)},  e = exp(logw - shift_b),
 // shift_b = m_b if `relative` else 0.
-template <typename T>
+// SC1: the partials are stored write-through at agent scope (global_store ... sc1) -- the form in which the workgroup
+// that arrives LAST at a counter may read them in the same launch without an L2 write-back (auto mode, pf_auto_tail).
+template <typename T, bool SC1 = false>
 __device__ __forceinline__ void block_weight_stats(T lw, T x, T y, T phi, bool valid, int relative, double* __restrict__ part) {
     __shared__ double sh[4];
     const double m = block_reduce(valid ? (double)lw : -__builtin_inf(), sh, true);
@@ -210,7 +280,12 @@ __device__ __forceinline__ void block_weight_stats(T lw, T x, T y, T phi, bool v
     const double ss = block_reduce(e * sin(ph), sh, false), sc = block_reduce(e * cos(ph), sh, false);
     if (threadIdx.x == 0) {
         double* o = part + (size_t)blockIdx.x * 8;
-        o[0] = m; o[1] = s1; o[2] = s2; o[3] = sx; o[4] = sy; o[5] = ss; o[6] = sc;
+        const double v[7] = {m, s1, s2, sx, sy, ss, sc};
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            if (SC1) __hip_atomic_store(o + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else o[i] = v[i];
+        }
     }
 }
 
@@ -335,6 +410,31 @@ __device__ __forceinline__ void apply_known(T* lm0, T* lm1, const int32_t* __res
     }
 }
 
+// One particle's filter step: predict (PREDICT), the m known-id updates, the log-weight.  Shared by the legacy kernels
+// (observation codes staged by the host) and the auto mode's kernel (codes planned on the device).
+template <typename T, bool PREDICT>
+__device__ __forceinline__ void step_core(T* __restrict__ pose, T* lm0, T* lm1, const int32_t* __restrict__ tabs,
+                                          T* __restrict__ logw, int64_t n, int64_t first, uint32_t step, uint64_t seed, T V, T G,
+                                          T wheelbase, T sigV, T sigG, T dt, const double* s_obs, const int32_t* s_ids,
+                                          const int32_t* s_meta, int m, T R00, T R10, T R01, T R11, T pend, int64_t p, bool valid,
+                                          T& x, T& y, T& phi, T& lw) {
+    x = pose[p]; y = pose[n + p]; phi = pose[2 * n + p];
+    if (PREDICT) {
+        T e1, e2;
+        normals2<T>((uint64_t)(first + p), step, STREAM_PREDICT, seed, e1, e2);
+        const T Vn = V + sigV * e1;                       // sim/sim-utils.jl:36
+        const T Gn = G + sigG * e2;                       // :37
+        const T xn = x + Vn * dt * cos(Gn + phi);         // src/ekf.jl:39-41
+        const T yn = y + Vn * dt * sin(Gn + phi);
+        const T pn = wrap_pi<T>(phi + Vn * dt * sin(Gn) / wheelbase);
+        x = xn; y = yn; phi = pn;
+        if (valid) { pose[p] = x; pose[n + p] = y; pose[2 * n + p] = phi; }
+    }
+    lw = logw[p] - pend;          // `pend`: the normalisation shift deferred by slam_pf_normalize (0 if none)
+    apply_known<T>(lm0, lm1, tabs, n, p, s_obs, s_ids, s_meta, m, x, y, phi, R00, R10, R01, R11, valid, lw);
+    if (valid) logw[p] = lw;
+}
+
 // F1 + F2/F3 (+ F4 partials): one pass over the particle -- predict (PREDICT), the m known-id updates, and
 // (STATS) the block's weight statistics, so that a filter step is ONE sweep of HBM instead of five launches.
 template <typename T, bool PREDICT, bool STATS>
@@ -355,54 +455,22 @@ __global__ __launch_bounds__(256) void pf_step_kernel(T* __restrict__ pose, T* l
     const bool valid = pi < n;
     if (!STATS && !valid) return;
     const int64_t p = valid ? pi : n - 1;          // (STATS: idle lanes shadow the last particle, stores are masked)
-    T x = pose[p], y = pose[n + p], phi = pose[2 * n + p];
-    if (PREDICT) {
-        T e1, e2;
-        normals2<T>((uint64_t)(first + p), step, STREAM_PREDICT, seed, e1, e2);
-        const T Vn = V + sigV * e1;                       // sim/sim-utils.jl:36
-        const T Gn = G + sigG * e2;                       // :37
-        const T xn = x + Vn * dt * cos(Gn + phi);         // src/ekf.jl:39-41
-        const T yn = y + Vn * dt * sin(Gn + phi);
-        const T pn = wrap_pi<T>(phi + Vn * dt * sin(Gn) / wheelbase);
-        x = xn; y = yn; phi = pn;
-        if (valid) { pose[p] = x; pose[n + p] = y; pose[2 * n + p] = phi; }
-    }
-    T lw = logw[p] - pend;        // `pend`: the normalisation shift deferred by slam_pf_normalize (0 if none)
-    apply_known<T>(lm0, lm1, tabs, n, p, s_obs, s_ids, s_meta, m, x, y, phi, R00, R10, R01, R11, valid, lw);
-    if (valid) logw[p] = lw;
-    // (folding the partials in the last workgroup to finish was tried: its agent-scope release/acquire is an L2
-    //  write-back + invalidate on this multi-XCD part and doubled the kernel's time; a 1-workgroup fold kernel follows)
+    T x, y, phi, lw;
+    step_core<T, PREDICT>(pose, lm0, lm1, tabs, logw, n, first, step, seed, V, G, wheelbase, sigV, sigG, dt, s_obs, s_ids, s_meta,
+                          m, R00, R10, R01, R11, pend, p, valid, x, y, phi, lw);
+    // (folding the partials in the last workgroup to finish behind an agent-scope release/acquire was tried: that is an L2
+    //  write-back + invalidate on this multi-XCD part and doubled the kernel's time; here a 1-workgroup fold kernel
+    //  follows, the auto mode's kernel uses write-through partials instead: pf_auto_step_kernel)
     if (STATS) block_weight_stats<T>(lw, x, y, phi, valid, 1, part);
 }
 
-// ---- N4: FastSLAM-2.0 proposal ------------------------------------------------------------------------
-// One step in which the pose is drawn from the proposal that already knows this step's observations (Montemerlo
-// et al. 2003; no reference code -- SURVEY 8f N4; specified in oracle/pf_ref.py::step_proposal).  The proposal
-// lives in CONTROL space: pose = f(pose, V + u0, G + u1) (src/ekf.jl:39-41), u = Lq w, Lq = chol(Q), w ~ N(0, I)
-// a priori.  Around w = 0 the pose moves by GL w, GL = Gu Lq (Gu: src/ekf.jl:27-29), so an observation of a landmark
-// the particle holds is a linear 2 x 2 measurement of w with noise Sf = Hf Pf Hf' + R: pass 1 assimilates them in
-// the Cholesky form of src/ekf.jl:67-75 and multiplies their predictive densities into the weight, the pose is
-// sampled with the SAME two normals FastSLAM-1.0's predict uses (no observation: the same pose bit for bit), and
-// pass 2 is apply_known from the sampled pose with the weight left alone.  One sweep, records read twice: 69 us
-// against the 48 us of pf_step_kernel at 262144 particles x 16 observations (the 84 MB of pass 1 at HBM speed).
-// (Keeping the 16 records in registers between the passes, all requested up front, was measured: 166 VGPRs, three
-//  waves per SIMD instead of six, and the step went from 107 to 122 us on the same box.)
+// One particle's FastSLAM-2.0 step (see pf_proposal_kernel).  Shared by the legacy kernel and the auto mode's kernel.
 template <typename T>
-__global__ __launch_bounds__(256) void pf_proposal_kernel(T* __restrict__ pose, T* lm0, T* lm1, const int32_t* __restrict__ tabs,
-                                                           T* __restrict__ logw,
-                                                           int64_t n, int64_t first, uint32_t step, uint64_t seed, T V, T G,
-                                                           T wheelbase, T lq00, T lq10, T lq11, T dt,
-                                                           const double* __restrict__ z, const int32_t* __restrict__ ids,
-                                                           int m, T R00, T R10, T R01, T R11, double* __restrict__ part, T pend) {
-    extern __shared__ double s_obs[];              // [m][2] doubles, then [m] codes, then [m] meta words
-    int32_t* s_ids = reinterpret_cast<int32_t*>(s_obs + 2 * m);
-    int32_t* s_meta = s_ids + m;
-    for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) s_obs[i] = z[i];
-    for (int i = threadIdx.x; i < m; i += blockDim.x) { s_ids[i] = ids[i]; s_meta[i] = ids[PF_OCAP + i]; }
-    __syncthreads();
-    const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = pi < n;
-    const int64_t p = valid ? pi : n - 1;          // idle lanes shadow the last particle, stores are masked
+__device__ __forceinline__ void proposal_core(T* __restrict__ pose, T* lm0, T* lm1, const int32_t* __restrict__ tabs,
+                                              T* __restrict__ logw, int64_t n, int64_t first, uint32_t step, uint64_t seed, T V,
+                                              T G, T wheelbase, T lq00, T lq10, T lq11, T dt, const double* s_obs,
+                                              const int32_t* s_ids, const int32_t* s_meta, int m, T R00, T R10, T R01, T R11,
+                                              T pend, int64_t p, bool valid, T& xo, T& yo, T& po, T& lwo) {
     const T x = pose[p], y = pose[n + p], phi = pose[2 * n + p];
     // motion mean (w = 0) and GL = Gu Lq
     const T s = sin(G + phi), c = cos(G + phi);
@@ -488,6 +556,40 @@ __global__ __launch_bounds__(256) void pf_proposal_kernel(T* __restrict__ pose, 
     if (valid) { pose[p] = xn; pose[n + p] = yn; pose[2 * n + p] = pn; logw[p] = lw; }
     T unused = 0;
     apply_known<T>(lm0, lm1, tabs, n, p, s_obs, s_ids, s_meta, m, xn, yn, pn, R00, R10, R01, R11, valid, unused);
+    xo = xn; yo = yn; po = pn; lwo = lw;
+}
+
+// ---- N4: FastSLAM-2.0 proposal ------------------------------------------------------------------------
+// One step in which the pose is drawn from the proposal that already knows this step's observations (Montemerlo
+// et al. 2003; no reference code -- SURVEY 8f N4; specified in oracle/pf_ref.py::step_proposal).  The proposal
+// lives in CONTROL space: pose = f(pose, V + u0, G + u1) (src/ekf.jl:39-41), u = Lq w, Lq = chol(Q), w ~ N(0, I)
+// a priori.  Around w = 0 the pose moves by GL w, GL = Gu Lq (Gu: src/ekf.jl:27-29), so an observation of a landmark
+// the particle holds is a linear 2 x 2 measurement of w with noise Sf = Hf Pf Hf' + R: pass 1 assimilates them in
+// the Cholesky form of src/ekf.jl:67-75 and multiplies their predictive densities into the weight, the pose is
+// sampled with the SAME two normals FastSLAM-1.0's predict uses (no observation: the same pose bit for bit), and
+// pass 2 is apply_known from the sampled pose with the weight left alone.  One sweep, records read twice: 69 us
+// against the 48 us of pf_step_kernel at 262144 particles x 16 observations (the 84 MB of pass 1 at HBM speed).
+// (Keeping the 16 records in registers between the passes, all requested up front, was measured: 166 VGPRs, three
+//  waves per SIMD instead of six, and the step went from 107 to 122 us on the same box.)
+template <typename T>
+__global__ __launch_bounds__(256) void pf_proposal_kernel(T* __restrict__ pose, T* lm0, T* lm1, const int32_t* __restrict__ tabs,
+                                                           T* __restrict__ logw,
+                                                           int64_t n, int64_t first, uint32_t step, uint64_t seed, T V, T G,
+                                                           T wheelbase, T lq00, T lq10, T lq11, T dt,
+                                                           const double* __restrict__ z, const int32_t* __restrict__ ids,
+                                                           int m, T R00, T R10, T R01, T R11, double* __restrict__ part, T pend) {
+    extern __shared__ double s_obs[];              // [m][2] doubles, then [m] codes, then [m] meta words
+    int32_t* s_ids = reinterpret_cast<int32_t*>(s_obs + 2 * m);
+    int32_t* s_meta = s_ids + m;
+    for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) s_obs[i] = z[i];
+    for (int i = threadIdx.x; i < m; i += blockDim.x) { s_ids[i] = ids[i]; s_meta[i] = ids[PF_OCAP + i]; }
+    __syncthreads();
+    const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = pi < n;
+    const int64_t p = valid ? pi : n - 1;          // idle lanes shadow the last particle, stores are masked
+    T xn, yn, pn, lw;
+    proposal_core<T>(pose, lm0, lm1, tabs, logw, n, first, step, seed, V, G, wheelbase, lq00, lq10, lq11, dt, s_obs, s_ids, s_meta, m,
+                     R00, R10, R01, R11, pend, p, valid, xn, yn, pn, lw);
     block_weight_stats<T>(lw, xn, yn, pn, valid, 1, part);
 }
 
@@ -650,10 +752,12 @@ __device__ __forceinline__ void fold_partials(const double* __restrict__ part, i
         out[0] = M;
         for (int i = 0; i < 6; ++i) out[1 + i] = acc[i];
         // the host polls pinned memory for `seq` (no copy kernel, no event, no interrupt-driven wake-up)
-        host_out[0] = M;
-        for (int i = 0; i < 6; ++i) host_out[1 + i] = acc[i];
-        __threadfence_system();
-        __hip_atomic_store(reinterpret_cast<long long*>(host_out + 7), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // write-through system-scope stores, drained, then the sequence word (a system-scope fence here is a write-back
+        // of the XCD's L2, full of the sweep's dirty landmark records: it cost most of this kernel's 7 us)
+        __hip_atomic_store(host_out, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int i = 0; i < 6; ++i) __hip_atomic_store(host_out + 1 + i, acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(reinterpret_cast<long long*>(host_out + 7), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -890,6 +994,415 @@ __global__ __launch_bounds__(256) void pf_materialise_kernel(T* lm0, T* lm1, con
     }
 }
 
+
+// ---- auto mode -------------------------------------------------------------------------------------------------------
+// slam_pf_step_auto: a filter step that needs NO answer from the host.  What the legacy entry points keep on the host
+// -- the folded weight statistics, the normalisation shift, Neff and the decision to resample, the bookkeeping of the
+// lazy resampling (which buffer and which ancestor table holds each landmark), the live pose buffer -- lives in a
+// device-resident control block (PfCtl) and a per-landmark state word:
+//   * every workgroup of the step kernel plans the observation codes itself, in LDS, from the state words (the host's
+//     pf_stage, a few dozen integer operations);
+//   * the per-block weight statistics are stored write-through (sc1) and the workgroup that arrives LAST at a counter
+//     folds them, forms shift / Neff / the decision, applies the state transitions of this step's observations and, if
+//     the filter resamples and lives wholly on this shard, prepares the lazy resampling (table list, fresh table,
+//     buffer flips) -- pf_auto_tail.  No release/acquire fence (an L2 write-back + invalidate on this multi-XCD part)
+//     is involved: write-through stores, every storing wave's vmcnt(0), one agent-scope counter add per workgroup, and
+//     sc1 loads in the workgroup whose add came last (MI355X guide, "Valid forms");
+//   * two conditional kernels follow every step (cdf; ancestors + lazy apply) and return at once unless the control
+//     block says that THIS step resamples.
+// A sharded filter (or an exhausted table pool) cannot resample on the device: the tail then records a HALT, the steps
+// already queued behind it return without touching anything, and the host -- which notices at its next call -- does the
+// resampling the legacy way and re-enqueues the skipped steps from its log.  The ranks of a sharded filter exchange
+// their three scalars (max, sum w, sum w^2) through a page of pinned host memory that every rank's GPU can write and
+// poll: no host in the loop, no collective launch per step.
+
+template <typename T>
+__device__ __forceinline__ T ld_sc1(const T* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the host's philox_uniform(step, stream, seed) (pf.py): counter (0, 0, step, stream)
+__host__ __device__ inline double resample_offset(uint32_t count, uint64_t seed) {
+    uint32_t r[4];
+    philox(0u, 0u, count, 2u /* STREAM_RESAMPLE */, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    return ((double)(r[0] >> 8) + 0.5) * (1.0 / 16777216.0);
+}
+
+struct PfAutoArgs {
+    void *pose0, *pose1, *lm0, *lm1, *logw;
+    int32_t *tab0, *tab1;
+    long long n, first, n_global, seq;
+    unsigned long long seed;
+    unsigned int step;
+    int m, nl, force, lazy_ok, rank, world;
+    double V, G, wheelbase, a0, a1, a2, dt, R00, R10, R01, R11, neff_frac;
+    const double* z;
+    const int32_t* ids;
+    double* part;
+    PfCtl* ctl;
+    int32_t* lmstate;
+    PfMirror* mir;
+    double* xchg;
+};
+
+// The planning of pf_stage on the device: observation i of landmark l = ids[i] - 1 gets its code (landmark, first
+// sighting / repeat of a first sighting) and its meta word (where the record is read and written) from the landmark's
+// state word; a repeat inside the call sees the state its first occurrence leaves behind.
+__device__ __forceinline__ void plan_obs(const int32_t* __restrict__ ids, const int32_t* __restrict__ lmstate, int m, int32_t* s_l,
+                                         int32_t* s_st, int32_t* s_ids, int32_t* s_meta, int32_t* s_first) {
+    const int tid = threadIdx.x;
+    if (tid < m) {
+        const int l = ids[tid] - 1;
+        s_l[tid] = l;
+        s_st[tid] = lmstate[l];
+    }
+    __syncthreads();
+    if (tid < m) {
+        const int l = s_l[tid];
+        int j0 = tid;
+        for (int j = 0; j < tid; ++j)
+            if (s_l[j] == l) { j0 = j; break; }
+        const int32_t st = s_st[tid];
+        const int tab = st & LS_TAB, rb = (st & LS_BUF) ? 1 : 0;
+        const int wb = tab ? (rb ^ 1) : rb;                  // behind a table the update goes to the OTHER buffer
+        const int32_t prior = tab | (rb ? META_RBUF : 0);
+        int32_t code, meta;
+        if (j0 == tid) {
+            code = l | ((st & LS_SEEN) ? 0 : NEW_FLAG);
+            meta = tab | (rb ? META_RBUF : 0) | (wb ? META_WBUF : 0);
+        } else {                                             // the first occurrence has made the landmark (buffer wb, identity)
+            code = l | ((st & LS_SEEN) ? 0 : FRESH_FLAG);
+            meta = (wb ? META_RBUF : 0) | (wb ? META_WBUF : 0);
+        }
+        s_ids[tid] = code;
+        s_meta[tid] = meta | (prior << META_PRIOR_SHIFT);
+        s_first[tid] = j0 == tid;
+    }
+    __syncthreads();
+}
+
+// six sums at once: one LDS exchange and one barrier pair for all of them (256 threads); the result reaches every thread
+__device__ __forceinline__ void block_reduce6(double (&v)[6], double (*sh6)[6]) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v[i] += __shfl_xor(v[i], off);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sh6[wave][i] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = sh6[0][i] + sh6[1][i] + sh6[2][i] + sh6[3][i];
+}
+
+// Runs in the workgroup whose arrival came last (all 256 threads).  s_l / s_st / s_first: this step's plan (LDS).
+template <typename T>
+__device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t* s_l, const int32_t* s_st, const int32_t* s_first) {
+    __shared__ double sh[4];
+    __shared__ double s_r6[4][6];
+    __shared__ double s_g[12];
+    __shared__ int s_tref[PF_TAB_MAX];
+    __shared__ int s_i[4];          // [0] identity landmarks, [1] outcome (0 none, 1 lazy resampling, 2 halt), [2] fresh table
+    const int tid = threadIdx.x;
+    PfCtl* ctl = a.ctl;
+    const int nblocks = (int)gridDim.x;
+    if (tid == 0) ctl->stamps[1] = wall_clock64();
+    // Every global load of the tail -- the table reference counts, this thread's landmark state words, its share of the
+    // partials -- is issued up front: the memory system is still draining the sweep's stores and a load takes microseconds
+    // to come back, so the tail pays that latency once, not once per phase.
+    const int my_tref = tid < PF_TAB_MAX ? ctl->tref[tid] : 0;
+    const int identity0 = ctl->identity;                      // landmarks without a table before this step
+    double q[4][7];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int b = tid + 256 * u;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) q[u][i] = b < nblocks ? ld_sc1(a.part + (size_t)b * 8 + i) : (i == 0 ? -__builtin_inf() : 0.0);
+    }
+    if (tid < PF_TAB_MAX) s_tref[tid] = my_tref;
+    if (tid == 0) s_i[0] = identity0;
+    __syncthreads();
+    if (tid == 0) ctl->stamps[6] = wall_clock64();
+    // ---- this step's state transitions (what pf_stage does on the host): one thread per observation; the state word
+    //      of every observed landmark is still in LDS from the plan ----
+    if (tid < a.m && s_first[tid]) {
+        const int32_t st = s_st[tid];
+        const int tab = st & LS_TAB, rb = (st & LS_BUF) ? 1 : 0;
+        if (tab) {
+            atomicSub(&s_tref[tab - 1], 1);
+            atomicAdd(&s_i[0], 1);                            // released its table: a landmark without one ("identity")
+        }
+        a.lmstate[s_l[tid]] = LS_SEEN | ((tab ? (rb ^ 1) : rb) ? LS_BUF : 0);
+    }
+    // ---- fold the write-through partials (the order of fold_partials); 1024 records per pass ----
+    double M = -__builtin_inf();
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    if (tid == 0) ctl->stamps[7] = wall_clock64();
+    for (int base = 0; base < nblocks; base += 1024) {
+        if (base > 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = base + tid + 256 * u;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) q[u][i] = b < nblocks ? ld_sc1(a.part + (size_t)b * 8 + i) : (i == 0 ? -__builtin_inf() : 0.0);
+            }
+        }
+        double m = fmax(fmax(q[0][0], q[1][0]), fmax(q[2][0], q[3][0]));
+        m = block_reduce(m, sh, true);
+        const double Mn = fmax(M, m);
+        const double fo = M == -__builtin_inf() ? 0.0 : exp(M - Mn);              // rescale what earlier passes summed
+        acc[0] *= fo; acc[1] *= fo * fo; acc[2] *= fo; acc[3] *= fo; acc[4] *= fo; acc[5] *= fo;
+        M = Mn;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double f = q[u][0] == -__builtin_inf() ? 0.0 : exp(q[u][0] - M);
+            acc[0] += q[u][1] * f;
+            acc[1] += q[u][2] * f * f;
+            acc[2] += q[u][3] * f; acc[3] += q[u][4] * f; acc[4] += q[u][5] * f; acc[5] += q[u][6] * f;
+        }
+    }
+    block_reduce6(acc, s_r6);
+    if (tid == 0) {
+        ctl->stamps[2] = wall_clock64();
+        double gM = M, gs1 = acc[0], gs2 = acc[1];
+        int err = 0;
+        if (a.world > 1) {
+            // all-gather of (max, sum, sum2) through the ranks' shared page: two parities (a rank is at most one
+            // step ahead of the slowest), the sequence number is written last
+            double* page = a.xchg + (size_t)(a.seq & 1) * a.world * 8;
+            double* mine = page + (size_t)a.rank * 8;
+            __hip_atomic_store(mine + 0, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(mine + 1, acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(mine + 2, acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // (no fence: a system-scope release is a write-back of this XCD's whole L2, which the sweep has just filled
+            //  with dirty landmark records; the three write-through stores are drained, then the sequence number goes out)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(mine + 3, (double)a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long t0 = wall_clock64();
+            for (int r = 0; r < a.world && !err; ++r) {
+                const double* slot = page + (size_t)r * 8;
+                while (__hip_atomic_load(slot + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (double)a.seq) {
+                    __builtin_amdgcn_s_sleep(20);
+                    if (wall_clock64() - t0 > 300000000ull) { err = 1; break; }      // 3 s at 100 MHz: a rank is gone
+                }
+            }
+            if (!err) {
+                gM = -__builtin_inf();
+                for (int r = 0; r < a.world; ++r)
+                    gM = fmax(gM, __hip_atomic_load(page + (size_t)r * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+                gs1 = gs2 = 0.0;
+                for (int r = 0; r < a.world; ++r) {                         // every rank folds the same table in rank order
+                    const double* slot = page + (size_t)r * 8;
+                    const double f = exp(__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - gM);
+                    gs1 += __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) * f;
+                    gs2 += __hip_atomic_load(slot + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) * f * f;
+                }
+            }
+        }
+        const double lg = log(gs1);
+        s_g[0] = gM; s_g[1] = gs1; s_g[2] = gs2;
+        s_g[3] = gM + lg;                                                   // the normalisation shift
+        s_g[4] = gs1 * gs1 / gs2;                                           // Neff
+        s_g[5] = (double)((T)gM - (T)(gM + lg));                            // the largest log-weight after the shift, as stored
+        const int want = err ? 1 : (a.force >= 0 ? a.force : (s_g[4] < a.neff_frac * (double)a.n_global ? 1 : 0));
+        s_i[1] = want ? ((a.lazy_ok && a.world == 1 && !err) ? 1 : 2) : 0;
+        s_i[2] = -1;
+        s_i[3] = err;
+    }
+    __syncthreads();
+    if (tid == 0) ctl->stamps[3] = wall_clock64();
+    if (tid == 0 && s_i[1] == 1) {
+        // lazy resampling: landmarks without a table share a fresh one (= the ancestor vector); live tables are composed
+        int count = 0, free_idx = -1;
+        for (int t = 0; t < PF_TAB_MAX; ++t) {
+            if (s_tref[t] > 0) ctl->tl_idx[count++] = t;
+            else if (free_idx < 0) free_idx = t;
+        }
+        if (s_i[0] > 0 && free_idx < 0) s_i[1] = 2;                         // no table left: the host resamples eagerly
+        else {
+            ctl->tl_count = count;
+            ctl->tl_fresh = s_i[0] > 0 ? free_idx : -1;
+            s_i[2] = s_i[0] > 0 ? free_idx : -1;
+            if (s_i[0] > 0) s_tref[free_idx] = s_i[0];
+        }
+    }
+    __syncthreads();
+    if (s_i[1] == 1 && s_i[2] >= 0)
+        for (int l = tid; l < a.nl; l += 256) {
+            const int32_t st = a.lmstate[l];
+            if ((st & LS_TAB) == 0) a.lmstate[l] = st | (s_i[2] + 1);
+        }
+    for (int t = tid; t < PF_TAB_MAX; t += 256) ctl->tref[t] = s_tref[t];
+    if (tid == 0) {
+        ctl->stamps[4] = wall_clock64();
+        const int outcome = s_i[1];
+        ctl->stats[0] = s_g[0]; ctl->stats[1] = s_g[1]; ctl->stats[2] = s_g[2];
+        // (weighted pose sums relative to the LOCAL maximum: shard-local, summed over the ranks by the caller)
+        ctl->stats[3] = acc[2]; ctl->stats[4] = acc[3]; ctl->stats[5] = acc[4]; ctl->stats[6] = acc[5];
+        ctl->stats[7] = s_g[4];
+        ctl->seq = a.seq;
+        ctl->shift_scan = s_g[3];
+        ctl->gmax_norm = s_g[5];
+        ctl->shift_next = outcome == 1 ? 0.0 : s_g[3];                      // a resampling leaves uniform weights behind
+        if (s_i[3]) ctl->error = 1;
+        ctl->identity = outcome == 1 ? 0 : s_i[0];                          // (a lazy resampling gives every landmark a table)
+        if (outcome == 1) {
+            ctl->u0 = resample_offset((uint32_t)ctl->nresamples, a.seed);
+            ctl->nresamples += 1;
+            ctl->pcur ^= 1;
+            ctl->tside ^= 1;
+            ctl->resample_seq = a.seq;
+        } else if (outcome == 2) {
+            ctl->halt_seq = a.seq;
+        }
+        __hip_atomic_store(&ctl->arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed
+        // what the host may read without synchronising
+        // Write-through system-scope stores, drained, then the sequence number: no fence (a system-scope release would
+        // write back this XCD's whole L2, which the sweep has just filled with dirty landmark records).
+        PfMirror* mir = a.mir;
+        __hip_atomic_store(&mir->neff, s_g[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mir->nresamples, (long long)ctl->nresamples, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (outcome == 1) __hip_atomic_store(&mir->resampled_seq, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (s_i[3]) __hip_atomic_store(&mir->error, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (outcome == 2) {
+            __hip_atomic_store(&mir->halt_seq, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __hip_atomic_store(&mir->done_seq, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        ctl->stamps[5] = wall_clock64();
+    }
+}
+
+template <typename T, bool PROPOSAL>
+__global__ __launch_bounds__(256) void pf_auto_step_kernel(PfAutoArgs a) {
+    PfCtl* ctl = a.ctl;
+    if (ctl->halt_seq != 0) return;                    // an earlier step waits for the host: the host replays this one
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->stamps[0] = wall_clock64();
+    __shared__ double s_obs[2 * PF_AUTO_MAXOBS];
+    __shared__ int32_t s_ids[PF_AUTO_MAXOBS], s_meta[PF_AUTO_MAXOBS], s_l[PF_AUTO_MAXOBS], s_st[PF_AUTO_MAXOBS], s_first[PF_AUTO_MAXOBS];
+    __shared__ int s_last;
+    const int m = a.m;
+    for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) s_obs[i] = a.z[i];
+    plan_obs(a.ids, a.lmstate, m, s_l, s_st, s_ids, s_meta, s_first);
+    const int pcur = ctl->pcur, tside = ctl->tside;
+    const T pend = (T)ctl->shift_next;
+    T* pose = (T*)(pcur ? a.pose1 : a.pose0);
+    const int32_t* tabs = tside ? a.tab1 : a.tab0;
+    const int64_t n = a.n;
+    const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = pi < n;
+    const int64_t p = valid ? pi : n - 1;              // idle lanes shadow the last particle, stores are masked
+    T x, y, phi, lw;
+    if (PROPOSAL)
+        proposal_core<T>(pose, (T*)a.lm0, (T*)a.lm1, tabs, (T*)a.logw, n, a.first, a.step, a.seed, (T)a.V, (T)a.G, (T)a.wheelbase, (T)a.a0,
+                         (T)a.a1, (T)a.a2, (T)a.dt, s_obs, s_ids, s_meta, m, (T)a.R00, (T)a.R10, (T)a.R01, (T)a.R11, pend, p, valid, x,
+                         y, phi, lw);
+    else
+        step_core<T, true>(pose, (T*)a.lm0, (T*)a.lm1, tabs, (T*)a.logw, n, a.first, a.step, a.seed, (T)a.V, (T)a.G, (T)a.wheelbase,
+                           (T)a.a0, (T)a.a1, (T)a.dt, s_obs, s_ids, s_meta, m, (T)a.R00, (T)a.R10, (T)a.R01, (T)a.R11, pend, p, valid, x,
+                           y, phi, lw);
+    block_weight_stats<T, true>(lw, x, y, phi, valid, 1, a.part);
+    if (threadIdx.x == 0) {
+        // the partials were stored write-through by this lane: drain them, then arrive
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = __hip_atomic_fetch_add(&ctl->arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (s_last) pf_auto_tail<T>(a, s_l, s_st, s_first);
+}
+
+// The cdf of the step that resamples (pf_scan1_kernel behind the control block's gate).
+template <typename T>
+__global__ __launch_bounds__(SCAN_BLOCK) void pf_auto_scan1_kernel(const T* __restrict__ logw, int64_t n, const PfCtl* __restrict__ ctl,
+                                                                    long long seq, double* __restrict__ cdf,
+                                                                    double* __restrict__ bsum) {
+    if (ctl->resample_seq != seq) return;
+    __shared__ double sh[SCAN_BLOCK];
+    const int64_t i = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    const T pend = (T)ctl->shift_scan;
+    const double gmax = ctl->gmax_norm;
+    sh[threadIdx.x] = i < n ? exp((double)(T)(logw[i] - pend) - gmax) : 0.0;
+    __syncthreads();
+    for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
+        const double v = threadIdx.x >= off ? sh[threadIdx.x - off] : 0.0;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (i < n) cdf[i] = sh[threadIdx.x];
+    if (threadIdx.x == SCAN_BLOCK - 1) bsum[blockIdx.x] = sh[threadIdx.x];
+}
+
+// Block offsets (pf_scan2_kernel's serial order, redone by every workgroup out of LDS), ancestors (pf_ancestor_kernel)
+// and the lazy apply (pf_lazy_apply_kernel) of the step that resamples, in one conditional launch.
+constexpr int AUTO_NB_MAX = 2048;            // scan blocks (of 1024 particles) the fused offsets support
+template <typename T>
+__global__ __launch_bounds__(256) void pf_auto_resample_kernel(T* pose0, T* pose1, int32_t* tab0, int32_t* tab1,
+                                                                T* __restrict__ logw, int64_t n, const PfCtl* __restrict__ ctl,
+                                                                long long seq, const double* __restrict__ cdf,
+                                                                const double* __restrict__ bsum, int nb,
+                                                                int32_t* __restrict__ anc_out, T lw_uniform) {
+    if (ctl->resample_seq != seq) return;
+    __shared__ double s_off[AUTO_NB_MAX + 1];
+    for (int i = threadIdx.x; i < nb; i += 256) s_off[i] = bsum[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double run = 0.0;
+        for (int i = 0; i < nb; ++i) {
+            const double v = s_off[i];
+            s_off[i] = run;
+            run += v;
+        }
+        s_off[nb] = run;
+    }
+    __syncthreads();
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const double total = s_off[nb];
+    const double target = ((double)p + ctl->u0) / (double)n * total;
+    // first j with cdf[j] + offset(block of j) >= target, in two levels: the block out of LDS (the last element of block b
+    // has exactly the value s_off[b + 1] = s_off[b] + bsum[b]), then ten steps inside it -- the same index as the plain
+    // binary search of pf_ancestor_kernel over all n
+    int bl = 0, bh = nb - 1;
+    while (bl < bh) {
+        const int bm = (bl + bh) >> 1;
+        if (s_off[bm + 1] >= target) bh = bm; else bl = bm + 1;
+    }
+    int64_t lo = (int64_t)bl * SCAN_BLOCK, hi = lo + SCAN_BLOCK - 1;
+    if (hi > n - 1) hi = n - 1;
+    const double boff = s_off[bl];
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (cdf[mid] + boff >= target) hi = mid; else lo = mid + 1;
+    }
+    const int32_t a = (int32_t)lo;
+    anc_out[p] = a;
+    // the tail has already flipped the buffers: the live ones are the destination
+    const int pnew = ctl->pcur, tnew = ctl->tside;
+    const T* pose_old = pnew ? pose0 : pose1;
+    T* pose_new = pnew ? pose1 : pose0;
+    const int32_t* tin = tnew ? tab0 : tab1;
+    int32_t* tout = tnew ? tab1 : tab0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) pose_new[(size_t)r * n + p] = pose_old[(size_t)r * n + a];
+    const int fresh = ctl->tl_fresh, count = ctl->tl_count;
+    if (fresh >= 0) tout[(size_t)fresh * n + p] = a;
+    for (int i = 0; i < count; ++i) {
+        const size_t t = (size_t)ctl->tl_idx[i];
+        tout[t * n + p] = tin[t * n + a];
+    }
+    logw[p] = lw_uniform;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pf_weights_kernel(const T* __restrict__ logw, int64_t n, T pend, double* __restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) out[p] = exp((double)(T)(logw[p] - pend));
+}
+
 template <typename P>
 int pf_alloc(P** p, size_t bytes, hipStream_t s) {
     *p = nullptr;
@@ -914,6 +1427,14 @@ inline int grid_for(int64_t n) { return (int)((n + 255) / 256); }
         }                              \
     } while (0)
 
+static int pf_auto_flush(slam_pf* h);      // wait for the steps slam_pf_step_auto has queued (resolving a halted one)
+static int pf_auto_leave(slam_pf* h);      // auto mode -> legacy mode: wait for the queue, bring the bookkeeping back to the host
+#define PF_LEGACY_ENTRY(h)                    \
+    do {                                      \
+        const int rc_leave_ = pf_auto_leave(h); \
+        if (rc_leave_) return rc_leave_;      \
+    } while (0)
+
 extern "C" int slam_pf_destroy(slam_pf_t h) {
     if (!h) return SLAM_OK;
     (void)hipSetDevice(h->device);
@@ -922,7 +1443,12 @@ extern "C" int slam_pf_destroy(slam_pf_t h) {
         if (h->pose[b]) (void)hipFree(h->pose[b]);
         if (h->lm[b]) (void)hipFree(h->lm[b]);
     }
-    void* devs[] = {h->logw, h->d_part, h->d_out, h->d_cdf, h->d_bsum, h->d_src, h->d_anc, h->d_tab[0], h->d_tab[1], h->d_lmeta};
+    void* devs[] = {h->logw, h->d_part, h->d_out, h->d_cdf, h->d_bsum, h->d_src, h->d_anc, h->d_tab[0], h->d_tab[1], h->d_lmeta,
+                    h->d_ctl, h->d_lmstate};
+    if (h->xchg_host) (void)hipHostUnregister(h->xchg_host);
+    if (h->h_mir) (void)hipHostFree(h->h_mir);
+    if (h->h_auto_obs) (void)hipHostFree(h->h_auto_obs);
+    if (h->h_auto_ids) (void)hipHostFree(h->h_auto_ids);
     for (void* p : devs)
         if (p) (void)hipFree(p);
     if (h->h_ids) (void)hipHostFree(h->h_ids);
@@ -968,6 +1494,16 @@ static int pf_create_impl(slam_pf* h) {
     HIP_TRY(hipHostGetDevicePointer((void**)&h->h_out_dev, h->h_out, 0));
     h->out_seq = 0;
     h->pending_shift = 0.0; h->has_pending = 0;
+    // auto mode
+    if ((rc = pf_alloc(&h->d_ctl, sizeof(PfCtl), h->stream))) return rc;
+    if ((rc = pf_alloc(&h->d_lmstate, sizeof(int32_t) * (size_t)h->nl, h->stream))) return rc;
+    HIP_TRY(hipHostMalloc((void**)&h->h_mir, sizeof(PfMirror), hipHostMallocDefault));
+    memset(h->h_mir, 0, sizeof(PfMirror));
+    HIP_TRY(hipHostGetDevicePointer((void**)&h->h_mir_dev, h->h_mir, 0));
+    HIP_TRY(hipHostMalloc((void**)&h->h_auto_obs, sizeof(double) * 2 * PF_AUTO_MAXOBS * PF_LOG, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&h->h_auto_ids, sizeof(int32_t) * PF_AUTO_MAXOBS * PF_LOG, hipHostMallocDefault));
+    HIP_TRY(hipHostGetDevicePointer((void**)&h->h_auto_obs_dev, h->h_auto_obs, 0));
+    HIP_TRY(hipHostGetDevicePointer((void**)&h->h_auto_ids_dev, h->h_auto_ids, 0));
     // uniform weights over the GLOBAL particle set
     const double lw = -log((double)h->n_global);
     PF_DISPATCH(h,
@@ -1008,6 +1544,11 @@ extern "C" int slam_pf_create(slam_pf_t* out, int dtype, int64_t n_local, int64_
     h->stage_ev[0] = h->stage_ev[1] = nullptr; h->stage_used[0] = h->stage_used[1] = 0; h->stage_slot = 0;
     h->d_part = h->d_out = h->h_out = h->d_cdf = h->d_bsum = nullptr; h->d_src = nullptr; h->d_anc = nullptr;
     h->seen.assign(max_landmarks, 0);
+    h->d_ctl = nullptr; h->d_lmstate = nullptr; h->h_mir = h->h_mir_dev = nullptr;
+    h->h_auto_obs = h->h_auto_obs_dev = nullptr; h->h_auto_ids = h->h_auto_ids_dev = nullptr;
+    h->auto_on = 0; h->auto_seq = 0; h->nresamples = 0; h->halted = 0; h->halt_gmax = 0.0; h->last_resampled_seq = 0;
+    h->d_xchg = nullptr; h->xchg_host = nullptr; h->xchg_rank = 0; h->xchg_world = 1;
+    for (int i = 0; i < 4; ++i) h->last_out[i] = 0.0;
     const int rc = pf_create_impl(h);
     if (rc) { slam_pf_destroy(h); return rc; }
     *out = h;
@@ -1109,6 +1650,7 @@ static int pf_resample_lazy(slam_pf* h, const int32_t* d_anc, int* done, bool fu
 extern "C" int slam_pf_set_pose(slam_pf_t h, const double pose[3]) {
     ARG_CHECK(h != nullptr && pose != nullptr, "null argument");
     HIP_TRY(hipSetDevice(h->device));
+    PF_LEGACY_ENTRY(h);
     h->has_pending = 0;                                // logw is overwritten: a deferred normalisation shift is moot
     h->pending_shift = 0.0;
     const double lw = -log((double)h->n_global);
@@ -1126,6 +1668,7 @@ extern "C" int slam_pf_init_landmarks(slam_pf_t h, const double* lm_xy, int nl, 
     ARG_CHECK(nl >= 0 && nl <= h->nl, "more landmarks than capacity");
     if (nl == 0) return SLAM_OK;
     HIP_TRY(hipSetDevice(h->device));
+    PF_LEGACY_ENTRY(h);
     { const int rcm = pf_materialise(h); if (rcm) return rcm; }
     double* d_xy = nullptr;
     HIP_TRY(hipMalloc((void**)&d_xy, sizeof(double) * 2 * nl));
@@ -1145,6 +1688,7 @@ extern "C" int slam_pf_init_landmarks(slam_pf_t h, const double* lm_xy, int nl, 
 extern "C" int slam_pf_predict(slam_pf_t h, double V, double G, double wheelbase, const double Q[4], double dt) {
     ARG_CHECK(h != nullptr && Q != nullptr, "null argument");
     HIP_TRY(hipSetDevice(h->device));
+    PF_LEGACY_ENTRY(h);
     const double sV = sqrt(Q[0]), sG = sqrt(Q[3]);
     PF_DISPATCH(h,
                 hipLaunchKernelGGL(pf_predict_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->pose[h->pcur],
@@ -1239,6 +1783,7 @@ extern "C" int slam_pf_update_known(slam_pf_t h, const double* z, const int32_t*
     int rc = pf_check_obs(h, z, ids, m, R);
     if (rc || m == 0) return rc;
     HIP_TRY(hipSetDevice(h->device));
+    PF_LEGACY_ENTRY(h);
     const double* dz;
     const int32_t* di;
     if ((rc = pf_stage(h, z, ids, m, &dz, &di))) return rc;
@@ -1293,6 +1838,7 @@ extern "C" int slam_pf_step(slam_pf_t h, double V, double G, double wheelbase, c
     if (rc) return rc;
     if (m) for (int i = 0; i < 4; ++i) Rz[i] = R[i];
     HIP_TRY(hipSetDevice(h->device));
+    PF_LEGACY_ENTRY(h);
     const double* dz = h->h_obs_dev;
     const int32_t* di = h->h_ids_dev;
     if (m && (rc = pf_stage(h, z, ids, m, &dz, &di))) return rc;
@@ -1331,6 +1877,7 @@ extern "C" int slam_pf_step_proposal(slam_pf_t h, double V, double G, double whe
     ARG_CHECK(Q[3] - lq10 * lq10 > 0.0, "Q is not positive definite");
     const double lq11 = sqrt(Q[3] - lq10 * lq10);
     HIP_TRY(hipSetDevice(h->device));
+    PF_LEGACY_ENTRY(h);
     const double* dz = h->h_obs_dev;
     const int32_t* di = h->h_ids_dev;
     if (m && (rc = pf_stage(h, z, ids, m, &dz, &di))) return rc;
@@ -1357,6 +1904,7 @@ extern "C" int slam_pf_step_proposal(slam_pf_t h, double V, double G, double whe
 extern "C" int slam_pf_clear_landmarks(slam_pf_t h) {
     ARG_CHECK(h != nullptr, "null handle");
     HIP_TRY(hipSetDevice(h->device));
+    PF_LEGACY_ENTRY(h);
     PF_DISPATCH(h,
                 hipLaunchKernelGGL(pf_clear_lm_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->lm[h->cur], h->n, h->nl),
                 hipLaunchKernelGGL(pf_clear_lm_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->lm[h->cur], h->n, h->nl));
@@ -1381,6 +1929,7 @@ extern "C" int slam_pf_update_unknown(slam_pf_t h, const double* z, int m, const
     if (m == 0) return SLAM_OK;
     ARG_CHECK(z != nullptr && R != nullptr, "null argument");
     HIP_TRY(hipSetDevice(h->device));
+    PF_LEGACY_ENTRY(h);
     { const int rcm = pf_materialise(h); if (rcm) return rcm; }
     const double* dz;
     const int32_t* di;
@@ -1415,6 +1964,7 @@ extern "C" int slam_pf_step_normalized(slam_pf_t h, double V, double G, double w
 // with w = exp(logw - shift), shift = local max if relative_to_max else 0.
 static int pf_stats(slam_pf* h, int relative_to_max, double out[7]) {
     HIP_TRY(hipSetDevice(h->device));
+    PF_LEGACY_ENTRY(h);
     { const int rcf = pf_flush_pending(h); if (rcf) return rcf; }
     PF_DISPATCH(h,
                 hipLaunchKernelGGL(pf_stats_kernel<T>, dim3(h->red_blocks), dim3(256), 0, h->stream, (const T*)h->logw,
@@ -1447,6 +1997,7 @@ extern "C" int slam_pf_normalize(slam_pf_t h, double gmax, double gsum) {
     ARG_CHECK(h != nullptr, "null handle");
     ARG_CHECK(gsum > 0.0, "gsum must be positive");
     HIP_TRY(hipSetDevice(h->device));
+    PF_LEGACY_ENTRY(h);
     const double shift = gmax + log(gsum);
     const int rc = pf_flush_pending(h);          // (two normalisations in a row: the first shift is applied on its own)
     if (rc) return rc;
@@ -1458,6 +2009,7 @@ extern "C" int slam_pf_normalize(slam_pf_t h, double gmax, double gsum) {
 extern "C" int slam_pf_copy_logw(slam_pf_t h, void* d_dst) {
     ARG_CHECK(h != nullptr && d_dst != nullptr, "null argument");
     HIP_TRY(hipSetDevice(h->device));
+    PF_LEGACY_ENTRY(h);
     { const int rcf = pf_flush_pending(h); if (rcf) return rcf; }
     HIP_TRY(hipMemcpyAsync(d_dst, h->logw, h->esz * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1469,6 +2021,7 @@ static int pf_ancestors_impl(slam_pf_t h, const void* d_logw_all, double gmax, d
     ARG_CHECK(h != nullptr && d_logw_all != nullptr && d_anc != nullptr, "null argument");
     ARG_CHECK(u0 >= 0.0 && u0 < 1.0, "u0 must be in [0, 1)");
     HIP_TRY(hipSetDevice(h->device));
+    PF_LEGACY_ENTRY(h);
     const int nb = (int)((h->n_global + SCAN_BLOCK - 1) / SCAN_BLOCK);
     PF_DISPATCH(h,
                 hipLaunchKernelGGL(pf_scan1_kernel<T>, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, (const T*)d_logw_all,
@@ -1505,6 +2058,7 @@ extern "C" int slam_pf_resample_local(slam_pf_t h, double gmax, double u0) {
     ARG_CHECK(h->n == h->n_global, "slam_pf_resample_local needs the whole filter on this shard");
     ARG_CHECK(u0 >= 0.0 && u0 < 1.0, "u0 must be in [0, 1)");
     HIP_TRY(hipSetDevice(h->device));
+    PF_LEGACY_ENTRY(h);
     const double pend = pf_take_pending(h);
     const int nb = (int)((h->n_global + SCAN_BLOCK - 1) / SCAN_BLOCK);
     PF_DISPATCH(h,
@@ -1538,6 +2092,7 @@ extern "C" int slam_pf_pack(slam_pf_t h, const int32_t* d_local_idx, int cnt, vo
     if (cnt == 0) return SLAM_OK;
     ARG_CHECK(d_local_idx != nullptr && d_records != nullptr, "null argument");
     HIP_TRY(hipSetDevice(h->device));
+    PF_LEGACY_ENTRY(h);
     { const int rcm = pf_materialise(h); if (rcm) return rcm; }
     const dim3 grid((cnt + 255) / 256, 3 + 5 * h->nl);
     PF_DISPATCH(h,
@@ -1556,6 +2111,7 @@ extern "C" int slam_pf_resample_apply(slam_pf_t h, const int32_t* d_anc, const i
     ARG_CHECK(nremote >= 0, "nremote < 0");
     ARG_CHECK(nremote == 0 || (d_remote_ids != nullptr && d_remote_records != nullptr), "remote buffers missing");
     HIP_TRY(hipSetDevice(h->device));
+    PF_LEGACY_ENTRY(h);
     const double lw = -log((double)h->n_global);      // uniform weights again
     if (nremote == 0 && h->n == h->n_global && !h->lazy_off) {
         // the whole filter is here: permute the poses, compose the ancestor tables, leave the maps where they are
@@ -1600,6 +2156,7 @@ extern "C" int slam_pf_resample_apply(slam_pf_t h, const int32_t* d_anc, const i
 extern "C" int slam_pf_download(slam_pf_t h, void* pose, void* logw, void* lm) {
     ARG_CHECK(h != nullptr, "null handle");
     HIP_TRY(hipSetDevice(h->device));
+    PF_LEGACY_ENTRY(h);
     const size_t n = (size_t)h->n;
     { const int rcf = pf_flush_pending(h); if (rcf) return rcf; }
     if (lm) { const int rcm = pf_materialise(h); if (rcm) return rcm; }
@@ -1613,6 +2170,10 @@ extern "C" int slam_pf_download(slam_pf_t h, void* pose, void* logw, void* lm) {
 extern "C" int slam_pf_sync(slam_pf_t h) {
     ARG_CHECK(h != nullptr, "null handle");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->auto_on) {                          // (steps queued by slam_pf_step_auto: a halted one is resolved on the way)
+        const int rc = pf_auto_flush(h);
+        if (rc) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(h->stream));
     return SLAM_OK;
 }
@@ -1620,5 +2181,395 @@ extern "C" int slam_pf_sync(slam_pf_t h) {
 extern "C" int slam_pf_stream(slam_pf_t h, void** stream) {
     ARG_CHECK(h != nullptr && stream != nullptr, "null argument");
     *stream = (void*)h->stream;
+    return SLAM_OK;
+}
+
+// ---- auto mode: host side -------------------------------------------------------------------------------------------
+static int pf_auto_nb(const slam_pf* h) { return (int)((h->n_global + SCAN_BLOCK - 1) / SCAN_BLOCK); }
+
+static bool pf_auto_lazy_ok(const slam_pf* h) {
+    return h->n == h->n_global && !h->lazy_off && h->xchg_world <= 1 && pf_auto_nb(h) <= AUTO_NB_MAX;
+}
+
+// legacy mode -> auto mode: the host's bookkeeping becomes the device's
+static int pf_auto_enter(slam_pf* h) {
+    if (h->auto_on) return SLAM_OK;
+    std::vector<int32_t> st(h->nl);
+    for (int l = 0; l < h->nl; ++l)
+        st[l] = (h->ltab[l] >= 0 ? h->ltab[l] + 1 : 0) | (h->lbuf[l] ? LS_BUF : 0) | (h->seen[l] ? LS_SEEN : 0);
+    PfCtl c;
+    memset(&c, 0, sizeof(c));
+    c.shift_next = pf_take_pending(h);
+    c.nresamples = (int32_t)h->nresamples;
+    c.pcur = h->pcur;
+    c.tside = h->tside;
+    c.seq = h->auto_seq;
+    for (int t = 0; t < PF_TAB_MAX; ++t) c.tref[t] = h->tref[t];
+    for (int l = 0; l < h->nl; ++l) c.identity += h->ltab[l] < 0;
+    HIP_TRY(hipMemcpyAsync(h->d_lmstate, st.data(), sizeof(int32_t) * h->nl, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_ctl, &c, sizeof(c), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));              // (pageable sources)
+    const PfMirror keep = *h->h_mir;                        // (Neff and the statistics of the last confirmed step stay readable)
+    memset(h->h_mir, 0, sizeof(PfMirror));
+    h->h_mir->neff = keep.neff;
+    for (int i = 0; i < 8; ++i) h->h_mir->stats[i] = keep.stats[i];
+    h->h_mir->done_seq = h->log.empty() ? h->auto_seq : h->log.front().seq - 1;      // (a replay: the logged steps are still to come)
+    h->h_mir->nresamples = h->nresamples;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    h->auto_on = 1;
+    return SLAM_OK;
+}
+
+// bring the device's bookkeeping back (the stream must be idle)
+static int pf_auto_import(slam_pf* h, bool halted) {
+    PfCtl c;
+    std::vector<int32_t> st(h->nl);
+    HIP_TRY(hipMemcpy(&c, h->d_ctl, sizeof(c), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(st.data(), h->d_lmstate, sizeof(int32_t) * h->nl, hipMemcpyDeviceToHost));
+    h->lazy_dirty = 0;
+    for (int l = 0; l < h->nl; ++l) {
+        h->ltab[l] = (int16_t)((st[l] & LS_TAB) - 1);
+        h->lbuf[l] = (int8_t)((st[l] & LS_BUF) ? 1 : 0);
+        h->seen[l] = (st[l] & LS_SEEN) ? 1 : 0;
+        if (h->ltab[l] >= 0 || h->lbuf[l] != h->cur) h->lazy_dirty = 1;
+    }
+    for (int t = 0; t < PF_TAB_MAX; ++t) h->tref[t] = c.tref[t];
+    h->pcur = c.pcur;
+    h->tside = c.tside;
+    h->nresamples = c.nresamples;
+    // a halted step has stored its weights but not yet normalised them: its shift is the pending one
+    const double shift = halted ? c.shift_scan : c.shift_next;
+    h->pending_shift = shift;
+    h->has_pending = shift != 0.0;
+    h->halt_gmax = c.gmax_norm;
+    h->auto_on = 0;
+    if (c.error) {
+        slam_set_error("the scalar exchange between the ranks of the sharded filter timed out (a rank is gone)");
+        return SLAM_E_HIP;
+    }
+    return SLAM_OK;
+}
+
+static int pf_auto_enqueue(slam_pf* h, const PfStepRec& r) {
+    const int slot = (int)(r.seq % PF_LOG);
+    double* hz = h->h_auto_obs + (size_t)slot * 2 * PF_AUTO_MAXOBS;
+    int32_t* hi = h->h_auto_ids + (size_t)slot * PF_AUTO_MAXOBS;
+    for (int i = 0; i < r.m; ++i) { hz[2 * i] = r.z[2 * i]; hz[2 * i + 1] = r.z[2 * i + 1]; hi[i] = r.ids[i]; }
+    PfAutoArgs a;
+    memset(&a, 0, sizeof(a));
+    a.pose0 = h->pose[0]; a.pose1 = h->pose[1]; a.lm0 = h->lm[0]; a.lm1 = h->lm[1]; a.logw = h->logw;
+    a.tab0 = h->d_tab[0]; a.tab1 = h->d_tab[1];
+    a.n = h->n; a.first = h->first; a.n_global = h->n_global; a.seq = r.seq;
+    a.seed = h->seed; a.step = r.rng_step;
+    a.m = r.m; a.nl = h->nl; a.force = r.force; a.lazy_ok = pf_auto_lazy_ok(h) ? 1 : 0;
+    a.rank = h->xchg_rank; a.world = h->xchg_world;
+    a.V = r.V; a.G = r.G; a.wheelbase = r.wheelbase; a.dt = r.dt;
+    if (r.proposal) {
+        const double lq00 = sqrt(r.Q[0]), lq10 = 0.5 * (r.Q[1] + r.Q[2]) / lq00;
+        a.a0 = lq00; a.a1 = lq10; a.a2 = sqrt(r.Q[3] - lq10 * lq10);
+    } else {
+        a.a0 = sqrt(r.Q[0]); a.a1 = sqrt(r.Q[3]);
+    }
+    a.R00 = r.R[0]; a.R10 = r.R[1]; a.R01 = r.R[2]; a.R11 = r.R[3];
+    a.neff_frac = r.neff_frac;
+    a.z = h->h_auto_obs_dev + (size_t)slot * 2 * PF_AUTO_MAXOBS;
+    a.ids = h->h_auto_ids_dev + (size_t)slot * PF_AUTO_MAXOBS;
+    a.part = h->d_part; a.ctl = h->d_ctl; a.lmstate = h->d_lmstate; a.mir = h->h_mir_dev; a.xchg = h->d_xchg;
+    const dim3 grid(grid_for(h->n));
+    if (h->dtype == SLAM_F32) {
+        if (r.proposal) hipLaunchKernelGGL((pf_auto_step_kernel<float, true>), grid, dim3(256), 0, h->stream, a);
+        else hipLaunchKernelGGL((pf_auto_step_kernel<float, false>), grid, dim3(256), 0, h->stream, a);
+    } else {
+        if (r.proposal) hipLaunchKernelGGL((pf_auto_step_kernel<double, true>), grid, dim3(256), 0, h->stream, a);
+        else hipLaunchKernelGGL((pf_auto_step_kernel<double, false>), grid, dim3(256), 0, h->stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    if (a.lazy_ok && r.force != 0) {                        // (force == 0: this step never resamples, nothing to gate)
+        const int nb = pf_auto_nb(h);
+        const double lw = -log((double)h->n_global);
+        PF_DISPATCH(h,
+                    hipLaunchKernelGGL(pf_auto_scan1_kernel<T>, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, (const T*)h->logw, h->n_global,
+                                       (const PfCtl*)h->d_ctl, r.seq, h->d_cdf, h->d_bsum),
+                    hipLaunchKernelGGL(pf_auto_scan1_kernel<T>, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, (const T*)h->logw, h->n_global,
+                                       (const PfCtl*)h->d_ctl, r.seq, h->d_cdf, h->d_bsum));
+        PF_DISPATCH(h,
+                    hipLaunchKernelGGL(pf_auto_resample_kernel<T>, grid, dim3(256), 0, h->stream, (T*)h->pose[0], (T*)h->pose[1],
+                                       h->d_tab[0], h->d_tab[1], (T*)h->logw, h->n, (const PfCtl*)h->d_ctl, r.seq,
+                                       (const double*)h->d_cdf, (const double*)h->d_bsum, nb, h->d_anc, (T)lw),
+                    hipLaunchKernelGGL(pf_auto_resample_kernel<T>, grid, dim3(256), 0, h->stream, (T*)h->pose[0], (T*)h->pose[1],
+                                       h->d_tab[0], h->d_tab[1], (T*)h->logw, h->n, (const PfCtl*)h->d_ctl, r.seq,
+                                       (const double*)h->d_cdf, (const double*)h->d_bsum, nb, h->d_anc, (T)lw));
+        HIP_TRY(hipGetLastError());
+    }
+    return SLAM_OK;
+}
+
+// wait (polling the pinned mirror) until step `target` is confirmed or a step has halted
+static int pf_auto_wait(slam_pf* h, long long target) {
+    volatile long long* done = &h->h_mir->done_seq;
+    volatile long long* halt = &h->h_mir->halt_seq;
+    unsigned long long spins = 0;
+    while (*done < target && *halt == 0) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xfffffull) == 0) {                // a failed kernel must not leave the host spinning
+            const hipError_t q = hipStreamQuery(h->stream);
+            if (q != hipErrorNotReady && *done < target && *halt == 0) {
+                slam_set_error("auto mode: step %lld was not confirmed: %s", target,
+                               q == hipSuccess ? "the stream is idle" : hipGetErrorString(q));
+                return SLAM_E_HIP;
+            }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return SLAM_OK;
+}
+
+static void pf_auto_trim(slam_pf* h) {
+    const long long done = h->h_mir->done_seq;
+    size_t k = 0;
+    while (k < h->log.size() && h->log[k].seq <= done) ++k;
+    if (k) h->log.erase(h->log.begin(), h->log.begin() + k);
+}
+
+static int pf_auto_replay(slam_pf* h) {
+    int rc = pf_auto_enter(h);
+    if (rc) return rc;
+    for (const PfStepRec& r : h->log)
+        if ((rc = pf_auto_enqueue(h, r))) return rc;
+    return SLAM_OK;
+}
+
+// A step has halted: its sweep is done, its resampling is not, everything queued behind it was skipped.  Returns
+// SLAM_PF_HALTED when the caller has to resample (sharded filter); a filter that lives on this shard resamples here
+// (the legacy path: lazy if a table is free, else the eager gather) and the skipped steps are enqueued again.
+static int pf_auto_handle_halt(slam_pf* h) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const long long s = h->h_mir->halt_seq;
+    h->h_mir->done_seq = s;                                // (it is: the halting tail publishes both)
+    pf_auto_trim(h);
+    int rc = pf_auto_import(h, true);
+    if (rc) return rc;
+    h->last_resampled_seq = s;
+    if (h->n != h->n_global) {
+        h->halted = 1;
+        return SLAM_PF_HALTED;
+    }
+    const double u0 = resample_offset((uint32_t)h->nresamples, h->seed);
+    if ((rc = slam_pf_resample_local(h, h->halt_gmax, u0))) return rc;
+    h->nresamples += 1;
+    return pf_auto_replay(h);
+}
+
+static int pf_auto_flush(slam_pf* h) {
+    while (h->auto_on) {
+        int rc = pf_auto_wait(h, h->auto_seq);
+        if (rc) return rc;
+        if (h->h_mir->halt_seq != 0) {
+            if ((rc = pf_auto_handle_halt(h))) return rc;
+            continue;
+        }
+        break;
+    }
+    if (h->auto_on) {
+        pf_auto_trim(h);
+        h->nresamples = h->h_mir->nresamples;
+        if (h->h_mir->resampled_seq > h->last_resampled_seq) h->last_resampled_seq = h->h_mir->resampled_seq;
+        h->last_out[0] = h->h_mir->neff;
+        h->last_out[1] = h->last_resampled_seq == h->auto_seq ? 1.0 : 0.0;
+        h->last_out[2] = (double)h->nresamples;
+        h->last_out[3] = (double)h->auto_seq;
+        if (h->h_mir->error) {
+            slam_set_error("the scalar exchange between the ranks of the sharded filter timed out (a rank is gone)");
+            return SLAM_E_HIP;
+        }
+    }
+    return SLAM_OK;
+}
+
+static int pf_auto_leave(slam_pf* h) {
+    if (!h->auto_on) return SLAM_OK;
+    int rc = pf_auto_flush(h);
+    if (rc) return rc;
+    if (!h->auto_on) return SLAM_OK;                       // (a halt was handled on the way and left us in legacy mode)
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return pf_auto_import(h, false);
+}
+
+/* One filter step with NO answer needed from the host: predict (or the FastSLAM-2.0 proposal), the m <= 64 known-id
+ * updates, the weight statistics, the normalisation, Neff, the decision to resample (force < 0: Neff < neff_frac *
+ * n_global; 0 / 1: never / always) and -- for a filter that lives wholly on this shard -- the (lazy) resampling itself,
+ * all on the device and all enqueued: the call returns at once and steps queue back to back.  Same particles as
+ * slam_pf_step + slam_pf_normalize + slam_pf_resample_local.  Returns SLAM_PF_HALTED (1, nothing was enqueued by THIS
+ * call) when an earlier step of a SHARDED filter decided to resample: the caller exchanges the weights and the
+ * migrating records with the legacy entry points, calls slam_pf_resume and repeats the call. */
+extern "C" int slam_pf_step_auto(slam_pf_t h, double V, double G, double wheelbase, const double Q[4], double dt, const double* z,
+                                 const int32_t* ids, int m, const double R[4], double neff_frac, int force, int proposal) {
+    ARG_CHECK(h != nullptr && Q != nullptr, "null argument");
+    ARG_CHECK(m >= 0 && m <= PF_AUTO_MAXOBS, "slam_pf_step_auto takes at most 64 observations per call");
+    ARG_CHECK(m == 0 || (z != nullptr && ids != nullptr && R != nullptr), "null argument");
+    for (int i = 0; i < m; ++i) ARG_CHECK(ids[i] >= 1 && ids[i] <= h->nl, "landmark id out of range");
+    ARG_CHECK(!h->halted, "a halted step is waiting for slam_pf_resume");
+    if (proposal) {
+        ARG_CHECK(Q[0] > 0.0, "Q is not positive definite");
+        const double lq10 = 0.5 * (Q[1] + Q[2]) / sqrt(Q[0]);
+        ARG_CHECK(Q[3] - lq10 * lq10 > 0.0, "Q is not positive definite");
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    int rc;
+    if (!h->auto_on && (rc = pf_auto_enter(h))) return rc;
+    if (h->h_mir->halt_seq != 0 && (rc = pf_auto_handle_halt(h))) return rc;
+    pf_auto_trim(h);
+    while ((int)h->log.size() >= PF_LOG - 1) {             // the host is a whole log ahead: wait for the oldest step
+        if ((rc = pf_auto_wait(h, h->log.front().seq))) return rc;
+        if (h->h_mir->halt_seq != 0 && (rc = pf_auto_handle_halt(h))) return rc;
+        pf_auto_trim(h);
+    }
+    PfStepRec r;
+    memset(&r, 0, sizeof(r));
+    r.seq = ++h->auto_seq;
+    r.rng_step = h->step++;
+    r.m = m; r.force = force; r.proposal = proposal ? 1 : 0;
+    r.V = V; r.G = G; r.wheelbase = wheelbase; r.dt = dt; r.neff_frac = neff_frac;
+    for (int i = 0; i < 4; ++i) { r.Q[i] = Q[i]; r.R[i] = m ? R[i] : 0.0; }
+    for (int i = 0; i < m; ++i) { r.z[2 * i] = z[2 * i]; r.z[2 * i + 1] = z[2 * i + 1]; r.ids[i] = ids[i]; }
+    h->log.push_back(r);
+    return pf_auto_enqueue(h, h->log.back());
+}
+
+/* Wait for everything slam_pf_step_auto has queued.  out (may be NULL) = {Neff of the last step, 1 if it resampled,
+ * resamplings so far, steps so far}.  SLAM_PF_HALTED as for slam_pf_step_auto. */
+extern "C" int slam_pf_flush(slam_pf_t h, double out[4]) {
+    ARG_CHECK(h != nullptr, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->halted) return SLAM_PF_HALTED;
+    const int rc = pf_auto_flush(h);
+    if (rc) return rc;
+    if (!h->auto_on) HIP_TRY(hipStreamSynchronize(h->stream));
+    if (out) for (int i = 0; i < 4; ++i) out[i] = h->last_out[i];
+    return SLAM_OK;
+}
+
+/* After SLAM_PF_HALTED and the caller's resampling (slam_pf_copy_logw ... slam_pf_resample_apply): the skipped steps are
+ * enqueued again.  `resamplings`: the caller's count after its resampling (the offset of the next one derives from it). */
+extern "C" int slam_pf_resume(slam_pf_t h, int64_t resamplings) {
+    ARG_CHECK(h != nullptr, "null handle");
+    ARG_CHECK(h->halted, "nothing is halted");
+    HIP_TRY(hipSetDevice(h->device));
+    h->halted = 0;
+    h->nresamples = resamplings;
+    return pf_auto_replay(h);
+}
+
+/* The halted step's numbers for the caller's resampling: out = {largest normalised log-weight, resamplings so far}. */
+extern "C" int slam_pf_halt_info(slam_pf_t h, double out[2]) {
+    ARG_CHECK(h != nullptr && out != nullptr, "null argument");
+    ARG_CHECK(h->halted, "nothing is halted");
+    out[0] = h->halt_gmax;
+    out[1] = (double)h->nresamples;
+    return SLAM_OK;
+}
+
+extern "C" int slam_pf_resample_count(slam_pf_t h, int64_t* count) {
+    ARG_CHECK(h != nullptr && count != nullptr, "null argument");
+    *count = h->auto_on ? (int64_t)h->h_mir->nresamples : (int64_t)h->nresamples;
+    return SLAM_OK;
+}
+
+extern "C" int slam_pf_set_resample_count(slam_pf_t h, int64_t count) {
+    ARG_CHECK(h != nullptr && count >= 0, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    PF_LEGACY_ENTRY(h);
+    h->nresamples = count;
+    return SLAM_OK;
+}
+
+/* The ranks' shared scalar page of a sharded filter: `page` is host memory that EVERY rank has mapped (one file in
+ * /dev/shm), at least 2 * world * 64 bytes, zero-filled before the first step.  It is registered with the HIP runtime
+ * here; the step kernel's last workgroup writes this rank's (max, sum w, sum w^2, step) into its slot and polls the
+ * others' -- the per-step all-gather of three scalars without a host in the loop. */
+extern "C" int slam_pf_attach_exchange(slam_pf_t h, int rank, int world, void* page, size_t bytes) {
+    ARG_CHECK(h != nullptr && page != nullptr, "null argument");
+    ARG_CHECK(world >= 1 && rank >= 0 && rank < world, "rank / world out of range");
+    ARG_CHECK(bytes >= (size_t)2 * world * 64, "the page is too small");
+    ARG_CHECK(h->n * world == h->n_global && h->first == (int64_t)rank * h->n, "ranks must own equal, contiguous slices in rank order");
+    HIP_TRY(hipSetDevice(h->device));
+    PF_LEGACY_ENTRY(h);
+    if (h->xchg_host) { (void)hipHostUnregister(h->xchg_host); h->xchg_host = nullptr; h->d_xchg = nullptr; }
+    HIP_TRY(hipHostRegister(page, bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+    h->xchg_host = page;
+    HIP_TRY(hipHostGetDevicePointer((void**)&h->d_xchg, page, 0));
+    h->xchg_rank = rank;
+    h->xchg_world = world;
+    return SLAM_OK;
+}
+
+/* normalise, and resample if Neff < neff_frac * n (filter wholly on this shard).  *resampled (may be NULL)
+ * tells whether it did.  The synchronous form of what slam_pf_step_auto decides on the device. */
+extern "C" int slam_pf_resample(slam_pf_t h, double neff_frac, int* resampled) {
+    ARG_CHECK(h != nullptr, "null handle");
+    ARG_CHECK(h->n == h->n_global, "slam_pf_resample needs the whole filter on this shard");
+    double s[7];
+    int rc = pf_stats(h, 1, s);
+    if (rc) return rc;
+    if ((rc = slam_pf_normalize(h, s[0], s[1]))) return rc;
+    const double neff = s[1] * s[1] / s[2];
+    const bool doit = neff < neff_frac * (double)h->n_global;
+    if (resampled) *resampled = doit ? 1 : 0;
+    if (!doit) return SLAM_OK;
+    const double lg = log(s[1]);
+    const double gmax = h->dtype == SLAM_F32 ? (double)((float)s[0] - (float)(s[0] + lg)) : s[0] - (s[0] + lg);
+    const double u0 = resample_offset((uint32_t)h->nresamples, h->seed);
+    if ((rc = slam_pf_resample_local(h, gmax, u0))) return rc;
+    h->nresamples += 1;
+    return SLAM_OK;
+}
+
+/* the weighted mean pose [x, y, phi] (phi = atan2 of the weighted sin / cos sums); filter wholly on this
+ * shard (a sharded filter adds slam_pf_mean_pose_sums over its ranks). */
+extern "C" int slam_pf_get_mean_pose(slam_pf_t h, double pose[3]) {
+    ARG_CHECK(h != nullptr && pose != nullptr, "null argument");
+    ARG_CHECK(h->n == h->n_global, "slam_pf_get_mean_pose needs the whole filter on this shard");
+    double s[7];
+    const int rc = pf_stats(h, 1, s);
+    if (rc) return rc;
+    pose[0] = s[3] / s[1];
+    pose[1] = s[4] / s[1];
+    pose[2] = atan2(s[5], s[6]);
+    return SLAM_OK;
+}
+
+/* the weights w = exp(logw) of the local particles (double, n_local values; normalised if the filter is). */
+extern "C" int slam_pf_get_weights(slam_pf_t h, double* w) {
+    ARG_CHECK(h != nullptr && w != nullptr, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    PF_LEGACY_ENTRY(h);
+    { const int rcf = pf_flush_pending(h); if (rcf) return rcf; }
+    double* d_w = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_w, sizeof(double) * (size_t)h->n));
+    PF_DISPATCH(h,
+                hipLaunchKernelGGL(pf_weights_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (const T*)h->logw, h->n, (T)0, d_w),
+                hipLaunchKernelGGL(pf_weights_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (const T*)h->logw, h->n, (T)0, d_w));
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(w, d_w, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_w);
+    if (e != hipSuccess) {
+        slam_set_error("HIP error in slam_pf_get_weights: %s", hipGetErrorString(e));
+        return SLAM_E_HIP;
+    }
+    return SLAM_OK;
+}
+
+/* Diagnostics: 100 MHz wall-clock stamps of the LAST auto step: [0] kernel start, [1] the last workgroup has arrived,
+ * [2] statistics folded, [3] decision taken, [4] bookkeeping done, [5] published.  Waits for the queue. */
+extern "C" int slam_pf_debug_stamps(slam_pf_t h, uint64_t out[8]) {
+    ARG_CHECK(h != nullptr && out != nullptr, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const int rc = pf_auto_flush(h);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    PfCtl c;
+    HIP_TRY(hipMemcpy(&c, h->d_ctl, sizeof(c), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; ++i) out[i] = c.stamps[i];
     return SLAM_OK;
 }

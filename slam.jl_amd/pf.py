@@ -27,10 +27,10 @@ import os
 
 import numpy as np
 
-from ._lib import SLAM_F32, SLAM_F64, check, lib
+from ._lib import SLAM_F32, SLAM_F64, SLAM_PF_HALTED, check, lib
 from .ekf import _obs, _small, _ptr
 
-__all__ = ["PFShard", "PFSlamState", "FastSLAM", "philox_uniform"]
+__all__ = ["PFShard", "PFSlamState", "FastSLAM", "philox_uniform", "small", "shared_page"]
 
 _M0, _M1, _W0, _W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
 STREAM_RESAMPLE = 2
@@ -46,6 +46,20 @@ def philox_uniform(step: int, stream: int, seed: int) -> float:
         c = [((p1 >> 32) ^ c[1] ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c[3] ^ k1) & 0xFFFFFFFF, p0 & 0xFFFFFFFF]
         k0, k1 = (k0 + _W0) & 0xFFFFFFFF, (k1 + _W1) & 0xFFFFFFFF
     return ((c[0] >> 8) + 0.5) / 16777216.0
+
+
+class _Small:
+    """A 2 x 2 matrix already in the library's column-major double[4] form, with its pointer (see :func:`small`)."""
+    __slots__ = ("a", "ptr")
+
+    def __init__(self, M):
+        self.a = _small(M)
+        self.ptr = _ptr(self.a)
+
+
+def small(M):
+    """Convert a 2 x 2 matrix once for repeated ``step_auto`` calls."""
+    return M if isinstance(M, _Small) else _Small(M)
 
 
 class PFShard:
@@ -177,6 +191,87 @@ class PFShard:
     def mean_pose_sums(self):
         out = np.empty(4)
         check(lib.slam_pf_mean_pose_sums(self._h, _ptr(out)))
+        return out
+
+    # -- the step without the host in the loop (slam_pf_step_auto) -----------------------------------
+    @staticmethod
+    def prepare_obs(z, ids):
+        """Observations in the layout the library takes, converted once, with their ctypes pointers (a timed loop calls
+        step_auto with these: a step is then one foreign call)."""
+        zp = _obs(z)
+        idv = np.ascontiguousarray(np.asarray(ids, dtype=np.int32).reshape(-1))
+        if idv.shape[0] != zp.shape[0]:
+            raise ValueError("ids and z disagree on the number of observations")
+        return zp, idv, _ptr(zp), _ptr(idv, C.c_int32)
+
+    def step_auto(self, V, G, wheelbase, Q, dt, z, ids, R, neff_frac=0.75, force=None, proposal=False, prepared=None):
+        """One whole filter step ENQUEUED (slam_pf_step_auto): statistics, normalisation, Neff, the decision to resample
+        and -- filter wholly on this shard -- the resampling itself stay on the device.  ``force``: None = Neff rule,
+        False / True = never / always.  Returns False, or True when the library reports SLAM_PF_HALTED (a queued step
+        of a sharded filter wants a resampling; nothing was enqueued by this call)."""
+        zp, _idv, pz, pi = prepared if prepared is not None else self.prepare_obs(z, ids)
+        pq = Q.ptr if isinstance(Q, _Small) else _ptr(_small(Q))
+        pr = R.ptr if isinstance(R, _Small) else _ptr(_small(R))
+        rc = lib.slam_pf_step_auto(self._h, V, G, wheelbase, pq, dt, pz, pi, zp.shape[0], pr, neff_frac,
+                                   -1 if force is None else int(bool(force)), 1 if proposal else 0)
+        if rc == SLAM_PF_HALTED:
+            return True
+        if rc:
+            check(rc)
+        return False
+
+    def flush(self):
+        """Wait for the queued steps: (Neff of the last step, it resampled?, resamplings so far, steps so far), or None
+        when the library reports SLAM_PF_HALTED."""
+        out = np.empty(4)
+        rc = lib.slam_pf_flush(self._h, _ptr(out))
+        if rc == SLAM_PF_HALTED:
+            return None
+        check(rc)
+        return float(out[0]), bool(out[1]), int(out[2]), int(out[3])
+
+    def debug_stamps(self):
+        """100 MHz stamps of the last auto step (slam_pf_debug_stamps), as microseconds since the kernel's start."""
+        out = (C.c_uint64 * 8)()
+        check(lib.slam_pf_debug_stamps(self._h, out))
+        return [(int(v) - int(out[0])) / 100.0 for v in out[:8]]
+
+    def halt_info(self):
+        out = np.empty(2)
+        check(lib.slam_pf_halt_info(self._h, _ptr(out)))
+        return float(out[0]), int(out[1])
+
+    def resume(self, resamplings):
+        check(lib.slam_pf_resume(self._h, int(resamplings)))
+
+    def resample_count(self):
+        out = C.c_int64()
+        check(lib.slam_pf_resample_count(self._h, C.byref(out)))
+        return int(out.value)
+
+    def set_resample_count(self, count):
+        check(lib.slam_pf_set_resample_count(self._h, int(count)))
+
+    def attach_exchange(self, rank, world, page):
+        """``page``: a float64 NumPy array over host memory that every rank has mapped (>= 2 * world * 8 values)."""
+        assert page.dtype == np.float64 and page.flags.c_contiguous and page.size >= 2 * world * 8
+        self._xchg_page = page                       # keeps the mapping alive
+        check(lib.slam_pf_attach_exchange(self._h, int(rank), int(world), C.c_void_p(page.ctypes.data), page.nbytes))
+
+    def resample_if_needed(self, neff_frac=0.75):
+        """slam_pf_resample: normalise and resample if Neff < neff_frac * n (filter wholly on this shard)."""
+        out = C.c_int()
+        check(lib.slam_pf_resample(self._h, float(neff_frac), C.byref(out)))
+        return bool(out.value)
+
+    def mean_pose(self):
+        out = np.empty(3)
+        check(lib.slam_pf_get_mean_pose(self._h, _ptr(out)))
+        return out
+
+    def weights(self):
+        out = np.empty(self.n)
+        check(lib.slam_pf_get_weights(self._h, _ptr(out)))
         return out
 
     # -- resampling pieces (torch tensors on this shard's device) ---------------------------------
@@ -435,14 +530,14 @@ class FastSLAM:
         if comm.world == 1 and not self.force_exchange and local is not None and self._gmax_norm is not None:
             local(self._gmax_norm, u0)                                  # the whole filter on one GPU: one library call
             self._gmax_norm = None
-            self.resamples += 1
+            self._count_resampling()
             return 0
         logw_all = comm.all_gather(sh.logw_tensor(), sh.n_global)      # the all-gather of log-weights
         gmax = self._gmax_norm if self._gmax_norm is not None else float(logw_all.max().item())
         self._gmax_norm = None
         if comm.world == 1 and not self.force_exchange:                 # every ancestor is local: nothing to exchange
             sh.resample_apply(sh.ancestors(logw_all, gmax, u0), None, None)
-            self.resamples += 1
+            self._count_resampling()
             return 0
         # Every rank computes the ancestor of EVERY slot from the same all-gathered weights, so each knows which of its
         # particles every other rank needs: no request round, ONE all-to-all of records.  The table is ascending
@@ -465,8 +560,15 @@ class FastSLAM:
         got = comm.all_to_all_v(rec.t().contiguous(), counts[0], counts[1])                 # [n_need, rows], ascending ids
         anc = anc_all[sh.first:sh.first + n].to(torch.int32).contiguous()
         sh.resample_apply(anc, need_ids.to(torch.int32), got.t().contiguous())
-        self.resamples += 1
+        self._count_resampling()
         return int(need_ids.numel())
+
+    def _count_resampling(self):
+        # the count is part of the filter state (it keys the systematic-resampling offset): the library's copy follows
+        self.resamples += 1
+        setter = getattr(self.shard, "set_resample_count", None)
+        if setter is not None:
+            setter(self.resamples)
 
     def step(self, V, G, wheelbase, Q, dt, z, ids, R, force_resample=None, proposal=False):
         """predict + known-id updates + normalise + (Neff-triggered) resample.  Returns (Neff, resampled?).
@@ -491,6 +593,35 @@ class FastSLAM:
             self.resample()
         return neff, bool(do)
 
+    # -- the same step without the host in the loop --------------------------------------------------------------------
+    def step_async(self, V, G, wheelbase, Q, dt, z, ids, R, force_resample=None, proposal=False, prepared=None):
+        """``step`` ENQUEUED (shard.step_auto): returns nothing; Neff and the resampling decision stay on the device,
+        steps queue back to back, ``flush()`` waits and reports.  On one rank the resampling itself happens on the
+        device too.  A sharded filter resamples through the host (all-gather of the log-weights + record exchange): the
+        library halts at such a step, skips what was queued behind it, and this method resolves the halt the moment
+        the library reports it -- resample(), resume (the skipped steps are enqueued again), carry on."""
+        self._gmax_norm = None
+        sh = self.shard
+        while sh.step_auto(V, G, wheelbase, Q, dt, z, ids, R, neff_frac=self.neff_frac, force=force_resample,
+                           proposal=proposal, prepared=prepared):
+            self._resolve_halt()
+
+    def flush(self):
+        """Wait for the steps queued by step_async.  Returns (Neff of the last step, it resampled?)."""
+        while True:
+            r = self.shard.flush()
+            if r is None:
+                self._resolve_halt()
+                continue
+            self.last_neff, did, self.resamples = r[0], r[1], r[2]
+            return self.last_neff, did
+
+    def _resolve_halt(self):
+        sh = self.shard
+        self._gmax_norm, self.resamples = sh.halt_info()
+        self.resample()                                   # the legacy path: collectives issued from here
+        sh.resume(self.resamples)
+
     def step_unknown(self, V, G, wheelbase, Q, dt, z, R, gate1, gate2, force_resample=None):
         """The filter step with UNKNOWN correspondences: predict, per-particle gated nearest-neighbour
         association + updates / new landmarks, normalise, (Neff-triggered) resample.  Returns (Neff, resampled?).
@@ -507,6 +638,22 @@ class FastSLAM:
     def mean_pose(self):
         s = self.comm.allreduce_sum(list(self.shard.mean_pose_sums()))
         return np.array([s[0], s[1], math.atan2(s[2], s[3])])       # weights are normalised: sums are means
+
+
+def shared_page(dist, rank, world, doubles):
+    """A zero-filled float64 page in /dev/shm that every rank of ONE node maps (the ranks' scalar page of a sharded
+    filter: slam_pf_attach_exchange).  The file is unlinked once every rank has mapped it."""
+    import uuid
+    name = [f"/dev/shm/slamhip-x-{uuid.uuid4().hex}" if rank == 0 else None]
+    dist.broadcast_object_list(name, src=0)
+    if rank == 0:
+        np.zeros(doubles, dtype=np.float64).tofile(name[0])
+    dist.barrier()
+    mem = np.memmap(name[0], dtype=np.float64, mode="r+", shape=(doubles,))
+    dist.barrier()
+    if rank == 0:
+        os.unlink(name[0])
+    return mem
 
 
 class PFSlamState(FastSLAM):
@@ -527,6 +674,8 @@ class PFSlamState(FastSLAM):
             per = n // world
             shard = PFShard(per, max_landmarks, seed, dtype=dtype, first=rank * per, n_global=n, device=device)
             comm = TorchComm(torch.device("cuda", int(device)))
+            if world > 1:                                # the per-step scalars of step_async travel GPU to GPU through this
+                shard.attach_exchange(rank, world, shared_page(dist, rank, world, 2 * world * 8))
         else:
             shard = PFShard(n, max_landmarks, seed, dtype=dtype, device=device)
             comm = None

@@ -542,3 +542,162 @@ def test_lazy_resampling_random_operation_sequences(pkg, monkeypatch, seed):
         assert np.array_equal(x, y)
     for g in f.values():
         g.shard.close()
+
+
+# ---- auto mode: the step without the host in the loop -----------------------------------------------------------------
+def _compare(a, b, what, exact_logw):
+    pa, wa, la = a.download()
+    pb, wb, lb = b.download()
+    assert np.array_equal(pa, pb), f"{what}: poses differ"
+    assert np.array_equal(la, lb), f"{what}: landmarks differ"
+    if exact_logw:
+        assert np.array_equal(wa, wb), f"{what}: log-weights differ"
+    else:                      # the shift is gmax + log(sum): the device's log and the host's may differ in the last bit
+        assert np.allclose(wa, wb, rtol=0, atol=4 * np.finfo(wa.dtype).eps * max(1.0, float(np.abs(wb).max()))), what
+
+
+@pytest.mark.parametrize("proposal", [False, True])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_auto_mode_equals_the_synchronous_driver(pkg, dtype, proposal):
+    """FastSLAM.step_async (slam_pf_step_auto: statistics, normalisation, Neff, the decision and the lazy resampling all on
+    the device, nothing read back per step) against FastSLAM.step (the host decides after every step): the same
+    particles, bit for bit, the same Neff, the same resampling steps -- with Neff-triggered and forced resamplings,
+    repeats and first sightings inside a call, and an empty observation list."""
+    n, nl, seed = 3000 + 37, 14, 91
+    lm = scene(nl, 17)
+    f = {}
+    for name in ("auto", "sync"):
+        sh = pkg.PFShard(n, nl, seed, dtype=dtype)
+        sh.set_pose([0.5, 1.5, -0.2])
+        sh.init_landmarks(lm[:9], 0.01, 0.1)                  # 10..14 are first seen later
+        f[name] = pkg.FastSLAM(sh, None, neff_frac=0.75)
+    rng = np.random.default_rng(6)
+    pose = np.array([0.5, 1.5, -0.2])
+    hist = []
+    for t in range(40):
+        pose = np.array([pose[0] + 0.6 * math.cos(pose[2]), pose[1] + 0.6 * math.sin(pose[2]), pose[2]])
+        if t == 17:
+            ids = np.zeros(0, dtype=np.int32)
+        else:
+            ids = np.array([1 + t % 9, 1 + (t + 4) % 9, 1 + t % 9, 10 + t % 5, 10 + t % 5, 3])
+        z = observe(lm, pose, ids, rng) if len(ids) else np.zeros((2, 0))
+        force = True if t % 7 == 3 else (False if t % 7 == 5 else None)
+        f["auto"].step_async(6.0, 0.01 * (t % 5), 4.0, Q, 0.1, z, ids, R, force_resample=force, proposal=proposal)
+        hist.append(f["sync"].step(6.0, 0.01 * (t % 5), 4.0, Q, 0.1, z, ids, R, force_resample=force, proposal=proposal))
+        if t in (4, 19, 39):                                  # read-backs at arbitrary places
+            neff, did = f["auto"].flush()
+            assert did == hist[-1][1], f"step {t}"
+            assert neff == pytest.approx(hist[-1][0], rel=1e-12 if dtype == "f64" else 1e-6)
+            assert f["auto"].resamples == f["sync"].resamples
+            _compare(f["auto"].shard, f["sync"].shard, f"step {t}", exact_logw=False)
+    assert f["sync"].resamples >= 8 and any(d for _, d in hist) and not all(d for _, d in hist)
+    assert f["auto"].shard.resample_count() == f["sync"].resamples
+    for g in f.values():
+        g.shard.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_auto_mode_with_an_exhausted_table_pool_and_legacy_calls_in_between(pkg, dtype):
+    """One observation per step over 100 landmarks with a resampling at every step needs more live ancestor tables than
+    the pool holds: the device then HALTS the step, the host resamples eagerly and re-enqueues what was queued behind
+    it (slam_pf_flush / the next slam_pf_step_auto do that by themselves on one shard).  Legacy entry points mixed in
+    (downloads, a separate update_known, a pack) wait for the queue and see the same filter."""
+    import torch
+    n, nl, seed = 1500 + 7, 100, 29
+    lm = scene(nl, 41)
+    f = {}
+    for name in ("auto", "sync"):
+        sh = pkg.PFShard(n, nl, seed, dtype=dtype)
+        sh.set_pose([0.0, 0.0, 0.2])
+        sh.init_landmarks(lm[:90], 0.01, 0.1)
+        f[name] = pkg.FastSLAM(sh, None)
+    rng = np.random.default_rng(42)
+    pose = np.array([0.0, 0.0, 0.2])
+    for t in range(110):
+        pose = np.array([pose[0] + 0.3 * math.cos(0.02 + pose[2]), pose[1] + 0.3 * math.sin(0.02 + pose[2]),
+                         pose[2] + 0.3 * math.sin(0.02) / 4.0])
+        ids = np.array([(7 * t) % 90 + 1]) if t < 80 else np.array([(3 * t) % 90 + 1, 91 + t % 10, (3 * t) % 90 + 1])
+        z = observe(lm, pose, ids, rng)
+        f["auto"].step_async(3.0, 0.02, 4.0, Q, 0.1, z, ids, R, force_resample=(t % 4 != 3))
+        f["sync"].step(3.0, 0.02, 4.0, Q, 0.1, z, ids, R, force_resample=(t % 4 != 3))
+        if t == 30:                                           # a separate legacy update in the middle of the queue
+            for g in f.values():
+                g.update_known(z, ids, R)
+        if t == 55:
+            idx = torch.arange(0, 64, dtype=torch.int32, device="cuda")
+            assert torch.equal(f["auto"].shard.pack(idx), f["sync"].shard.pack(idx))
+        if t % 20 == 19:
+            _compare(f["auto"].shard, f["sync"].shard, f"step {t}", exact_logw=False)
+    f["auto"].flush()
+    assert f["auto"].resamples == f["sync"].resamples
+    _compare(f["auto"].shard, f["sync"].shard, "end", exact_logw=False)
+    for g in f.values():
+        g.shard.close()
+
+
+def test_whole_filter_calls(pkg):
+    """SURVEY 8b's slam_pf_resample / slam_pf_get_mean_pose / slam_pf_get_weights against the driver's pieces."""
+    n, nl, seed = 4096, 6, 3
+    lm = scene(nl, 5)
+    a, b = pkg.PFShard(n, nl, seed, dtype="f64"), pkg.PFShard(n, nl, seed, dtype="f64")
+    drv = pkg.FastSLAM(b, None, neff_frac=0.6)
+    rng = np.random.default_rng(8)
+    pose = np.array([0.0, 0.0, 0.1])
+    for sh in (a, b):
+        sh.set_pose(pose)
+        sh.init_landmarks(lm, 0.01, 0.1)
+    did_any = False
+    for t in range(12):
+        pose = np.array([pose[0] + 0.5 * math.cos(pose[2]), pose[1] + 0.5 * math.sin(pose[2]), pose[2]])
+        ids = (np.arange(3) + 3 * t) % nl + 1
+        z = observe(lm, pose, ids, rng)
+        a.predict(5.0, 0.0, 4.0, Q, 0.1)
+        a.update_known(z, ids, R)
+        w = a.weights()
+        lw = a.download(landmarks=False)[1]
+        assert np.allclose(w, np.exp(lw), rtol=1e-14)
+        mp = a.mean_pose()
+        did = a.resample_if_needed(0.6)
+        _neff, did_b = drv.step(5.0, 0.0, 4.0, Q, 0.1, z, ids, R)
+        assert did == did_b
+        did_any = did_any or did
+        if not did:                                            # (after a resampling the weights are uniform again)
+            assert np.allclose(mp, drv.mean_pose(), rtol=1e-10, atol=1e-12)
+        assert a.weights().sum() == pytest.approx(1.0, rel=1e-12)
+    assert did_any
+    pa, wa, la = a.download()
+    pb, wb, lb = b.download()
+    assert np.array_equal(pa, pb) and np.array_equal(la, lb) and np.allclose(wa, wb, rtol=0, atol=1e-13)
+    a.close()
+    b.close()
+
+
+def test_auto_mode_two_ranks_on_one_card(pkg, tmp_path):
+    """The sharded auto mode rehearsed with two processes on ONE card (gloo for the resampling collectives): the ranks'
+    GPUs exchange their per-step scalars through the shared pinned page (device writes, device polls -- here both
+    'GPUs' are the same card), a resampling step halts, the hosts resample through the collectives, resume, and the
+    skipped steps are replayed.  The two shards together must equal the one-rank synchronous filter."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "auto2")
+    outs = {}
+    for world, mode, port in ((1, "sync", 29711), (2, "auto", 29712)):
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "pf_auto_worker.py"), f"{out}{mode}", mode],
+                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        logs = [p.communicate(timeout=500)[0] for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
+        parts = [np.load(f"{out}{mode}.rank{k}.npz") for k in range(world)]
+        outs[mode] = dict(pose=np.hstack([p["pose"] for p in parts]), lm=np.concatenate([p["lm"] for p in parts], axis=2),
+                          logw=np.concatenate([p["logw"] for p in parts]), resamples=int(parts[0]["resamples"]),
+                          neff=parts[0]["neff"])
+    a, s = outs["auto"], outs["sync"]
+    assert a["resamples"] == s["resamples"] >= 3
+    assert np.array_equal(a["pose"], s["pose"]) and np.array_equal(a["lm"], s["lm"])
+    assert np.allclose(a["logw"], s["logw"], rtol=0, atol=1e-12)
+    assert np.allclose(a["neff"], s["neff"], rtol=1e-10)

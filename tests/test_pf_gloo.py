@@ -59,3 +59,18 @@ def test_sharded_proposal_step_matches_single_rank(tmp_path):
     assert np.allclose(got["info"], one["info"], rtol=1e-12)
     known = run_world(1, tmp_path, 29643)
     assert not np.array_equal(known["pose"], one["pose"])          # it is a different sampler
+
+
+@pytest.mark.timeout(600)
+def test_async_driver_with_halt_and_resume_matches_the_synchronous_one(tmp_path):
+    """FastSLAM.step_async / flush (steps enqueued; a sharded filter halts at a resampling step, the host resamples through
+    the collectives and resumes) must give the particles of FastSLAM.step, on 1, 2 and 4 ranks.  The NumPy shard restates
+    the library's protocol (tests/pf_numpy_shard.py), including the ranks' shared scalar page."""
+    sync = run_world(1, tmp_path, 29651)
+    for world, port in ((1, 29652), (2, 29653), (4, 29654)):
+        got = run_world(world, tmp_path, port, "known-async")
+        assert got["resamples"] == sync["resamples"] >= 5
+        assert np.array_equal(got["pose"], sync["pose"]) and np.array_equal(got["lm"], sync["lm"])
+        assert np.allclose(got["logw"], sync["logw"], rtol=0, atol=1e-12)
+        assert np.allclose(got["info"][-1], sync["info"][-1], rtol=1e-12)       # (Neff, resampled?) of the last step
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("slamhip-")]
