@@ -14,11 +14,14 @@ module SLAMHip
 
 export SlamState, EKFSlamState, set_state!, predict, update, add_features, associate,
        compute_association, predict_observation, mpi_to_pi,
-       ekf_predict!, ekf_update!, augment!, observe!
+       ekf_predict!, ekf_update!, augment!, observe!, cov_block, cov_diag, feature_ellipses, vehicle_ellipse,
+       PFSlamState, set_pose!, init_landmarks!, pf_predict!, update_known!, step!, step_async!, flush!,
+       resample!, mean_pose, weights, particles
 
 const libslamhip = get(ENV, "SLAMHIP_LIB", joinpath(@__DIR__, "libslamhip.so"))
 
 const SLAM_OK = Cint(0)
+const SLAM_PF_HALTED = Cint(1)
 const SLAM_E_NOTPD = Cint(-3)
 const SLAM_F32 = Cint(0)
 const SLAM_F64 = Cint(1)
@@ -166,6 +169,36 @@ function observe!(s::EKFSlamState, z::AbstractMatrix, R::AbstractMatrix, gate1::
     assoc
 end
 
+# ---- looking at the covariance without downloading it ------------------------------------------
+"cov[r, c] for the ranges r, c (1-based, like `state.cov[r, c]`) without downloading the matrix (slam_ekf_get_block)."
+function cov_block(s::EKFSlamState{T}, r::AbstractUnitRange, c::AbstractUnitRange) where {T}
+    out = Matrix{T}(undef, length(r), length(c))
+    check(ccall((:slam_ekf_get_block, libslamhip), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Ptr{Cvoid}, Cint),
+                handle(s), first(r) - 1, first(c) - 1, length(r), length(c), out, max(length(r), 1)))
+    out
+end
+
+"diag(state.cov) (slam_ekf_get_diag)."
+function cov_diag(s::EKFSlamState{T}) where {T}
+    out = Vector{T}(undef, length(s))
+    check(ccall((:slam_ekf_get_diag, libslamhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), handle(s), out))
+    out
+end
+
+"feature_ellipses(x, cov) of the browser monitor (sim/browser/wsserver.jl:72-85): 5 x N [cx; cy; rx; ry; phi], on the device."
+function feature_ellipses(s::EKFSlamState)
+    out = Matrix{Float64}(undef, 5, nlandmarks(s))
+    check(ccall((:slam_ekf_ellipses, libslamhip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), handle(s), out, C_NULL))
+    out
+end
+
+"The vehicle-ellipse record of monitor() (sim/browser/wsserver.jl:60-65): [cx, cy, vehicle_phi, rx, ry, phi]."
+function vehicle_ellipse(s::EKFSlamState)
+    out = zeros(Float64, 6)
+    check(ccall((:slam_ekf_ellipses, libslamhip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), handle(s), C_NULL, out))
+    out
+end
+
 # ---- the reference's function surface ------------------------------------------------------
 # The reference returns (x, P) and its only caller assigns them back to the state
 # (sim/ekfslam-sim.jl:100,117,120).  Here the state was already updated in place, so the
@@ -219,6 +252,125 @@ function predict_observation(s::EKFSlamState, idf::Integer)
     fpos = 3 + 2 * idf - 1
     H[:, fpos:fpos+1] = Hf
     zp, H
+end
+
+# ---- PFSlamState: the FastSLAM-1.0 particle filter -----------------------------------------------
+# The reference declares `Particle` / `PFSlamState` (src/common.jl:14-20,31-34) and no filter code (README.md:6);
+# the algorithm is the one specified from the reference's EKF building blocks (include/slamhip.h, "FastSLAM").
+# These wrappers cover a filter that lives on ONE GPU -- every call is one `ccall`; a filter sharded over several
+# GPUs additionally needs the collectives between the calls (slam.jl_amd/pf.py shows the sequence).
+
+"""
+    PFSlamState{T}(n, max_landmarks; seed = 0, device = 0)
+
+`PFSlamState{T}` (src/common.jl:31-34) with `n` particles, device resident (structure of arrays:
+`pose[3][n]`, `logw[n]`, `lm[max_landmarks][5][n]`).
+"""
+mutable struct PFSlamState{T<:Union{Float32,Float64}} <: SlamState
+    handle::Ptr{Cvoid}
+    n::Int
+    max_landmarks::Int
+    function PFSlamState{T}(n::Integer, max_landmarks::Integer; seed::Integer = 0, device::Integer = 0) where {T}
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:slam_pf_create, libslamhip), Cint,
+                    (Ref{Ptr{Cvoid}}, Cint, Int64, Int64, Int64, Cint, Cint, UInt64),
+                    h, T === Float32 ? SLAM_F32 : SLAM_F64, n, n, 0, max_landmarks, device, seed))
+        s = new{T}(h[], n, max_landmarks)
+        finalizer(s) do st
+            ccall((:slam_pf_destroy, libslamhip), Cint, (Ptr{Cvoid},), st.handle)
+        end
+        return s
+    end
+end
+
+"Every particle at `pose`, uniform weights (Particle.pose, src/common.jl:15)."
+function set_pose!(s::PFSlamState, pose::AbstractVector)
+    check(ccall((:slam_pf_set_pose, libslamhip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), s.handle, Float64[pose[1], pose[2], pose[3]]))
+    s
+end
+
+"Landmarks 1..size(xy, 2) known to every particle at xy (2 x nl) + N(0, jitter^2), covariance diag(var, var)."
+function init_landmarks!(s::PFSlamState, xy::AbstractMatrix, var::Real, jitter::Real)
+    check(ccall((:slam_pf_init_landmarks, libslamhip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cdouble, Cdouble),
+                s.handle, Matrix{Float64}(xy), size(xy, 2), var, jitter))
+    s
+end
+
+"F1: control noise per particle (sim/sim-utils.jl:35-38) + the pose update of predict (src/ekf.jl:39-41)."
+function pf_predict!(s::PFSlamState, V::Real, G::Real, wheelbase::Real, Q::AbstractMatrix, dt::Real)
+    check(ccall((:slam_pf_predict, libslamhip), Cint, (Ptr{Cvoid}, Cdouble, Cdouble, Cdouble, Ptr{Cdouble}, Cdouble),
+                s.handle, V, G, wheelbase, colmajor4(Q), dt))
+    s
+end
+
+"F2/F3: z (2 x m) with known 1-based landmark ids; per-landmark 2 x 2 EKF update, log-weights, first sightings."
+function update_known!(s::PFSlamState, z::AbstractMatrix, ids, R::AbstractMatrix)
+    m = size(z, 2)
+    m == 0 && return s
+    check(ccall((:slam_pf_update_known, libslamhip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Int32}, Cint, Ptr{Cdouble}),
+                s.handle, pairs64(z), Vector{Int32}(vec(collect(ids))), m, colmajor4(R)))
+    s
+end
+
+"""
+    step!(state, V, G, wheelbase, Q, dt, z, ids, R; neff_frac = 0.75, proposal = false) -> (Neff, resampled)
+
+One whole filter step, synchronously: predict (or the FastSLAM-2.0 proposal), the known-id updates, the weights, the
+normalisation, and systematic resampling if Neff < neff_frac * n.
+"""
+function step!(s::PFSlamState, V::Real, G::Real, wheelbase::Real, Q::AbstractMatrix, dt::Real, z::AbstractMatrix, ids,
+               R::AbstractMatrix; neff_frac::Real = 0.75, proposal::Bool = false)
+    step_async!(s, V, G, wheelbase, Q, dt, z, ids, R; neff_frac = neff_frac, proposal = proposal)
+    out = flush!(s)
+    out[1], out[2] != 0
+end
+
+"The same step ENQUEUED (slam_pf_step_auto): Neff, the decision and the resampling stay on the device; `flush!` waits."
+function step_async!(s::PFSlamState, V::Real, G::Real, wheelbase::Real, Q::AbstractMatrix, dt::Real, z::AbstractMatrix, ids,
+                     R::AbstractMatrix; neff_frac::Real = 0.75, force::Integer = -1, proposal::Bool = false)
+    check(ccall((:slam_pf_step_auto, libslamhip), Cint,
+                (Ptr{Cvoid}, Cdouble, Cdouble, Cdouble, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Ptr{Int32}, Cint, Ptr{Cdouble},
+                 Cdouble, Cint, Cint),
+                s.handle, V, G, wheelbase, colmajor4(Q), dt, pairs64(z), Vector{Int32}(vec(collect(ids))), size(z, 2),
+                colmajor4(R), neff_frac, force, proposal ? 1 : 0))
+    s
+end
+
+"Wait for the queued steps: [Neff of the last step, 1.0 if it resampled, resamplings so far, steps so far]."
+function flush!(s::PFSlamState)
+    out = zeros(Float64, 4)
+    check(ccall((:slam_pf_flush, libslamhip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), s.handle, out))
+    out
+end
+
+"F4: normalise, and resample if Neff < neff_frac * n.  Returns whether it resampled."
+function resample!(s::PFSlamState, neff_frac::Real = 0.75)
+    did = Ref{Cint}(0)
+    check(ccall((:slam_pf_resample, libslamhip), Cint, (Ptr{Cvoid}, Cdouble, Ref{Cint}), s.handle, neff_frac, did))
+    did[] != 0
+end
+
+"Weighted mean pose [x, y, phi]."
+function mean_pose(s::PFSlamState)
+    out = zeros(Float64, 3)
+    check(ccall((:slam_pf_get_mean_pose, libslamhip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), s.handle, out))
+    out
+end
+
+"The particles' weights (Particle.weight, src/common.jl:19)."
+function weights(s::PFSlamState)
+    out = zeros(Float64, s.n)
+    check(ccall((:slam_pf_get_weights, libslamhip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), s.handle, out))
+    out
+end
+
+"Download: (pose 3 x n ... as n x 3, logw n, lm n x 5 x max_landmarks): the device's SoA arrays, particle index fastest."
+function particles(s::PFSlamState{T}) where {T}
+    pose = Matrix{T}(undef, s.n, 3)
+    logw = Vector{T}(undef, s.n)
+    lm = Array{T,3}(undef, s.n, 5, s.max_landmarks)
+    check(ccall((:slam_pf_download, libslamhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), s.handle, pose, logw, lm))
+    pose, logw, lm
 end
 
 end # module

@@ -500,6 +500,12 @@ __device__ __forceinline__ void request_chunk_p(const DdCtx& c, int2 t, int chun
     const int sx = (t.x * c.img_nch + chunk) * IMG_CHUNK, sy = (t.y * c.img_nch + chunk) * IMG_CHUNK;
     // pieces tid, tid + 512, tid + 1024 of the 1536 sixteen-byte pieces [X image | Y image]
     g[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, sx, 0);
+#ifdef SLAMHIP_EXPERIMENTS
+    if (c.dbg & 64) {          // experiment: the Y image is NOT loaded (what a column panel resident in LDS would save; wrong numbers)
+        if (tid < 256) g[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + 512) * 16, sx, 0);
+        return;
+    }
+#endif
     g[1] = tid < 256 ? __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + 512) * 16, sx, 0)
                      : __builtin_amdgcn_raw_buffer_load_b128(rs, (tid - 256) * 16, sy, 0);
     g[2] = __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + 256) * 16, sy, 0);
@@ -654,7 +660,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // provably wave-uniform
     DdCtx c;
-    c.P = P; c.X = X; c.Y = Y; c.ld = ld; c.pitch = pitch; c.kp = kp; c.dbg = dbg & 0xff; c.xflags = dbg >> 8;
+    c.P = P; c.X = X; c.Y = Y; c.ld = ld; c.pitch = pitch; c.kp = kp; c.dbg = dbg & 0xff; c.xflags = dbg >> 8;      // (experiments build: bit 64 = no Y image loads)
     c.img = img; c.img_nch = img_nch;
     c.nchunks = (kp + KC - 1) / KC;                           // kp is a multiple of 16: the last chunk may be half
     c.wr = wave & 1;                  // row half of the tile
@@ -945,10 +951,16 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
         if (per_xcd > h->tiles_len) per_xcd = h->tiles_len;
         if (per_xcd < 1) per_xcd = 1;
 #ifdef SLAMHIP_EXPERIMENTS
-        if (h->debug_flags & 32)  // timing experiments on the split-bf16 path (1 no stores, 2 no MFMAs, 4 no P loads, 16 no split)
-            hipLaunchKernelGGL((downdate_f32_mfma<true, 4, 3, true>), dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,
-                               (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
-                               h->d_status, h->debug_flags & 0x1f, (unsigned long long*)nullptr, dcount, joseph, IMGARGS);
+        if (h->debug_flags & 32) {  // timing experiments on the split-bf16 path (1 no stores, 2 no MFMAs, 4 no P loads, 16 no split), launched like the product's
+            const bool bandB = !(getenv("SLAMHIP_ORDER") && atoi(getenv("SLAMHIP_ORDER")) == 0);
+            const int2* lst = bandB ? (const int2*)h->tiles + h->tilesB_off : (const int2*)h->tiles;
+            const int L = bandB ? h->tilesB_len : h->tiles_len;
+            int wgs = getenv("SLAMHIP_WGS") ? atoi(getenv("SLAMHIP_WGS")) : L;
+            if (wgs > L) wgs = L;
+            hipLaunchKernelGGL((downdate_f32_mfma<true, 4, 3, true>), dim3(8 * wgs), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,
+                               (const float*)X, (const float*)Y, pitch, kp_total, lst, L,
+                               h->d_status, h->debug_flags & 0x5f, (unsigned long long*)nullptr, dcount, joseph, IMGARGS);
+        }
         else if (h->debug_flags)      // timing experiments only (SLAMHIP_DEBUG): parts of the kernel switched off
             hipLaunchKernelGGL(downdate_f32_mfma<true>, dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,
                                (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,

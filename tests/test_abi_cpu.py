@@ -122,3 +122,51 @@ def test_telemetry_host_helpers():
     assert d == [{"a": 10.0, "b": 5.0}, {"a": 5.0, "b": 3.0}, {"a": 8.0, "b": 6.0}]      # the docstring example of the reference
     m = T.message("tracks", {"x": 1}, timestamp=3.0)
     assert json.loads(T.to_json(m)) == {"type": "tracks", "data": {"x": 1}, "timestamp": 3.0}
+
+
+def _julia_ccalls():
+    """(symbol, number of argument types) of every ccall in SLAMHip.jl."""
+    src = open(os.path.join(ROOT, "slam.jl_amd", "SLAMHip.jl")).read()
+    out = []
+    for m in re.finditer(r"ccall\(\(:(slam_[a-z0-9_]+),\s*libslamhip\),\s*([A-Za-z0-9]+),\s*\(", src):
+        i = m.end()                                  # just past the "(" of the argument-type tuple
+        depth, j = 1, i
+        while depth:
+            depth += {"(": 1, ")": -1}.get(src[j], 0)
+            j += 1
+        body = src[i:j - 1]
+        d, parts, cur = 0, [], ""
+        for ch in body:                              # split at top-level commas (Ref{Ptr{Cvoid}} has none, tuples might)
+            if ch in "({":
+                d += 1
+            elif ch in ")}":
+                d -= 1
+            if ch == "," and d == 0:
+                parts.append(cur)
+                cur = ""
+            else:
+                cur += ch
+        if cur.strip():
+            parts.append(cur)
+        out.append((m.group(1), m.group(2), len([x for x in parts if x.strip()])))
+    return out
+
+
+def test_julia_binding_names_exported_symbols_with_the_right_arity(pkg):
+    """SLAMHip.jl cannot be executed here (no julia): at least every `ccall((:name, libslamhip), ...)` in it must name a
+    symbol the library exports, with as many argument types as the ctypes binding (which the GPU tests exercise) and
+    Cint / Cstring as the return type; and the PF surface SURVEY 8b lists must be bound."""
+    calls = _julia_ccalls()
+    assert len(calls) >= 28
+    sigs = pkg._lib.SIGNATURES
+    lib = ctypes.CDLL(pkg._lib.LIB_PATH)
+    for name, ret, nargs in calls:
+        assert hasattr(lib, name), name
+        assert name in sigs, name
+        assert nargs == len(sigs[name][1]), (name, nargs, len(sigs[name][1]))
+        assert ret == ("Cstring" if name == "slam_last_error" else "Cint"), (name, ret)
+    bound = {c[0] for c in calls}
+    for need in ("slam_pf_create", "slam_pf_destroy", "slam_pf_predict", "slam_pf_update_known", "slam_pf_step_auto", "slam_pf_flush",
+                 "slam_pf_resample", "slam_pf_get_mean_pose", "slam_pf_get_weights", "slam_ekf_ellipses", "slam_ekf_get_block",
+                 "slam_ekf_observe"):
+        assert need in bound, need

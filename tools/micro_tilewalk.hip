@@ -54,6 +54,23 @@ __global__ __launch_bounds__(512) void walk(float* P, int ld, const Seg* segs, c
     }
 }
 
+// tile-major storage: tile k of the walk is the contiguous 64 KiB block k (band-major order = one linear stream)
+template <int AUX>
+__global__ __launch_bounds__(512) void walk_tm(float* P, int ntiles) {
+    const int tid = threadIdx.x;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        f32x4* base = (f32x4*)(P + (size_t)t * 16384);
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = AUX ? __builtin_nontemporal_load(base + u * 512 + tid) : base[u * 512 + tid];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            v[u] *= 1.0001f;
+            if (AUX) __builtin_nontemporal_store(v[u], base + u * 512 + tid); else base[u * 512 + tid] = v[u];
+        }
+    }
+}
+
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 20003;
     const int T = (n + 127) / 128;
@@ -68,6 +85,20 @@ int main(int argc, char** argv) {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     const double bytes = 2.0 * (double)T * (T + 1) / 2 * 65536.0;
+    {   // mode 9 / 10: tile-major storage, band-major order; one workgroup per tile / persistent grid
+        const int ntiles = T * (T + 1) / 2;
+        for (int pers = 0; pers < 2; ++pers)
+            for (int aux = 0; aux < 2; ++aux) {
+                const int grid = pers ? nwg : ntiles;
+                for (int rep = 0; rep < 3; ++rep) { if (aux) walk_tm<2><<<grid, 512>>>(P, ntiles); else walk_tm<0><<<grid, 512>>>(P, ntiles); }
+                hipEventRecord(a);
+                for (int rep = 0; rep < 10; ++rep) { if (aux) walk_tm<2><<<grid, 512>>>(P, ntiles); else walk_tm<0><<<grid, 512>>>(P, ntiles); }
+                hipEventRecord(b);
+                hipEventSynchronize(b);
+                float ms; hipEventElapsedTime(&ms, a, b);
+                printf("n %d tile-major band-major %s %s: %.4f ms per pass, %.2f TB/s\n", n, pers ? "persistent   " : "1 WG per tile", aux ? "nt   " : "plain", ms / 10, bytes / (ms / 10 * 1e-3) / 1e12);
+            }
+    }
     for (int mode = 0; mode < 9; ++mode) {
         if (only >= 0 && mode != only && mode != 0 && !(only == 7 && mode == 8)) continue;
         const int rows = mode == 2 ? 256 : mode == 3 ? 512 : 128;
