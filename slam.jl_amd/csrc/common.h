@@ -97,6 +97,10 @@ struct slam_ekf {
     int tiles_xlen[8];   // valid entries of each XCD's list
     int diag_off, diag_len, diag_xlen[8];   // fp32: the diagonal tiles, listed after the main lists
 
+    // N2 pre-gate: upper bound of the landmarks' variances (ekf_gate.hip)
+    double* d_pmax;      // device double, >= max diag(P_ff)
+    int pmax_valid;      // 0: recompute before the next sweep (upload, Joseph-form update)
+
     // gating partials
     double* gate_part;   // [gate_blocks][ocap][3]
     int gate_blocks_cap;
@@ -143,6 +147,7 @@ int launch_augment(slam_ekf* h, int nn, const double R[4], const double* zn_dev)
 int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gate2, const double* z_src, bool compact);
 // z_src: device-readable (obsbuf or pinned host); compact (observe()): d_assoc -> idfbuf/obsbuf (matched, in order),
 // znbuf (new), d_count = {m, nn}, h_assoc (pinned) -- done by the last gate_final launch
+int ensure_pmax(slam_ekf* h);       // the pre-gate's variance bound is current
 int launch_nis(slam_ekf* h, const double z1[2], int j, const double R[4]);
 int launch_obs_model(slam_ekf* h, int j);
 int launch_update(slam_ekf* h, int m, const double R[4], int form, bool device_count);   // device_count: m is an upper bound, kernels read d_count[0]

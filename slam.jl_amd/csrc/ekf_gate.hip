@@ -108,11 +108,42 @@ __device__ inline PairConst landmark_const(const T* __restrict__ x, const T* __r
     return pair_const(om, pvv, pfv, pff, R);
 }
 
+// ---- N2: the spatial pre-gate (the reference's TODO, src/data-association.jl:18-20: "a quick bounding-box threshold to
+// remove distant features") -- with IDENTICAL decisions.  For S positive definite, nis = v' inv(S) v >= v_k^2 / S_kk for
+// either component k (Cauchy-Schwarz), and for P positive semi-definite |P_ij| <= sqrt(P_ii P_jj), so
+//     S_kk = h_k P5 h_k' + R_kk <= (sum_j |h_kj| sqrt(P_jj))^2 + R_kk =: B_k
+// where the landmark's own two variances are replaced by the filter-wide bound pmax >= max diag(P_ff) (kept on the device:
+// set at upload, raised by add_features, never raised by the down-date, which only lowers a diagonal).  B_k needs the
+// landmark's MEAN only (two coalesced values); if v_k^2 > gate2 * B_k for k = 0 or 1, the pair has nis > gate2: it is
+// neither a candidate (nis < gate1 <= gate2) nor "near" (nis <= gate2) and contributes nothing -- exactly what the
+// full evaluation would find.  A landmark that is out of reach of all the wave's observations never loads its ten
+// covariance values (the stride-(2 ld + 2) gathers that made the sweep fetch 6.5x its algorithmic bytes).
+struct PreGate {
+    double b0, b1;        // gate2 * B_k * (1 + slack); +inf where the bound is not usable (then nothing is skipped)
+};
+
+__device__ inline PreGate pre_gate(double dx, double dy, const double* pvv, double pmax, const double R[4], double gate2) {
+    PreGate g;
+    const double d2 = dx * dx + dy * dy, d = sqrt(d2);
+    const double sx = sqrt(pvv[0]), sy = sqrt(pvv[4]), sp = sqrt(pvv[8]), sm = sqrt(pmax);
+    const double ax = fabs(dx), ay = fabs(dy);
+    // h_0 = [-dx/d, -dy/d, 0, dx/d, dy/d],  h_1 = [dy/d2, -dx/d2, -1, -dy/d2, dx/d2]   (src/common.jl:161-162)
+    const double a0 = (ax * sx + ay * sy + (ax + ay) * sm) / d;
+    const double a1 = (ay * sx + ax * sy + (ax + ay) * sm) / d2 + sp;
+    const double slack = 1.0 + 1e-6;
+    g.b0 = gate2 * (a0 * a0 + R[0]) * slack;
+    g.b1 = gate2 * (a1 * a1 + R[3]) * slack;
+    if (!(g.b0 > 0.0) || !(g.b0 < __builtin_inf())) g.b0 = __builtin_inf();      // NaN, d = 0, a negative variance: no skipping
+    if (!(g.b1 > 0.0) || !(g.b1 < __builtin_inf())) g.b1 = __builtin_inf();
+    return g;
+}
+
 template <typename T>
 __global__ __launch_bounds__(GATE_BLOCK * OBS_WAVES) void gate_kernel(const T* __restrict__ x, const T* __restrict__ P, int ld,
                                                            int N, const double* __restrict__ z, int nz, double R0,
                                                            double R1, double R2, double R3, double gate1, double gate2,
-                                                           double* __restrict__ part) {
+                                                           double* __restrict__ part, const double* __restrict__ pmax_ptr,
+                                                           int pregate) {
     extern __shared__ double smem[];
     double* zs = smem;                 // [nz][2]
     double* red = smem + 2 * nz;       // [nz][3]
@@ -132,10 +163,27 @@ __global__ __launch_bounds__(GATE_BLOCK * OBS_WAVES) void gate_kernel(const T* _
 
     // the landmark constants are evaluated by every wave (cheaper than a hand-over through LDS: ~200 flops)
     const int j0 = blockIdx.x * GATE_BLOCK + lane;
-    const bool valid = j0 < N;
+    bool valid = j0 < N;
+    const double INF = __builtin_inf();
+    if (pregate) {
+        // N2: which of this wave's landmarks are within reach of ANY of this wave's observations?  Needs the landmark's
+        // mean only; the others are provably outside both gates for every one of them and skip the covariance loads.
+        __syncthreads();                                        // the observations are in LDS
+        bool need = false;
+        if (valid) {
+            const int f = 3 + 2 * j0;
+            const double dx = (double)x[f] - pose[0], dy = (double)x[f + 1] - pose[1];
+            const PreGate g = pre_gate(dx, dy, pvv, *pmax_ptr, R, gate2);
+            const double zp0 = sqrt(dx * dx + dy * dy), zp1 = atan2(dy, dx) - pose[2];
+            for (int i = wave; i < nz; i += OBS_WAVES) {
+                const double v0 = zs[2 * i] - zp0, v1 = mpi_to_pi_d(zs[2 * i + 1] - zp1);
+                if (!(v0 * v0 > g.b0) && !(v1 * v1 > g.b1)) need = true;
+            }
+        }
+        valid = need;
+    }
     PairConst pc;
     if (valid) pc = landmark_const(x, P, ld, j0, pose, pvv, R);
-    const double INF = __builtin_inf();
     // per-observation result of this wave, default "nothing in either gate"
     for (int i = tid; i < nz; i += NT) {
         red[3 * i] = INF;
@@ -290,11 +338,58 @@ __global__ void single_pair_kernel(const T* __restrict__ x, const T* __restrict_
 
 }  // namespace
 
+// pmax = max over the landmarks' diagonal entries of P (>= 0), as the bit pattern of a non-negative double (which orders
+// like the integer); a negative or NaN variance makes it +inf: the pre-gate then skips nothing.
+template <typename T>
+__global__ __launch_bounds__(256) void diag_max_kernel(const T* __restrict__ P, int ld, int n, unsigned long long* __restrict__ pmax) {
+    const int i = 3 + blockIdx.x * blockDim.x + threadIdx.x;
+    double v = 0.0;
+    if (i < n) {
+        v = (double)P[(size_t)i * ld + i];
+        if (!(v >= 0.0)) v = __builtin_inf();
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    if ((threadIdx.x & 63) == 0 && v > 0.0) atomicMax(pmax, (unsigned long long)__double_as_longlong(v));
+}
+
+// (re)compute the bound when the state was uploaded or a Joseph-form update may have raised a diagonal by a rounding
+int ensure_pmax(slam_ekf* h) {
+    if (h->pmax_valid) return SLAM_OK;
+    const int n = 3 + 2 * h->N;
+    HIP_TRY(hipMemsetAsync(h->d_pmax, 0, sizeof(double), h->stream));
+    if (h->N > 0) {
+        const int blocks = (2 * h->N + 255) / 256;
+        if (h->dtype == SLAM_F32)
+            hipLaunchKernelGGL(diag_max_kernel<float>, dim3(blocks), dim3(256), 0, h->stream, (const float*)h->P, h->ld, n,
+                               (unsigned long long*)h->d_pmax);
+        else
+            hipLaunchKernelGGL(diag_max_kernel<double>, dim3(blocks), dim3(256), 0, h->stream, (const double*)h->P, h->ld, n,
+                               (unsigned long long*)h->d_pmax);
+        HIP_TRY(hipGetLastError());
+    }
+    h->pmax_valid = 1;
+    return SLAM_OK;
+}
+
 int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gate2, const double* z_src, bool compact) {
     const int nblocks = (h->N + GATE_BLOCK - 1) / GATE_BLOCK;
     if (nblocks > h->gate_blocks_cap) {
         slam_set_error("internal: gate partial buffer too small");
         return SLAM_E_HIP;
+    }
+    // N2 pre-gate: needs S positive definite for every landmark, i.e. (P being a covariance) R positive definite, and
+    // gate2 >= gate1 -- otherwise the plain sweep.
+    const bool r_pd = R[0] > 0.0 && R[3] > 0.0 && R[0] * R[3] - 0.25 * (R[1] + R[2]) * (R[1] + R[2]) > 0.0 && R[1] == R[2];
+    // Measured (tools/bench_gate.py, fp32, 64 observations): the sweep is LATENCY-bound, and the pre-gate puts the
+    // covariance loads behind the test on the mean -- 8.1 against 5.9 us at N = 1k, 8.9 against 7.1 us at N = 10k; it pays
+    // only where the saved gathers outweigh the longer chain: 14.7 against 15.2 us at N = 50k.  So it is used from
+    // 32768 landmarks on (SLAMHIP_X bit 64: always, bit 32: never).
+    const bool big = h->N >= 32768 || (h->xflags & 64);
+    const int pregate = (big && r_pd && gate2 >= gate1 && gate2 < __builtin_inf() && !(h->xflags & 32)) ? 1 : 0;
+    if (pregate) {
+        const int rcp = ensure_pmax(h);
+        if (rcp) return rcp;
     }
     // observations are swept in chunks so the LDS footprint stays bounded for any nz
     constexpr int CHUNK = 256;
@@ -307,11 +402,11 @@ int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gat
             if (h->dtype == SLAM_F32)
                 hipLaunchKernelGGL(gate_kernel<float>, dim3(nblocks), dim3(GATE_BLOCK * OBS_WAVES), shmem, h->stream,
                                    (const float*)h->x, (const float*)h->P, h->ld, h->N, zc, cz, R[0], R[1], R[2], R[3],
-                                   gate1, gate2, h->gate_part);
+                                   gate1, gate2, h->gate_part, (const double*)h->d_pmax, pregate);
             else
                 hipLaunchKernelGGL(gate_kernel<double>, dim3(nblocks), dim3(GATE_BLOCK * OBS_WAVES), shmem, h->stream,
                                    (const double*)h->x, (const double*)h->P, h->ld, h->N, zc, cz, R[0], R[1], R[2], R[3],
-                                   gate1, gate2, h->gate_part);
+                                   gate1, gate2, h->gate_part, (const double*)h->d_pmax, pregate);
         }
         HIP_TRY(hipGetLastError());
         {

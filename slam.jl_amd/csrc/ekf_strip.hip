@@ -21,7 +21,7 @@ namespace {
 template <typename T>
 __global__ __launch_bounds__(256) void augment_kernel(T* __restrict__ x, T* __restrict__ P, int ld, int n0,
                                                        const double* __restrict__ zn, int nn, double R0, double R1,
-                                                       double R2, double R3) {
+                                                       double R2, double R3, unsigned long long* __restrict__ pmax) {
     const double xv = (double)x[0], yv = (double)x[1], phi = (double)x[2];   // ekf.jl:88 (phi fixed for the call)
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < n0) {
@@ -70,6 +70,12 @@ __global__ __launch_bounds__(256) void augment_kernel(T* __restrict__ x, T* __re
                     const double val = (GP[r][0] * Ga[cc][0] + GP[r][1] * Ga[cc][1] + GP[r][2] * Ga[cc][2]) +
                                        (GR[r][0] * Gz[cc][0] + GR[r][1] * Gz[cc][1]);
                     P[(size_t)(fa + cc) * ld + fa + r] = (T)val;
+                    // the new landmark's variances enter the pre-gate's bound (ekf_gate.hip): bit pattern of a
+                    // non-negative double orders like the integer; anything else disables the pre-gate (+inf)
+                    if (r == cc) {
+                        const double sv = (double)(T)val;
+                        atomicMax(pmax, (unsigned long long)__double_as_longlong(sv >= 0.0 ? sv : __builtin_inf()));
+                    }
                 }
             x[fa] = (T)(xv + ra * ca);                                  // (:99)
             x[fa + 1] = (T)(yv + ra * sa);
@@ -279,10 +285,10 @@ int launch_augment(slam_ekf* h, int nn, const double R[4], const double* zn_dev)
         KTimer t(h, SLAM_K_AUGMENT);
         if (h->dtype == SLAM_F32)
             hipLaunchKernelGGL(augment_kernel<float>, dim3(blocks), dim3(256), 0, h->stream, (float*)h->x, (float*)h->P,
-                               h->ld, n0, zn_dev, nn, R[0], R[1], R[2], R[3]);
+                               h->ld, n0, zn_dev, nn, R[0], R[1], R[2], R[3], (unsigned long long*)h->d_pmax);
         else
             hipLaunchKernelGGL(augment_kernel<double>, dim3(blocks), dim3(256), 0, h->stream, (double*)h->x,
-                               (double*)h->P, h->ld, n0, zn_dev, nn, R[0], R[1], R[2], R[3]);
+                               (double*)h->P, h->ld, n0, zn_dev, nn, R[0], R[1], R[2], R[3], (unsigned long long*)h->d_pmax);
     }
     HIP_TRY(hipGetLastError());
     return SLAM_OK;

@@ -1004,6 +1004,9 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form, const int32_t*
 }  // namespace
 
 int launch_update(slam_ekf* h, int m, const double R[4], int form, bool device_count) {
+    // the reference form only LOWERS a diagonal entry (P_ii - sum_k w_ik^2, every term non-negative as computed); the
+    // Joseph form may raise one by a rounding: the pre-gate's variance bound is recomputed before the next sweep
+    if (form == SLAM_FORM_JOSEPH) h->pmax_valid = 0;
     const int32_t* dcount = device_count ? h->d_count : (const int32_t*)nullptr;
     return h->dtype == SLAM_F32 ? update_typed<float>(h, m, R, form, dcount) : update_typed<double>(h, m, R, form, dcount);
 }

@@ -803,3 +803,48 @@ def test_full_size_50k_landmarks_fp64_joseph(pkg):
         r0, c0 = int(rng.integers(0, n - 96)), int(rng.integers(0, n - 96))
         check_block(r0, c0, 96, 96, "random block")
     st.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_spatial_pre_gate_changes_no_decision(pkg, monkeypatch, dtype):
+    """Row N2 (the reference's TODO, src/data-association.jl:18-20): the sweep skips a landmark's covariance loads when a
+    bound that needs its MEAN only proves nis > gate2 for all observations (forced on with SLAMHIP_X=64; by default it
+    starts at 32768 landmarks, where it begins to pay).  The decisions must be those of the plain sweep (SLAMHIP_X=32)
+    and of the oracle -- on maps with tiny and with huge covariances (nothing can be skipped),
+    with observations matched, dropped (dead band), new, repeated, behind the vehicle; after add_features (which
+    raises the bound) and after reference-form and Joseph-form updates (which may lower / recompute it)."""
+    rng = np.random.default_rng(91)
+    N = 400
+    for scale, spread in ((1.0, 300.0), (1e-3, 300.0), (50.0, 60.0)):
+        x, P = random_state(rng, N, spread=spread)
+        P = P * scale
+        sts = {}
+        for name, flag in (("pre", "64"), ("plain", "32")):        # (by default the pre-gate starts at 32768 landmarks)
+            monkeypatch.setenv("SLAMHIP_X", flag)
+            sts[name] = pkg.EKFSlamState(x, P, dtype=dtype, max_landmarks=N + 40)
+        monkeypatch.delenv("SLAMHIP_X", raising=False)
+        xo, Po = rounded(sts["pre"])
+        for rnd in range(4):
+            ids = rng.choice(np.arange(1, sts["pre"].N + 1), size=20, replace=False)
+            zm = noisy_obs(rng, xo, ids)
+            zd = noisy_obs(rng, xo, ids[:6]) + np.array([[0.35 * math.sqrt(scale) + 0.25], [0.0]])     # around the dead band
+            znew = np.vstack([rng.uniform(500, 900, 3), rng.uniform(-3, 3, 3)])
+            zrep = zm[:, :2] + 1e-3
+            z = np.hstack([zm, zd, znew, zrep])[:, rng.permutation(31)]
+            nis, nd = O.association_table_sparse(xo, Po, z, R)
+            ao = O.assoc_vector(nis, nd, 4.0, 25.0)
+            form = "joseph" if rnd % 2 else "cholesky"
+            a_pre = sts["pre"].observe(z, R, 4.0, 25.0, form=form)
+            a_plain = sts["plain"].observe(z, R, 4.0, 25.0, form=form)
+            assert np.array_equal(a_pre, a_plain), f"scale {scale} round {rnd}"
+            assert np.array_equal(a_pre, ao), f"scale {scale} round {rnd} (oracle)"
+            assert len(set(ao.tolist()) & {0}) + int(np.any(ao < 0)) + int(np.any(ao > 0)) >= 2
+            xa, Pa = sts["pre"].download()
+            xb, Pb = sts["plain"].download()
+            assert np.array_equal(xa, xb) and np.array_equal(Pa, Pb)
+            xo, Po = xa.astype(np.float64), np.array(Pa, dtype=np.float64)
+            for st in sts.values():
+                st.predict(6.0, 0.05, 4.0, Q, 0.025)
+            xo, Po = rounded(sts["pre"])
+        for st in sts.values():
+            st.close()
