@@ -252,6 +252,94 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
                          "conditional no-op launches, nothing read back by the host"}}
 
 
+
+def measure_traffic(args, want_fastslam):
+    """HBM-side traffic of the dominant kernels, MEASURED in this run: two child passes of this script under
+    `rocprofv3 --kernel-trace --pmc <counter>` (FETCH_SIZE and WRITE_SIZE need separate passes: TCC slots), started
+    BEFORE this process touches the GPU (children are plain subprocesses).  Returns {kernel: {"fetch_kb": ..,
+    "write_kb": .., "launches": ..}} with the per-launch means, or {"error": ...}.  gfx950 corrections as the guide's
+    HBM section prescribes: FETCH_SIZE counts 64 B per 128-B request (x2), WRITE_SIZE is exact; unit KB = 1024 B."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return {"error": "rocprofv3 not found"}
+    names = {"downdate_f32_mfma": "downdate", "downdate_f64_mfma": "downdate", "pf_auto_step_kernel": "pf_step"}
+    out = {}
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-pmc",
+             "--prewarm-ms", "20", "--landmarks", str(args.landmarks), "--obs", str(args.obs), "--dtype", args.dtype,
+             "--form", args.form] + ([] if want_fastslam else ["--no-fastslam"])
+    for counter, key in (("FETCH_SIZE", "fetch_kb"), ("WRITE_SIZE", "write_kb")):
+        d = tempfile.mkdtemp(prefix="slam_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child,
+                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", SLAM_BENCH_CHILD="1"), capture_output=True,
+                               text=True, timeout=400)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {"error": f"rocprofv3 --pmc {counter} failed (exit {r.returncode}): {r.stderr[-300:]}"}
+            acc = {}
+            for row in csv.DictReader(open(files[0])):
+                if row.get("Counter_Name") != counter:
+                    continue
+                short = next((v for k, v in names.items() if k in row["Kernel_Name"]), None)
+                if short:
+                    acc.setdefault(short, []).append(float(row["Counter_Value"]))
+            for short, vals in acc.items():
+                out.setdefault(short, {})[key] = sum(vals) / len(vals)
+                out[short]["launches"] = len(vals)
+        except Exception as e:                                  # the bench line must still come out
+            return {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
+def hbm_bytes(rec):
+    """FETCH_SIZE x 2 (gfx950: 128-B requests tallied at 64 B) + WRITE_SIZE, KB of 1024 B -> bytes per launch."""
+    if not rec or "fetch_kb" not in rec or "write_kb" not in rec:
+        return None
+    return (2.0 * rec["fetch_kb"] + rec["write_kb"]) * 1024.0
+
+
+def literal_cpu_legs(budget_s=12.0):
+    """the LITERAL dense restatement (oracle/ekf_ref.py: dense 2 x n Jacobians, dense H*P*H' per pair, as
+    the reference computes) timed at C2 (N = 1000, 16 observations, fp64) on a bounded sample -- one observation against
+    all 1000 landmarks for the association, one dense batched update -- and the probe for a `julia` binary."""
+    import shutil
+    from oracle import ekf_ref as O
+    x, P, zs = make_workload(1000, 16, 1, SEED)
+    xo, Po = x.astype(np.float64), P.astype(np.float64)
+    z = zs[0]
+    t0 = time.perf_counter()
+    pairs = 0
+    for j in range(1, 1001):
+        O.compute_association(xo, Po, z[:, 0], R, j)
+        pairs += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    t_pair = (time.perf_counter() - t0) / pairs
+    zf, idf, _zn = O.associate_sparse(xo, Po, z, R, GATE1, GATE2)
+    t1 = time.perf_counter()
+    O.update(xo, Po, zf, R, idf)
+    t_upd = time.perf_counter() - t1
+    step = 16 * 1000 * t_pair + t_upd
+    legs = [{"kind": "literal", "value": idf.shape[1] / step, "unit": "obs-updates/s",
+             "cores": min(os.cpu_count() or 1, len(os.sched_getaffinity(0))),
+             "sample": f"C2 (N=1000, 16 obs, fp64): {pairs} dense compute_association pairs timed ({t_pair * 1e3:.2f} ms each, "
+                       f"extrapolated to the 16000 of a step) + one dense batched update ({t_upd * 1e3:.0f} ms); the literal form is "
+                       f"O(nz N n^2) and is not timed at N = 10k"}]
+    jl = shutil.which("julia")
+    legs.append({"kind": "julia", "available": bool(jl), "path": jl,
+                 "note": "the reference is Julia 0.5/0.6 source that does not parse on Julia >= 1.0; no julia binary on this node"
+                         if not jl else "a julia binary exists, but the reference's own sources do not parse on Julia >= 1.0 and the "
+                                        "repo ships no Julia restatement of them: not timed"})
+    return legs
+
+
 def spawn_ranks(n):
     """One child process per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, the same command line; children
     are plain subprocesses (never an exec of this process).  Returns the exit code for the parent."""
@@ -300,6 +388,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fastslam", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="untimed device warm-up before the W warm-up steps: a GPU coming out of idle needs ~40 ms of load "
                          "to reach its sustained clocks (tools/step_trend.py: 0.63 -> 0.54 ms per step over the first 60 steps)")
@@ -310,6 +399,14 @@ def main():
         # this process has touched the GPU), relay rank 0's JSON line, fail if any rank fails.  Under
         # torch.distributed.run the ranks already exist (WORLD_SIZE is set) and this is skipped.
         sys.exit(spawn_ranks(args.gpus))
+
+    # roofline.traffic is measured in this run: two child passes under rocprofv3 --pmc, before this process touches the GPU
+    pmc = None
+    under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+    if under_profiler:                 # (the profiler's library has initialised the GPU already: no child processes from here)
+        pmc = {"error": "this run is itself under rocprofv3"}
+    elif not args.no_pmc and "WORLD_SIZE" not in os.environ and args.gpus == 1:
+        pmc = measure_traffic(args, not args.no_fastslam)
 
     import torch
     import torch.distributed as dist
@@ -445,13 +542,10 @@ def main():
         alg_bytes = 1.0 * n * n * esz                                 # lower triangle read + lower triangle written
         tflops = alg_flops / syrk_avg_s / 1e12 if syrk_avg_s > 0 else 0.0
         gbps = alg_bytes / syrk_avg_s / 1e9 if syrk_avg_s > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_downdate_traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            w = tj.get("workload", {})
-            if (w.get("landmarks"), w.get("obs_per_step"), w.get("dtype"), w.get("form")) == (N, nz, args.dtype, args.form):
-                traffic = tj["hbm_bytes_per_launch"]           # PMC-derived (separate rocprofv3 --pmc passes), see profiles/
+        traffic = hbm_bytes((pmc or {}).get("downdate"))           # measured in this run (child rocprofv3 --pmc passes)
+        traffic_note = ("FETCH_SIZE x 2 + WRITE_SIZE per launch from two rocprofv3 --pmc child passes of this run "
+                        f"({(pmc or {}).get('downdate', {}).get('launches', 0)} launches)" if traffic is not None else
+                        ("not measured: " + ((pmc or {}).get("error") or "--no-pmc / multi-rank run")))
         split_bf16 = (args.dtype == "f32" and args.form == "cholesky" and 64 < k_avg <= 128
                       and not (int(os.environ.get("SLAMHIP_X", "0")) & 8))
         if split_bf16:
@@ -473,7 +567,7 @@ def main():
                     "hbm_achieved_GBps": gbps, "hbm_frac_of_8TBps": gbps / HBM_PEAK_GBPS}
         else:
             roof = {"kernel": "downdate (P -= X*Y')", "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, "traffic": None,
+                    "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic,
                     "avg_launch_ms": syrk_avg_s * 1e3, "launches": syrk_n,
                     "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes}
         out = {
@@ -492,6 +586,7 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (EKF does not shard)"},
             "roofline": roof,
             "kernel_ms_per_step": {k: v[0] / max(ndiag, 1) for k, v in tim_all.items()},
+            "traffic_note": traffic_note,
             "kernel_ms_per_step_note": f"{ndiag} extra steps after the timed region with every kernel bracketed by events",
             "factor_phases_us": dict(zip(["innovation", "build_S", "symmetrise", "eliminate", "y_g", "emit_C"], phases)),
         }
@@ -504,7 +599,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(x, P, zs, args.cpu_budget)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            out["cpu_baseline"]["other_legs"] = literal_cpu_legs()
         if fast is not None:
+            fast["roofline"]["traffic"] = hbm_bytes((pmc or {}).get("pf_step"))
             out["fastslam"] = fast
         print(json.dumps(out))
     if world > 1:

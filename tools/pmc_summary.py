@@ -3,7 +3,7 @@
 import collections, csv, glob, sys
 root = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/pmc'
 names = {'downdate_f32': 'downdate_f32_mfma', 'downdate_valu': 'downdate_valu', 'w1_mfma': 'w1_mfma', 'panel_gemm': 'panel_gemm',
-         'factor_kernel': 'factor', 'pht_kernel': 'pht', 'gate_kernel': 'gate', 'gate_final': 'gate_final', 'compact_kernel': 'compact'}
+         'factor_kernel': 'factor', 'pf_auto_step': 'pf_auto_step', 'pf_auto_resample': 'pf_auto_resample', 'pf_auto_scan1': 'pf_auto_scan1', 'downdate_f64': 'downdate_f64_mfma', 'pht_kernel': 'pht', 'gate_kernel': 'gate', 'gate_final': 'gate_final', 'compact_kernel': 'compact'}
 for name in ['sq1', 'sq2', 'fetch', 'write', 'tcc', 'grbm']:
     fs = glob.glob(f'{root}/{name}/**/*counter_collection.csv', recursive=True)
     if not fs:
