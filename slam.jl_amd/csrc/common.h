@@ -53,11 +53,11 @@ struct slam_ekf {
     int maxN;         // landmark capacity
     int N;            // landmarks in the map
     int ncap;         // 3 + 2*maxN
-    int ld;           // leading dimension of P (elements) = npad
+    int ld;           // = npad: carries the tile-row count of P's allocation (T = ld / E) and is the panels' row count
     int npad;         // rows of the panel buffers, multiple of SLAM_TILE
     size_t esz;       // element size
     void* x;          // [ncap]
-    void* P;          // [ld * npad] column-major, whole 128 x 128 tiles; rows/cols >= n are zero padding
+    void* P;          // tile-major, block lower (device_math.h): T(T+1)/2 tiles of E x E, T = npad / E; rows/cols >= n are zero padding
     hipStream_t stream;
     double* PHtS;          // compact panel [3 + kcap][kcap]: the rows of P*H' the factorisation needs
     hipEvent_t stage_ev;   // marks the last H2D copy out of the pinned staging buffers
@@ -141,7 +141,8 @@ struct KTimer {
 // ---- kernel launchers (one per .hip file) -----------------------------------
 int launch_ellipses(slam_ekf* h, double* d_out);     // [N + 1][5]: vehicle, then the landmarks
 int launch_block_gather(slam_ekf* h, int r0, int c0, int nr, int nc, int diag, void* d_out);   // dense nr x nc copy of P[r0.., c0..] (symmetric view)
-int launch_mirror(slam_ekf* h);     // make the tiles above the diagonal valid (before a download)
+int launch_pack(slam_ekf* h, const void* d_src, int lds, int n);     // column-major n x n (device) -> the tile-major state
+int launch_unpack(slam_ekf* h, void* d_dst, int ldd, int n);        // the full symmetric n x n matrix, column-major (device)
 int launch_predict(slam_ekf* h, double v, double g, double w, const double Q[4], double dt);
 int launch_augment(slam_ekf* h, int nn, const double R[4], const double* zn_dev);   // zn already on the device (obsbuf or znbuf)
 int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gate2, const double* z_src, bool compact);

@@ -39,10 +39,40 @@ __host__ __device__ inline ObsModel obs_model(double xv, double yv, double phi, 
     return o;
 }
 
-// P is stored "block lower": the square tiles (edge 2^tile_log2: 128 for fp32, 64 for fp64) on and
-// below the diagonal are maintained, the tiles above it are not (the rank-k down-date updates one
-// triangle, like BLAS syrk).  Every read of P goes through this: element (r, c) of the symmetric matrix.
+// ---- storage of the covariance: TILE-MAJOR, block lower -----------------------------------------------------------------
+// Only the square tiles (edge E = 2^L: 128 for fp32, 64 for fp64) ON and BELOW the diagonal exist (the rank-k down-date
+// updates one triangle, like BLAS syrk).  Each tile is one contiguous E x E column-major block; the tiles of column band J
+// follow each other, I = J (the diagonal tile, stored complete and symmetric), J + 1, ..., T - 1, band after band:
+//     tile (I, J) is block number  J*T - J*(J-1)/2 + (I - J),      T = ld >> L  tile rows of the ALLOCATION.
+// The down-date walks the bands in this order, so its P traffic is ONE linear stream through memory -- a 128 x 128 tile of a
+// column-major matrix is 128 runs of 512 bytes 80 KB apart, which the memory system serves 7-10 % slower
+// (tools/micro_tilewalk.hip) -- and half of the square matrix is never allocated.  `ld` (= npad, a multiple of 128) only
+// carries T; every access to P goes through p_off / sym_at / p_store_sym.
+__host__ __device__ inline size_t tile_base(int I, int J, int T, int L) {
+    return ((size_t)J * (size_t)T - (size_t)J * (size_t)(J - 1) / 2 + (size_t)(I - J)) << (2 * L);
+}
+
+// offset of element (r, c); requires (r >> L) >= (c >> L)
+__host__ __device__ inline size_t p_off(int ld, int L, int r, int c) {
+    const int m = (1 << L) - 1;
+    return tile_base(r >> L, c >> L, ld >> L, L) + ((size_t)(c & m) << L) + (size_t)(r & m);
+}
+
+// element (r, c) of the symmetric matrix, from whichever of (r, c) / (c, r) lies in a stored tile
 template <typename T>
 __device__ inline T sym_at(const T* __restrict__ P, int ld, int tile_log2, int r, int c) {
-    return ((r >> tile_log2) >= (c >> tile_log2)) ? P[(size_t)c * ld + r] : P[(size_t)r * ld + c];
+    return ((r >> tile_log2) >= (c >> tile_log2)) ? P[p_off(ld, tile_log2, r, c)] : P[p_off(ld, tile_log2, c, r)];
+}
+
+// store P[r, c] = P[c, r] = v wherever those positions exist (both inside a diagonal tile, one otherwise)
+template <typename T>
+__device__ inline void p_store_sym(T* __restrict__ P, int ld, int tile_log2, int r, int c, T v) {
+    if ((r >> tile_log2) >= (c >> tile_log2)) P[p_off(ld, tile_log2, r, c)] = v;
+    if ((c >> tile_log2) >= (r >> tile_log2) && r != c) P[p_off(ld, tile_log2, c, r)] = v;
+}
+
+// store P[r, c] = v if that position exists (its mirror is the caller's business)
+template <typename T>
+__device__ inline void p_store(T* __restrict__ P, int ld, int tile_log2, int r, int c, T v) {
+    if ((r >> tile_log2) >= (c >> tile_log2)) P[p_off(ld, tile_log2, r, c)] = v;
 }

@@ -206,7 +206,11 @@ static int create_impl(slam_ekf* h) {
     int rc;
     if ((rc = update_kernels_init())) return rc;
     if ((rc = dev_alloc_zero(&h->x, h->esz * (size_t)h->ncap, h->stream))) return rc;
-    if ((rc = dev_alloc_zero(&h->P, h->esz * (size_t)h->ld * h->npad, h->stream))) return rc;
+    {   // tile-major, block lower (device_math.h): T (T + 1) / 2 tiles of E x E elements
+        const int E = h->dtype == SLAM_F32 ? 128 : 64;
+        const size_t T = (size_t)h->npad / E;
+        if ((rc = dev_alloc_zero(&h->P, h->esz * (T * (T + 1) / 2) * E * E, h->stream))) return rc;
+    }
     if ((rc = dev_alloc_zero(&h->d_small, sizeof(double) * 64, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->d_count, sizeof(int32_t) * 4, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->d_pmax, sizeof(double), h->stream))) return rc;
@@ -294,9 +298,30 @@ static int set_state_impl(slam_ekf* h, const void* x, const void* P, int n, int 
         if (rc) return rc;
     }
     HIP_TRY(hipMemcpyAsync(h->x, x, h->esz * (size_t)n, kind, h->stream));
-    HIP_TRY(hipMemcpy2DAsync(h->P, h->esz * (size_t)h->ld, P, h->esz * (size_t)ldP, h->esz * (size_t)n, (size_t)n, kind,
-                             h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    // the caller's matrix is column-major (Julia order); the state is tile-major: a device-side repack.  A host source
+    // is staged through a temporary column-major device buffer.
+    void* d_tmp = nullptr;
+    const void* d_src = P;
+    int lds = ldP;
+    if (kind == hipMemcpyHostToDevice) {
+        HIP_TRY(hipMalloc(&d_tmp, h->esz * (size_t)n * n));
+        const hipError_t e = hipMemcpy2DAsync(d_tmp, h->esz * (size_t)n, P, h->esz * (size_t)ldP, h->esz * (size_t)n, (size_t)n, kind, h->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(d_tmp);
+            slam_set_error("upload of the covariance failed: %s", hipGetErrorString(e));
+            return SLAM_E_HIP;
+        }
+        d_src = d_tmp;
+        lds = n;
+    }
+    int rc = launch_pack(h, d_src, lds, n);
+    const hipError_t es = hipStreamSynchronize(h->stream);
+    if (d_tmp) (void)hipFree(d_tmp);
+    if (rc) return rc;
+    if (es != hipSuccess) {
+        slam_set_error("hipStreamSynchronize failed in set_state: %s", hipGetErrorString(es));
+        return SLAM_E_HIP;
+    }
     h->N = N;
     h->pmax_valid = 0;                  // the pre-gate's variance bound belongs to the old matrix
     return SLAM_OK;
@@ -316,14 +341,28 @@ extern "C" int slam_ekf_get_state(slam_ekf_t h, void* x, void* P, int n, int ldP
     ARG_CHECK(P == nullptr || ldP >= n, "ldP < n");
     HIP_TRY(hipSetDevice(h->device));
     if (x) HIP_TRY(hipMemcpyAsync(x, h->x, h->esz * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    void* d_tmp = nullptr;
+    int rc = SLAM_OK;
     if (P) {
-        const int rc = launch_mirror(h);            // the down-date maintains only the tiles on/below the diagonal
-        if (rc) return rc;
+        // the full symmetric matrix in the caller's column-major order: unpacked on the device from the stored triangle
+        HIP_TRY(hipMalloc(&d_tmp, h->esz * (size_t)n * n));
+        rc = launch_unpack(h, d_tmp, n, n);
+        if (rc == SLAM_OK) {
+            const hipError_t e = hipMemcpy2DAsync(P, h->esz * (size_t)ldP, d_tmp, h->esz * (size_t)n, h->esz * (size_t)n, (size_t)n,
+                                                  hipMemcpyDeviceToHost, h->stream);
+            if (e != hipSuccess) {
+                slam_set_error("download of the covariance failed: %s", hipGetErrorString(e));
+                rc = SLAM_E_HIP;
+            }
+        }
     }
-    if (P)
-        HIP_TRY(hipMemcpy2DAsync(P, h->esz * (size_t)ldP, h->P, h->esz * (size_t)h->ld, h->esz * (size_t)n, (size_t)n,
-                                 hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    const hipError_t es = hipStreamSynchronize(h->stream);
+    if (d_tmp) (void)hipFree(d_tmp);
+    if (rc) return rc;
+    if (es != hipSuccess) {
+        slam_set_error("hipStreamSynchronize failed in get_state: %s", hipGetErrorString(es));
+        return SLAM_E_HIP;
+    }
     return SLAM_OK;
 }
 

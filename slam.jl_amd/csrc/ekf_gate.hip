@@ -89,7 +89,7 @@ __device__ inline void pair_eval(const PairConst& pc, double z0, double z1, doub
 }
 
 template <typename T>
-__device__ inline PairConst landmark_const(const T* __restrict__ x, const T* __restrict__ P, int ld, int j0,
+__device__ inline PairConst landmark_const(const T* __restrict__ x, const T* __restrict__ P, int ld, int tlog, int j0,
                                            const double pose[3], const double* pvv, const double R[4]) {
     const int f = 3 + 2 * j0;
     const double lx = (double)x[f], ly = (double)x[f + 1];
@@ -97,14 +97,14 @@ __device__ inline PairConst landmark_const(const T* __restrict__ x, const T* __r
     double pfv[2][3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        pfv[0][c] = (double)P[(size_t)c * ld + f];
-        pfv[1][c] = (double)P[(size_t)c * ld + f + 1];
+        pfv[0][c] = (double)P[p_off(ld, tlog, f, c)];
+        pfv[1][c] = (double)P[p_off(ld, tlog, f + 1, c)];
     }
     double pff[4];
-    pff[0] = (double)P[(size_t)f * ld + f];           // P[f][f]
-    pff[2] = (double)P[(size_t)f * ld + f + 1];       // P[f+1][f]  (lower: always maintained)
-    pff[1] = pff[2];                                  // P[f][f+1]  = its mirror (it may lie in a tile above the diagonal)
-    pff[3] = (double)P[(size_t)(f + 1) * ld + f + 1]; // P[f+1][f+1]
+    pff[0] = (double)P[p_off(ld, tlog, f, f)];           // P[f][f]
+    pff[2] = (double)P[p_off(ld, tlog, f + 1, f)];       // P[f+1][f]  (lower: always stored)
+    pff[1] = pff[2];                                     // P[f][f+1]  = its mirror (it may lie in a tile above the diagonal)
+    pff[3] = (double)P[p_off(ld, tlog, f + 1, f + 1)];   // P[f+1][f+1]
     return pair_const(om, pvv, pfv, pff, R);
 }
 
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(GATE_BLOCK * OBS_WAVES) void gate_kernel(const T* _
                                                            int N, const double* __restrict__ z, int nz, double R0,
                                                            double R1, double R2, double R3, double gate1, double gate2,
                                                            double* __restrict__ part, const double* __restrict__ pmax_ptr,
-                                                           int pregate) {
+                                                           int pregate, int tlog) {
     extern __shared__ double smem[];
     double* zs = smem;                 // [nz][2]
     double* red = smem + 2 * nz;       // [nz][3]
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(GATE_BLOCK * OBS_WAVES) void gate_kernel(const T* _
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) pvv[r * 3 + c] = (double)P[(size_t)c * ld + r];
+        for (int c = 0; c < 3; ++c) pvv[r * 3 + c] = (double)P[p_off(ld, tlog, r, c)];
 
     // the landmark constants are evaluated by every wave (cheaper than a hand-over through LDS: ~200 flops)
     const int j0 = blockIdx.x * GATE_BLOCK + lane;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(GATE_BLOCK * OBS_WAVES) void gate_kernel(const T* _
         valid = need;
     }
     PairConst pc;
-    if (valid) pc = landmark_const(x, P, ld, j0, pose, pvv, R);
+    if (valid) pc = landmark_const(x, P, ld, tlog, j0, pose, pvv, R);
     // per-observation result of this wave, default "nothing in either gate"
     for (int i = tid; i < nz; i += NT) {
         red[3 * i] = INF;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(64) void gate_final_kernel(
 // compute_association for ONE pair and predict_observation for ONE landmark.
 template <typename T>
 __global__ void single_pair_kernel(const T* __restrict__ x, const T* __restrict__ P, int ld, int j0, double z0, double z1,
-                                   double R0, double R1, double R2, double R3, int mode, double* __restrict__ out) {
+                                   double R0, double R1, double R2, double R3, int mode, double* __restrict__ out, int tlog) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const double R[4] = {R0, R1, R2, R3};
     double pose[3] = {(double)x[0], (double)x[1], (double)x[2]};
@@ -328,8 +328,8 @@ __global__ void single_pair_kernel(const T* __restrict__ x, const T* __restrict_
     }
     double pvv[9];
     for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) pvv[r * 3 + c] = (double)P[(size_t)c * ld + r];
-    const PairConst pc = landmark_const(x, P, ld, j0, pose, pvv, R);
+        for (int c = 0; c < 3; ++c) pvv[r * 3 + c] = (double)P[p_off(ld, tlog, r, c)];
+    const PairConst pc = landmark_const(x, P, ld, tlog, j0, pose, pvv, R);
     double nis, nd;
     pair_eval(pc, z0, z1, nis, nd);
     out[0] = nis;
@@ -341,11 +341,11 @@ __global__ void single_pair_kernel(const T* __restrict__ x, const T* __restrict_
 // pmax = max over the landmarks' diagonal entries of P (>= 0), as the bit pattern of a non-negative double (which orders
 // like the integer); a negative or NaN variance makes it +inf: the pre-gate then skips nothing.
 template <typename T>
-__global__ __launch_bounds__(256) void diag_max_kernel(const T* __restrict__ P, int ld, int n, unsigned long long* __restrict__ pmax) {
+__global__ __launch_bounds__(256) void diag_max_kernel(const T* __restrict__ P, int ld, int n, unsigned long long* __restrict__ pmax, int tlog) {
     const int i = 3 + blockIdx.x * blockDim.x + threadIdx.x;
     double v = 0.0;
     if (i < n) {
-        v = (double)P[(size_t)i * ld + i];
+        v = (double)P[p_off(ld, tlog, i, i)];
         if (!(v >= 0.0)) v = __builtin_inf();
     }
 #pragma unroll
@@ -362,10 +362,10 @@ int ensure_pmax(slam_ekf* h) {
         const int blocks = (2 * h->N + 255) / 256;
         if (h->dtype == SLAM_F32)
             hipLaunchKernelGGL(diag_max_kernel<float>, dim3(blocks), dim3(256), 0, h->stream, (const float*)h->P, h->ld, n,
-                               (unsigned long long*)h->d_pmax);
+                               (unsigned long long*)h->d_pmax, 7);
         else
             hipLaunchKernelGGL(diag_max_kernel<double>, dim3(blocks), dim3(256), 0, h->stream, (const double*)h->P, h->ld, n,
-                               (unsigned long long*)h->d_pmax);
+                               (unsigned long long*)h->d_pmax, 6);
         HIP_TRY(hipGetLastError());
     }
     h->pmax_valid = 1;
@@ -402,11 +402,11 @@ int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gat
             if (h->dtype == SLAM_F32)
                 hipLaunchKernelGGL(gate_kernel<float>, dim3(nblocks), dim3(GATE_BLOCK * OBS_WAVES), shmem, h->stream,
                                    (const float*)h->x, (const float*)h->P, h->ld, h->N, zc, cz, R[0], R[1], R[2], R[3],
-                                   gate1, gate2, h->gate_part, (const double*)h->d_pmax, pregate);
+                                   gate1, gate2, h->gate_part, (const double*)h->d_pmax, pregate, 7);
             else
                 hipLaunchKernelGGL(gate_kernel<double>, dim3(nblocks), dim3(GATE_BLOCK * OBS_WAVES), shmem, h->stream,
                                    (const double*)h->x, (const double*)h->P, h->ld, h->N, zc, cz, R[0], R[1], R[2], R[3],
-                                   gate1, gate2, h->gate_part, (const double*)h->d_pmax, pregate);
+                                   gate1, gate2, h->gate_part, (const double*)h->d_pmax, pregate, 6);
         }
         HIP_TRY(hipGetLastError());
         {
@@ -424,10 +424,10 @@ int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gat
 static int launch_single(slam_ekf* h, int j0, double z0, double z1, const double R[4], int mode) {
     if (h->dtype == SLAM_F32)
         hipLaunchKernelGGL(single_pair_kernel<float>, dim3(1), dim3(64), 0, h->stream, (const float*)h->x,
-                           (const float*)h->P, h->ld, j0, z0, z1, R[0], R[1], R[2], R[3], mode, h->d_small);
+                           (const float*)h->P, h->ld, j0, z0, z1, R[0], R[1], R[2], R[3], mode, h->d_small, 7);
     else
         hipLaunchKernelGGL(single_pair_kernel<double>, dim3(1), dim3(64), 0, h->stream, (const double*)h->x,
-                           (const double*)h->P, h->ld, j0, z0, z1, R[0], R[1], R[2], R[3], mode, h->d_small);
+                           (const double*)h->P, h->ld, j0, z0, z1, R[0], R[1], R[2], R[3], mode, h->d_small, 6);
     HIP_TRY(hipGetLastError());
     return SLAM_OK;
 }

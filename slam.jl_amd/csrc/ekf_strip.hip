@@ -4,9 +4,10 @@
 // add_features()  src/ekf.jl:84-122
 //
 // Both only touch the three pose rows/columns of P (plus the new rows/columns
-// for add_features).  In column-major storage the COLUMN strip P[:, 0:3] is
-// three contiguous runs, so it is the one that is read (coalesced); the row
-// strip P[0:3, :] is its mirror (P is symmetric) and is only written.  The
+// for add_features).  The COLUMN strip P[:, 0:3] lives in the tiles of the first
+// column band (tile-major storage, device_math.h): 128 consecutive rows of a
+// column are contiguous, so it is read and written coalesced; the row strip
+// P[0:3, :] is its mirror and exists only inside the first (diagonal) tile.  The
 // reference reads the row strip (:34) and re-allocates all of P per new feature
 // (:108-109); here the capacity was allocated once at create.
 #include "common.h"
@@ -21,13 +22,13 @@ namespace {
 template <typename T>
 __global__ __launch_bounds__(256) void augment_kernel(T* __restrict__ x, T* __restrict__ P, int ld, int n0,
                                                        const double* __restrict__ zn, int nn, double R0, double R1,
-                                                       double R2, double R3, unsigned long long* __restrict__ pmax) {
+                                                       double R2, double R3, unsigned long long* __restrict__ pmax, int tlog) {
     const double xv = (double)x[0], yv = (double)x[1], phi = (double)x[2];   // ekf.jl:88 (phi fixed for the call)
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < n0) {
-        const double p0 = (double)P[(size_t)0 * ld + c];
-        const double p1 = (double)P[(size_t)1 * ld + c];
-        const double p2 = (double)P[(size_t)2 * ld + c];
+        const double p0 = (double)P[p_off(ld, tlog, c, 0)];
+        const double p1 = (double)P[p_off(ld, tlog, c, 1)];
+        const double p2 = (double)P[p_off(ld, tlog, c, 2)];
         for (int a = 0; a < nn; ++a) {
             const double r = zn[2 * a], b = zn[2 * a + 1];
             const double s = sin(phi + b), co = cos(phi + b);
@@ -35,16 +36,14 @@ __global__ __launch_bounds__(256) void augment_kernel(T* __restrict__ x, T* __re
             const T v0 = (T)(p0 - r * s * p2);
             const T v1 = (T)(p1 + r * co * p2);
             const int fa = n0 + 2 * a;
-            P[(size_t)fa * ld + c] = v0;            // P[c, fa]      column of the new feature (:114,:118)
-            P[(size_t)(fa + 1) * ld + c] = v1;
-            P[(size_t)c * ld + fa] = v0;            // P[fa, c]      row of the new feature    (:113,:117)
-            P[(size_t)c * ld + fa + 1] = v1;
+            p_store_sym(P, ld, tlog, fa, c, v0);        // P[fa, c] (row of the new feature, :113,:117) and its mirror (:114,:118)
+            p_store_sym(P, ld, tlog, fa + 1, c, v1);
         }
     }
     if (blockIdx.x != 0) return;
     double Pvv[3][3];
     for (int r = 0; r < 3; ++r)
-        for (int cc = 0; cc < 3; ++cc) Pvv[r][cc] = (double)P[(size_t)cc * ld + r];
+        for (int cc = 0; cc < 3; ++cc) Pvv[r][cc] = (double)P[p_off(ld, tlog, r, cc)];
     const double R[2][2] = {{R0, R2}, {R1, R3}};
     // pairs (a, b) with b <= a
     const int npairs = nn * (nn + 1) / 2;
@@ -69,7 +68,7 @@ __global__ __launch_bounds__(256) void augment_kernel(T* __restrict__ x, T* __re
                 for (int cc = 0; cc < 2; ++cc) {
                     const double val = (GP[r][0] * Ga[cc][0] + GP[r][1] * Ga[cc][1] + GP[r][2] * Ga[cc][2]) +
                                        (GR[r][0] * Gz[cc][0] + GR[r][1] * Gz[cc][1]);
-                    P[(size_t)(fa + cc) * ld + fa + r] = (T)val;
+                    p_store(P, ld, tlog, fa + r, fa + cc, (T)val);      // (the entry above the diagonal exists inside a diagonal tile only)
                     // the new landmark's variances enter the pre-gate's bound (ekf_gate.hip): bit pattern of a
                     // non-negative double orders like the integer; anything else disables the pre-gate (+inf)
                     if (r == cc) {
@@ -93,30 +92,48 @@ __global__ __launch_bounds__(256) void augment_kernel(T* __restrict__ x, T* __re
                 for (int cc = 0; cc < 2; ++cc) {
                     // (Gv_a * (Gv_b Pvv)')[r][cc] = sum_t Ga[r][t] * GbP[cc][t]
                     const T val = (T)(Ga[r][0] * GbP[cc][0] + Ga[r][1] * GbP[cc][1] + Ga[r][2] * GbP[cc][2]);
-                    P[(size_t)(fb + cc) * ld + fa + r] = val;           // P[fa+r, fb+cc]
-                    P[(size_t)(fa + r) * ld + fb + cc] = val;           // mirror (:118)
+                    p_store_sym(P, ld, tlog, fa + r, fb + cc, val);     // P[fa+r, fb+cc] and its mirror (:118)
                 }
         }
     }
 }
 
-// Copy the maintained tiles (on/below the diagonal) onto their mirrors above it, 32 x 32 blocks through LDS
-// so that both the read and the write are coalesced.  Used before a download: slam_ekf_get_state returns the
-// full symmetric matrix like the reference's state.cov.
+// Column-major <-> tile-major.  pack: every element of every stored tile (rows / columns >= n: the zero padding) from a
+// column-major n x n source; a workgroup owns 32 x 32 elements of one tile (consecutive threads walk rows: coalesced on
+// both sides).  unpack: the full symmetric n x n matrix, each element from whichever tile stores it.
 template <typename T>
-__global__ __launch_bounds__(256) void mirror_kernel(T* __restrict__ P, int ld, int n, int tile_log2) {
+__global__ __launch_bounds__(256) void pack_kernel(T* __restrict__ P, int ld, int tlog, const T* __restrict__ src, int lds, int n) {
+    const int r0 = 32 * blockIdx.x, c0 = 32 * blockIdx.y;
+    if ((r0 >> tlog) < (c0 >> tlog)) return;                           // (32 divides the tile edge)
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + tx, c = c0 + j;
+        P[p_off(ld, tlog, r, c)] = (r < n && c < n) ? src[(size_t)c * lds + r] : (T)0;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void unpack_kernel(const T* __restrict__ P, int ld, int tlog, T* __restrict__ dst, int ldd, int n) {
     __shared__ T sh[32][33];
-    const int br = blockIdx.x, bc = blockIdx.y;                    // destination block: rows 32*br.., cols 32*bc..
-    if (((32 * br) >> tile_log2) >= ((32 * bc) >> tile_log2)) return;     // destination must lie above the diagonal tiles
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
-    for (int j = ty; j < 32; j += 8) {                             // source block: rows 32*bc.., cols 32*br..
-        const int r = 32 * bc + tx, c = 32 * br + j;
-        sh[j][tx] = (r < n && c < n) ? P[(size_t)c * ld + r] : (T)0;
+    const int r0 = 32 * blockIdx.x, c0 = 32 * blockIdx.y;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const bool lower = (r0 >> tlog) >= (c0 >> tlog);
+    if (lower) {
+        for (int j = ty; j < 32; j += 8) {
+            const int r = r0 + tx, c = c0 + j;
+            if (r < n && c < n) dst[(size_t)c * ldd + r] = P[p_off(ld, tlog, r, c)];
+        }
+        return;
+    }
+    // a block above the diagonal tiles: read its mirror (rows c0.., columns r0..) coalesced, transpose through LDS
+    for (int j = ty; j < 32; j += 8) {
+        const int rr = c0 + tx, cc = r0 + j;                            // element (rr, cc) of the stored triangle
+        sh[j][tx] = (rr < n && cc < n) ? P[p_off(ld, tlog, rr, cc)] : (T)0;
     }
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
-        const int r = 32 * br + tx, c = 32 * bc + j;
-        if (r < n && c < n) P[(size_t)c * ld + r] = sh[tx][j];     // P[r, c] = P[c, r]
+        const int r = r0 + tx, c = c0 + j;
+        if (r < n && c < n) dst[(size_t)c * ldd + r] = sh[tx][j];      // P[r, c] = P[c, r]
     }
 }
 
@@ -127,12 +144,12 @@ __global__ __launch_bounds__(256) void mirror_kernel(T* __restrict__ P, int ld, 
 // [-pi/2, pi/2] -- the same ellipse.  Closed form for the symmetric 2 x 2 block, in double.
 template <typename T>
 __global__ __launch_bounds__(256) void ellipse_kernel(const T* __restrict__ x, const T* __restrict__ P, int ld, int N,
-                                                       double* __restrict__ out) {
+                                                       double* __restrict__ out, int tlog) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;          // 0: vehicle, 1..N: landmarks
     if (j > N) return;
     const int f = j == 0 ? 0 : 3 + 2 * (j - 1);
-    const double a = (double)P[(size_t)f * ld + f], b = (double)P[(size_t)f * ld + f + 1],
-                 d = (double)P[(size_t)(f + 1) * ld + f + 1];
+    const double a = (double)P[p_off(ld, tlog, f, f)], b = (double)P[p_off(ld, tlog, f + 1, f)],
+                 d = (double)P[p_off(ld, tlog, f + 1, f + 1)];
     const double tr = a + d, df = a - d;
     const double disc = sqrt(df * df + 4.0 * b * b);
     const double l2 = 0.5 * (tr + disc);
@@ -181,21 +198,30 @@ int launch_ellipses(slam_ekf* h, double* d_out) {
     const int cnt = h->N + 1;
     if (h->dtype == SLAM_F32)
         hipLaunchKernelGGL(ellipse_kernel<float>, dim3((cnt + 255) / 256), dim3(256), 0, h->stream, (const float*)h->x,
-                           (const float*)h->P, h->ld, h->N, d_out);
+                           (const float*)h->P, h->ld, h->N, d_out, 7);
     else
         hipLaunchKernelGGL(ellipse_kernel<double>, dim3((cnt + 255) / 256), dim3(256), 0, h->stream, (const double*)h->x,
-                           (const double*)h->P, h->ld, h->N, d_out);
+                           (const double*)h->P, h->ld, h->N, d_out, 6);
     HIP_TRY(hipGetLastError());
     return SLAM_OK;
 }
 
-int launch_mirror(slam_ekf* h) {
-    const int n = 3 + 2 * h->N;
+int launch_pack(slam_ekf* h, const void* d_src, int lds, int n) {
+    const int nb = h->npad / 32;
+    if (h->dtype == SLAM_F32)
+        hipLaunchKernelGGL(pack_kernel<float>, dim3(nb, nb), dim3(256), 0, h->stream, (float*)h->P, h->ld, 7, (const float*)d_src, lds, n);
+    else
+        hipLaunchKernelGGL(pack_kernel<double>, dim3(nb, nb), dim3(256), 0, h->stream, (double*)h->P, h->ld, 6, (const double*)d_src, lds, n);
+    HIP_TRY(hipGetLastError());
+    return SLAM_OK;
+}
+
+int launch_unpack(slam_ekf* h, void* d_dst, int ldd, int n) {
     const int nb = (n + 31) / 32;
     if (h->dtype == SLAM_F32)
-        hipLaunchKernelGGL(mirror_kernel<float>, dim3(nb, nb), dim3(256), 0, h->stream, (float*)h->P, h->ld, n, 7);
+        hipLaunchKernelGGL(unpack_kernel<float>, dim3(nb, nb), dim3(256), 0, h->stream, (const float*)h->P, h->ld, 7, (float*)d_dst, ldd, n);
     else
-        hipLaunchKernelGGL(mirror_kernel<double>, dim3(nb, nb), dim3(256), 0, h->stream, (double*)h->P, h->ld, n, 6);
+        hipLaunchKernelGGL(unpack_kernel<double>, dim3(nb, nb), dim3(256), 0, h->stream, (const double*)h->P, h->ld, 6, (double*)d_dst, ldd, n);
     HIP_TRY(hipGetLastError());
     return SLAM_OK;
 }
@@ -209,25 +235,21 @@ namespace {
 template <typename T>
 __global__ __launch_bounds__(256) void predict_kernel(T* __restrict__ x, T* __restrict__ P, int ld, int n, double v, double g,
                                                        double w, double Q0, double Q1, double Q2, double Q3, double dt,
-                                                       int32_t* __restrict__ arrive) {
+                                                       int32_t* __restrict__ arrive, int tlog) {
     const double phi = (double)x[2];
     const double sn = sin(g + phi), cs = cos(g + phi);
     const double vts = v * dt * sn, vtc = v * dt * cs;
     const int f = 3 + blockIdx.x * blockDim.x + threadIdx.x;
     if (f < n) {
-        const double p0 = (double)P[(size_t)0 * ld + f];
-        const double p1 = (double)P[(size_t)1 * ld + f];
-        const double p2 = (double)P[(size_t)2 * ld + f];
+        const double p0 = (double)P[p_off(ld, tlog, f, 0)];
+        const double p1 = (double)P[p_off(ld, tlog, f, 1)];
+        const double p2 = (double)P[p_off(ld, tlog, f, 2)];
         const T n0 = (T)(p0 - vts * p2);     // Gv = [1 0 -vts; 0 1 vtc; 0 0 1]
         const T n1 = (T)(p1 + vtc * p2);
         const T n2 = (T)p2;
-        P[(size_t)0 * ld + f] = n0;          // column strip  P[f, 0:3]
-        P[(size_t)1 * ld + f] = n1;
-        P[(size_t)2 * ld + f] = n2;
-        T* row = P + (size_t)f * ld;         // row strip     P[0:3, f]
-        row[0] = n0;
-        row[1] = n1;
-        row[2] = n2;
+        p_store_sym(P, ld, tlog, f, 0, n0);  // column strip P[f, 0:3]; its mirror P[0:3, f] exists inside the first tile only
+        p_store_sym(P, ld, tlog, f, 1, n1);
+        p_store_sym(P, ld, tlog, f, 2, n2);
     }
     __shared__ int last;
     __syncthreads();                         // every thread of the workgroup has its heading
@@ -241,7 +263,7 @@ __global__ __launch_bounds__(256) void predict_kernel(T* __restrict__ x, T* __re
     const double Q[2][2] = {{Q0, Q2}, {Q1, Q3}};   // column-major input
     double Pvv[3][3], GP[3][3], GQ[3][2], out[3][3];
     for (int r = 0; r < 3; ++r)
-        for (int cc = 0; cc < 3; ++cc) Pvv[r][cc] = (double)P[(size_t)cc * ld + r];
+        for (int cc = 0; cc < 3; ++cc) Pvv[r][cc] = (double)P[p_off(ld, tlog, r, cc)];
     for (int r = 0; r < 3; ++r)
         for (int cc = 0; cc < 3; ++cc)
             GP[r][cc] = Gv[r][0] * Pvv[0][cc] + Gv[r][1] * Pvv[1][cc] + Gv[r][2] * Pvv[2][cc];
@@ -252,7 +274,7 @@ __global__ __launch_bounds__(256) void predict_kernel(T* __restrict__ x, T* __re
             out[r][cc] = (GP[r][0] * Gv[cc][0] + GP[r][1] * Gv[cc][1] + GP[r][2] * Gv[cc][2]) +
                          (GQ[r][0] * Gu[cc][0] + GQ[r][1] * Gu[cc][1]);
     for (int r = 0; r < 3; ++r)
-        for (int cc = 0; cc < 3; ++cc) P[(size_t)cc * ld + r] = (T)out[r][cc];
+        for (int cc = 0; cc < 3; ++cc) P[p_off(ld, tlog, r, cc)] = (T)out[r][cc];
     const double x0 = (double)x[0], x1 = (double)x[1];
     x[0] = (T)(x0 + vtc);
     x[1] = (T)(x1 + vts);
@@ -269,10 +291,10 @@ int launch_predict(slam_ekf* h, double v, double g, double w, const double Q[4],
         int32_t* arrive = h->d_count + 3;
         if (h->dtype == SLAM_F32)
             hipLaunchKernelGGL(predict_kernel<float>, dim3(blocks), dim3(256), 0, h->stream, (float*)h->x, (float*)h->P, h->ld, n,
-                               v, g, w, Q[0], Q[1], Q[2], Q[3], dt, arrive);
+                               v, g, w, Q[0], Q[1], Q[2], Q[3], dt, arrive, 7);
         else
             hipLaunchKernelGGL(predict_kernel<double>, dim3(blocks), dim3(256), 0, h->stream, (double*)h->x, (double*)h->P, h->ld,
-                               n, v, g, w, Q[0], Q[1], Q[2], Q[3], dt, arrive);
+                               n, v, g, w, Q[0], Q[1], Q[2], Q[3], dt, arrive, 6);
     }
     HIP_TRY(hipGetLastError());
     return SLAM_OK;
@@ -285,10 +307,10 @@ int launch_augment(slam_ekf* h, int nn, const double R[4], const double* zn_dev)
         KTimer t(h, SLAM_K_AUGMENT);
         if (h->dtype == SLAM_F32)
             hipLaunchKernelGGL(augment_kernel<float>, dim3(blocks), dim3(256), 0, h->stream, (float*)h->x, (float*)h->P,
-                               h->ld, n0, zn_dev, nn, R[0], R[1], R[2], R[3], (unsigned long long*)h->d_pmax);
+                               h->ld, n0, zn_dev, nn, R[0], R[1], R[2], R[3], (unsigned long long*)h->d_pmax, 7);
         else
             hipLaunchKernelGGL(augment_kernel<double>, dim3(blocks), dim3(256), 0, h->stream, (double*)h->x,
-                               (double*)h->P, h->ld, n0, zn_dev, nn, R[0], R[1], R[2], R[3], (unsigned long long*)h->d_pmax);
+                               (double*)h->P, h->ld, n0, zn_dev, nn, R[0], R[1], R[2], R[3], (unsigned long long*)h->d_pmax, 6);
     }
     HIP_TRY(hipGetLastError());
     return SLAM_OK;

@@ -46,6 +46,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "device_math.h"
 
 namespace {
 
@@ -75,19 +76,26 @@ __device__ __forceinline__ void wave_lds_fence() {
 // sub-block: eight lanes cover one full 128-byte line, a wave instruction eight lines.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ auto band_rsrc(const float* band, int ld) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(band), (short)0, TILE * ld * 4, 0x00020000);
+struct DdCtxP {      // where P lives (first members of DdCtx)
+    float* P;
+    int ld;
+};
+
+// P is TILE-MAJOR (device_math.h): tile (I, J) is one contiguous 64 KiB column-major block, the tiles of a column band
+// follow each other -- the band-major walk of the split-bf16 path reads and writes P as one linear stream.
+__device__ __forceinline__ auto tile_rsrc(const DdCtxP& c, int R0, int C0) {
+    const float* tile = c.P + tile_base(R0 >> 7, C0 >> 7, c.ld >> 7, 7);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tile), (short)0, TILE * TILE * 4, 0x00020000);
 }
 
 constexpr int SP = 36;                 // pitch of the per-wave 32 x 32 epilogue scratches (16-byte aligned rows)
 constexpr int NWAVE = 8;               // waves per workgroup: wave (wr, wc) owns rows 64*wr.., columns 32*wc.. of the tile
 constexpr int NTHREADS = 64 * NWAVE;
 
-struct DdCtx {       // per-thread constants of the down-date kernel
-    float* P;
+struct DdCtx : DdCtxP {       // per-thread constants of the down-date kernel
     const float* X;
     const float* Y;
-    int ld, pitch, kp, nchunks, dbg, xflags;
+    int pitch, kp, nchunks, dbg, xflags;
     const char* img;     // pre-split bf16 image of the panel (split-bf16 path, reference form), or null
     int img_nch;         // chunks of 16 columns per 128-row block in the image
     int wr, wc, l31, lh, q, cl, srow, sc4;
@@ -95,13 +103,13 @@ struct DdCtx {       // per-thread constants of the down-date kernel
 };
 
 __device__ __forceinline__ void load_p_tile(const DdCtx& c, int R0, int C0, f32x4 (&pold)[2][4]) {
-    const auto rs = band_rsrc(c.P + (size_t)C0 * c.ld, c.ld);
-    const int voff = (c.cl * c.ld + 4 * c.q) * 4;
+    const auto rs = tile_rsrc(c, R0, C0);
+    const int voff = (c.cl * TILE + 4 * c.q) * 4;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int soff = ((32 * c.wc + 8 * s) * c.ld + R0 + 64 * c.wr + 32 * rb) * 4;
+            const int soff = ((32 * c.wc + 8 * s) * TILE + 64 * c.wr + 32 * rb) * 4;
             pold[rb][s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
         }
 }
@@ -115,9 +123,8 @@ __device__ __forceinline__ void load_p_tile(const DdCtx& c, int R0, int C0, f32x
 template <bool diag>
 __device__ __forceinline__ void store_p_tile(const DdCtx& c, int R0, int C0, const f32x4 (&pold)[2][4],
                                              const f32x16 (&acc)[2], float* sD, float* sV, int dbg) {
-    const auto rs = band_rsrc(c.P + (size_t)C0 * c.ld, c.ld);       // direct:   columns C0.., rows R0..
-    const auto rsm = band_rsrc(c.P + (size_t)R0 * c.ld, c.ld);      // mirrored: columns R0.., rows C0..
-    const int voff = (c.cl * c.ld + 4 * c.q) * 4;
+    const auto rs = tile_rsrc(c, R0, C0);       // the tile (the in-tile mirror of a diagonal tile goes to the same one)
+    const int voff = (c.cl * TILE + 4 * c.q) * 4;
     const int q = c.q, cl = c.cl;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
@@ -130,7 +137,7 @@ __device__ __forceinline__ void store_p_tile(const DdCtx& c, int R0, int C0, con
             const int col = cl + 8 * s;
             const f32x4 prod = *reinterpret_cast<const f32x4*>(&sD[col * SP + 4 * q]);
             const f32x4 val = pold[rb][s] - prod;
-            const int soff = ((32 * c.wc + 8 * s) * c.ld + R0 + 64 * c.wr + 32 * rb) * 4;
+            const int soff = ((32 * c.wc + 8 * s) * TILE + 64 * c.wr + 32 * rb) * 4;
             if (dbg & 1) continue;                                 // experiment: no stores (P stays as it is)
             if (!diag) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rs, voff, soff, 0);
@@ -151,12 +158,12 @@ __device__ __forceinline__ void store_p_tile(const DdCtx& c, int R0, int C0, con
             for (int s = 0; s < 4; ++s) {
                 const int rr = cl + 8 * s;                         // row of the sub-block -> column of the mirror
                 const f32x4 val = *reinterpret_cast<const f32x4*>(&sV[rr * SP + 4 * q]);
-                const int soff = ((64 * c.wr + 32 * rb + 8 * s) * c.ld + C0 + 32 * c.wc) * 4;
+                const int soff = ((64 * c.wr + 32 * rb + 8 * s) * TILE + 32 * c.wc) * 4;
                 const float ve[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                     if (rowb + rr > colb + 4 * q + t)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ve[t]), rsm, voff + 4 * t, soff, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ve[t]), rs, voff + 4 * t, soff, 0);
             }
             wave_lds_fence();
         }
@@ -299,26 +306,26 @@ __device__ __forceinline__ void dd_tile(DdCtx& c, int2 tile, int2 next, smem_t& 
 // two of the six barriers per tile, the per-wave LDS transposes, and the pipeline drain at the tile boundary.
 template <int AUX = 2>        // 2 = non-temporal: the P tile is streamed (see dd_stream_b)
 __device__ __forceinline__ void load_p_mfma(const DdCtx& c, int R0, int C0, float (&pold)[2][16]) {
-    const auto rs = band_rsrc(c.P + (size_t)C0 * c.ld, c.ld);
-    const int voff = (4 * c.lh * c.ld + c.l31) * 4;
+    const auto rs = tile_rsrc(c, R0, C0);
+    const int voff = (4 * c.lh * TILE + c.l31) * 4;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int soff = ((32 * c.wc + 8 * (r >> 2) + (r & 3)) * c.ld + R0 + 64 * c.wr + 32 * rb) * 4;
+            const int soff = ((32 * c.wc + 8 * (r >> 2) + (r & 3)) * TILE + 64 * c.wr + 32 * rb) * 4;
             pold[rb][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, AUX));
         }
 }
 
 template <int AUX = 2>
 __device__ __forceinline__ void store_p_mfma(const DdCtx& c, int R0, int C0, const float (&pold)[2][16], f32x16 (&acc)[2]) {
-    const auto rs = band_rsrc(c.P + (size_t)C0 * c.ld, c.ld);
-    const int voff = (4 * c.lh * c.ld + c.l31) * 4;
+    const auto rs = tile_rsrc(c, R0, C0);
+    const int voff = (4 * c.lh * TILE + c.l31) * 4;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int soff = ((32 * c.wc + 8 * (r >> 2) + (r & 3)) * c.ld + R0 + 64 * c.wr + 32 * rb) * 4;
+            const int soff = ((32 * c.wc + 8 * (r >> 2) + (r & 3)) * TILE + 64 * c.wr + 32 * rb) * 4;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pold[rb][r] - acc[rb][r]), rs, voff, soff, AUX);
             acc[rb][r] = 0.0f;
         }
@@ -785,6 +792,7 @@ __global__ __launch_bounds__(256) void downdate_f64_mfma(double* __restrict__ P,
     const int R0 = tile.x * DT;
     const int C0 = tile.y * DT;
     const bool diag = tile.x == tile.y;
+    double* Pt = P + tile_base(tile.x, tile.y, ld >> 6, 6);        // the tile: one contiguous 64 x 64 column-major block
     // P tile -> registers (rows/columns >= n are padding inside the allocation: P is allocated in whole tiles)
     f64x4 pold[2][2], acc[2][2];
 #pragma unroll
@@ -793,8 +801,8 @@ __global__ __launch_bounds__(256) void downdate_f64_mfma(double* __restrict__ P,
         for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int col = C0 + 32 * wc + 16 * cb + 4 * r + kk, row = R0 + 32 * wr + 16 * rb + li;
-                pold[cb][rb][r] = P[(size_t)col * ld + row];       // (non-temporal loads/stores: no change here, 15.8 ms either way)
+                const int cl = 32 * wc + 16 * cb + 4 * r + kk, rl = 32 * wr + 16 * rb + li;
+                pold[cb][rb][r] = Pt[cl * DT + rl];                 // (non-temporal loads/stores: no change here, 15.8 ms either way)
                 acc[cb][rb][r] = 0.0;
             }
         }
@@ -832,9 +840,8 @@ __global__ __launch_bounds__(256) void downdate_f64_mfma(double* __restrict__ P,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int cl = 32 * wc + 16 * cb + 4 * r + kk, rl = 32 * wr + 16 * rb + li;
-                const int col = C0 + cl, row = R0 + rl;
                 const double val = pold[cb][rb][r] - acc[cb][rb][r];
-                if (!diag || row >= col) P[(size_t)col * ld + row] = val;
+                if (!diag || rl >= cl) Pt[cl * DT + rl] = val;
                 if (diag) sT[rl][cl] = val;
             }
     if (!diag) return;          // tiles above the diagonal are not maintained (see the header comment)
@@ -845,12 +852,10 @@ __global__ __launch_bounds__(256) void downdate_f64_mfma(double* __restrict__ P,
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const int rl = ty + 16 * v;
-        const int rowI = R0 + rl;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int cl = tx + 16 * u;
-            const int colJ = C0 + cl;
-            if (rowI > colJ) P[(size_t)rowI * ld + colJ] = sT[rl][cl];
+            if (rl > cl) Pt[rl * DT + cl] = sT[rl][cl];             // element (row cl, column rl) of the diagonal tile
         }
     }
     (void)n;
@@ -1008,8 +1013,11 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
                                (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
                                h->d_status, h->xflags << 8, (unsigned long long*)nullptr, dcount, joseph, IMGARGS);
     } else {
-        hipLaunchKernelGGL(downdate_f64_mfma, dim3(8 * h->tiles_len), dim3(256), 0, h->stream, (double*)h->P, h->ld, n,
-                           (const double*)X, (const double*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
+        const bool bandB = getenv("SLAMHIP_ORDER64") && atoi(getenv("SLAMHIP_ORDER64")) == 2;      // experiment knob (speed only)
+        const int2* lst = bandB ? (const int2*)h->tiles + h->tilesB_off : (const int2*)h->tiles;
+        const int L = bandB ? h->tilesB_len : h->tiles_len;
+        hipLaunchKernelGGL(downdate_f64_mfma, dim3(8 * L), dim3(256), 0, h->stream, (double*)h->P, h->ld, n,
+                           (const double*)X, (const double*)Y, pitch, kp_total, lst, L,
                            h->d_status, dcount, joseph, joseph ? k16 : kp_total);
     }
     HIP_TRY(hipGetLastError());

@@ -67,9 +67,9 @@ __device__ __forceinline__ void pht_body(const T* __restrict__ x, const T* __res
     if (r >= n) return;
     double* out = PHt + (size_t)r * pitch + 2 * i0;
     if (mc > 0) {
-        const double p0 = (double)P[(size_t)0 * ld + r];
-        const double p1 = (double)P[(size_t)1 * ld + r];
-        const double p2 = (double)P[(size_t)2 * ld + r];
+        const double p0 = (double)P[p_off(ld, tile_log2, r, 0)];
+        const double p1 = (double)P[p_off(ld, tile_log2, r, 1)];
+        const double p2 = (double)P[p_off(ld, tile_log2, r, 2)];
         // all gathers of the chunk are issued before the first use: one memory latency, not sixteen
         T q0[PHT_OBS], q1[PHT_OBS];
 #pragma unroll
