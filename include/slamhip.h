@@ -12,7 +12,7 @@
  *    never throws; slam_last_error() gives a thread-local message;
  *  - on error the filter state is unchanged;
  *  - the state (x, P) lives on the device for the life of the handle
- *    (P at N = 10k is 1.6 GB: moving it per call would dwarf the update);
+ *    (P at N = 10k is 1.6 GB as a matrix: moving it per call would dwarf the update);
  *  - host arrays passed in are borrowed for the duration of the call only;
  *  - matrices are column-major (Julia order).  Small matrices Q, R are
  *    double[4] = {m11, m21, m12, m22}.  Observations are double pairs
@@ -95,11 +95,13 @@ int slam_ekf_get_diag(slam_ekf_t h, void* out);
 int slam_ekf_get_pose(slam_ekf_t h, double pose[3]);       /* state.x[1:3]          */
 int slam_ekf_num_landmarks(slam_ekf_t h, int* N);          /* (length(x)-3)/2       */
 int slam_ekf_dtype(slam_ekf_t h, int* dtype);
-/* Raw device views (for zero-copy interop, e.g. a torch tensor over P):
- * d_x has 3+2*max_landmarks elements, d_P is column-major with leading dim ld.
- * NOTE: like BLAS syrk, the covariance down-date maintains only the square tiles (128 for
- * fp32, 64 for fp64) on and below the diagonal; the tiles above it are stale in this raw
- * view.  slam_ekf_get_state mirrors them and returns the full symmetric matrix. */
+/* Raw device views (for zero-copy interop, e.g. a torch tensor over x): d_x has 3+2*max_landmarks elements.
+ * d_P is NOT a column-major matrix: the covariance is stored TILE-MAJOR, BLOCK LOWER -- only the square tiles (edge E =
+ * 128 for fp32, 64 for fp64) on and below the diagonal exist, each one contiguous E x E column-major block, the tiles of
+ * column band J one after the other (I = J, J+1, ..., T-1), band after band: tile (I, J) is block number
+ * J*T - J*(J-1)/2 + (I - J) with T = ld / E (ld is returned for that purpose); element (r, c), r >= c tile-wise, sits at
+ * block * E*E + (c % E) * E + (r % E).  Diagonal tiles are complete and symmetric.  slam_ekf_get_state /
+ * slam_ekf_get_block return ordinary column-major data. */
 int slam_ekf_device_ptrs(slam_ekf_t h, void** d_x, void** d_P, int* ld, void** stream);
 
 /* ---- the hot path ----------------------------------------------------------- */
