@@ -160,6 +160,7 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
         z = np.vstack([np.hypot(dx, dy), np.arctan2(dy, dx) - pose[2]]) + rng.normal(0, [[0.1], [math.pi / 180]], (2, M))
         obs.append((z, ids))
     res = {}
+    fence()                                # the ranks start their (device-side) scalar exchange together
     # observations converted once, outside the timed regions: a timed step is one library call
     prep = [pkg.PFShard.prepare_obs(z, ids) for z, ids in obs]
     Qs, Rs = pkg.small(Q), pkg.small(R)

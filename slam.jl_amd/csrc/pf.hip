@@ -1185,7 +1185,7 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
                 const double* slot = page + (size_t)r * 8;
                 while (__hip_atomic_load(slot + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (double)a.seq) {
                     __builtin_amdgcn_s_sleep(20);
-                    if (wall_clock64() - t0 > 300000000ull) { err = 1; break; }      // 3 s at 100 MHz: a rank is gone
+                    if (wall_clock64() - t0 > 2000000000ull) { err = 1; break; }     // 20 s at 100 MHz: a rank is gone
                 }
             }
             if (!err) {

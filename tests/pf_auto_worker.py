@@ -17,12 +17,23 @@ from __graft_entry__ import load_package  # noqa: E402
 def main():
     out_path, mode = sys.argv[1], sys.argv[2]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    if world > 1:
+    if mode == "nccl1":
+        # a ONE-rank RCCL group: the collectives of the sharded flow (all-gather of the log-weights, all-to-all of the
+        # records, object collectives, barriers) execute through RCCL on the one GPU a test box has
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    elif world > 1:
         dist.init_process_group("gloo")
     torch.cuda.set_device(0)
     pkg = load_package()
     N, NL, SEED = 4096, 8, 21
-    pf = pkg.PFSlamState(N, NL, seed=SEED, dtype="f64", device=0, distributed=world > 1)
+    pf = pkg.PFSlamState(N, NL, seed=SEED, dtype="f64", device=0, distributed=(world > 1 or mode == "nccl1"))
+    if mode == "nccl1":
+        assert pf.comm.dist.get_backend() == "nccl" and not pf.comm.stage
+        pf.force_exchange = True                 # take the multi-rank resampling flow (collectives) although every ancestor is local
+        # the object collectives and barriers the sharded set-up uses, over RCCL; and a /dev/shm page registered with HIP
+        shm = pkg.pf.ShmScalars(dist, 0, 1)
+        assert shm.all_gather([1.0, 2.0, 3.0]) == [[1.0, 2.0, 3.0]]
+        pf.shard.attach_exchange(0, 1, pkg.shared_page(dist, 0, 1, 16))
     rng = np.random.default_rng(5)                      # same scene / observations on every rank
     lm = rng.uniform(-30, 30, (NL, 2))
     R = np.array([[0.01, 0.0], [0.0, (math.pi / 180) ** 2]])
@@ -50,7 +61,7 @@ def main():
     p, lw, l = pf.shard.download()
     np.savez(out_path + f".rank{rank}", pose=p, lm=l, logw=lw, resamples=pf.resamples, neff=np.array(neffs))
     pf.close()
-    if world > 1:
+    if world > 1 or mode == "nccl1":
         dist.barrier()
         dist.destroy_process_group()
 

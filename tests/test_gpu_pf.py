@@ -701,3 +701,28 @@ def test_auto_mode_two_ranks_on_one_card(pkg, tmp_path):
     assert np.array_equal(a["pose"], s["pose"]) and np.array_equal(a["lm"], s["lm"])
     assert np.allclose(a["logw"], s["logw"], rtol=0, atol=1e-12)
     assert np.allclose(a["neff"], s["neff"], rtol=1e-10)
+
+
+def test_rccl_collectives_of_the_sharded_flow_on_a_one_rank_group(pkg, tmp_path):
+    """The `nccl` (= RCCL) branch of the sharded driver has no multi-GPU box to run on here; a ONE-rank RCCL process group
+    does exist on a one-GPU box: the filter is driven through FastSLAM with the multi-rank resampling flow forced
+    (all-gather of the log-weights, the ancestor table of the whole filter, pack, all-to-all of records, apply), so every
+    collective call of slam.jl_amd/pf.py:TorchComm executes on RCCL with device tensors.  Same particles as the plain
+    single-process filter."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode, port in (("sync", 29721), ("nccl1", 29722)):
+        out = str(tmp_path / f"r_{mode}")
+        env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "pf_auto_worker.py"), out, mode], env=env,
+                           capture_output=True, text=True, timeout=500)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        outs[mode] = np.load(out + ".rank0.npz")
+    a, s = outs["nccl1"], outs["sync"]
+    assert int(a["resamples"]) == int(s["resamples"]) >= 3
+    assert np.array_equal(a["pose"], s["pose"]) and np.array_equal(a["lm"], s["lm"])
+    assert np.allclose(a["logw"], s["logw"], rtol=0, atol=1e-12)
