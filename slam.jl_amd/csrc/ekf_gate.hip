@@ -236,9 +236,10 @@ __device__ __forceinline__ void compact_wave(const int32_t* assoc, int nz, const
     int m = 0, nn = 0;
     for (int base = 0; base < nz; base += 64) {
         const int i = base + lane;
-        const int a = i < nz ? assoc[i] : 0;
+        // the decisions were stored write-through by the other workgroups of this launch: read them at agent scope
+        const int a = i < nz ? __hip_atomic_load(assoc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         const double z0 = i < nz ? zsrc[2 * i] : 0.0, z1 = i < nz ? zsrc[2 * i + 1] : 0.0;
-        if (i < nz) assoc_host[i] = a;           // pinned host memory: the host reads it after the event behind this kernel
+        if (i < nz) __hip_atomic_store(assoc_host + i, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // pinned host memory
         const unsigned long long mm = __ballot(a > 0), mn = __ballot(a < 0);
         const unsigned long long below = (1ull << lane) - 1ull;
         __builtin_amdgcn_s_waitcnt(0);           // every lane holds its z before any lane overwrites the front
@@ -261,9 +262,11 @@ __device__ __forceinline__ void compact_wave(const int32_t* assoc, int nz, const
         count[1] = nn;
     }
     // the host polls this word in pinned memory instead of waiting on an event (an event record costs ~6 us of
-    // stream time): decisions first, system-scope fence, then the sequence number of this call
-    __threadfence_system();
-    if (lane == 0) __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // stream time): the decisions go out as write-through system-scope stores, every lane drains its own, then the
+    // sequence number of this call.  No fence: a system-scope release writes back this XCD's whole L2.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) __hip_atomic_store(flag_host, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // One wave per observation folds the per-workgroup partials into assoc[i].  With `compact_total` > 0 (observe(),
@@ -298,14 +301,15 @@ __global__ __launch_bounds__(64) void gate_final_kernel(
         if (nd_c < INF) a = (int32_t)j_c;            // jbest != 0          (:43)
         else if (!any_near) a = -1;                  // outer > gate2       (:46)
         else a = 0;                                  // dropped
-        assoc[i] = a;
+        // write-through at agent scope, drained, then the arrival: the workgroup whose add comes last reads the
+        // decisions with agent-scope loads (no release/acquire fence = no L2 write-back + invalidate)
+        __hip_atomic_store(assoc + i, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (compact_total > 0) {
-            __threadfence();                         // assoc[i] before the arrival
-            last = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            last = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
         }
     }
     if (compact_total > 0 && __shfl(last, 0)) {
-        __threadfence();
         compact_wave(assoc_all, compact_total, zsrc, zbuf, idf, zn, count, assoc_host, lane, flag_host, seq);
         if (lane == 0) __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed
     }

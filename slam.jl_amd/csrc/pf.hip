@@ -268,47 +268,81 @@ __device__ __forceinline__ void fold_partials(const double* __restrict__ part, i
 // shift_b = m_b if `relative` else 0.
 // SC1: the partials are stored write-through at agent scope (global_store ... sc1) -- the form in which the workgroup
 // that arrives LAST at a counter may read them in the same launch without an L2 write-back (auto mode, pf_auto_tail).
+// six block sums at once: one LDS exchange and one barrier pair for all of them.  Same order of additions as six
+// block_reduce calls (xor tree inside the wave, then wave 0 + wave 1 + ...), so the sums are the same bit for bit.
+__device__ __forceinline__ void block_sum6(double (&v)[6], double (*sh6)[6]) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v[i] += __shfl_xor(v[i], off);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sh6[wave][i] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double r = sh6[0][i];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r += sh6[w][i];
+        v[i] = r;
+    }
+}
+
 template <typename T, bool SC1 = false>
 __device__ __forceinline__ void block_weight_stats(T lw, T x, T y, T phi, bool valid, int relative, double* __restrict__ part) {
-    __shared__ double sh[4];
+    __shared__ double sh[16];
+    __shared__ double sh6[16][6];
     const double m = block_reduce(valid ? (double)lw : -__builtin_inf(), sh, true);
     const double shift = relative ? m : 0.0;
     const double e = valid ? exp((double)lw - shift) : 0.0;
-    const double ph = (double)phi;
-    const double s1 = block_reduce(e, sh, false), s2 = block_reduce(e * e, sh, false);
-    const double sx = block_reduce(e * (double)x, sh, false), sy = block_reduce(e * (double)y, sh, false);
-    const double ss = block_reduce(e * sin(ph), sh, false), sc = block_reduce(e * cos(ph), sh, false);
+    double sn, cs;
+    sincos((double)phi, &sn, &cs);
+    double v[6] = {e, e * e, e * (double)x, e * (double)y, e * sn, e * cs};
+    block_sum6(v, sh6);
     if (threadIdx.x == 0) {
         double* o = part + (size_t)blockIdx.x * 8;
-        const double v[7] = {m, s1, s2, sx, sy, ss, sc};
+        const double w[7] = {m, v[0], v[1], v[2], v[3], v[4], v[5]};
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
-            if (SC1) __hip_atomic_store(o + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else o[i] = v[i];
+            if (SC1) __hip_atomic_store(o + i, w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else o[i] = w[i];
         }
     }
 }
 
 // F3: first sighting of a landmark -- src/ekf.jl:94-103,112 without the pose term.
+// Where an updated record goes: a plain pointer to the particle's first value (rows n apart), or -- the sweep -- a buffer
+// descriptor of the landmark's rows plus the lane's byte offset (see lm_rsrc).
+template <typename T, typename R>
+struct BufRow {
+    R rs;
+    uint32_t voff, row;
+};
 template <typename T>
-__device__ __forceinline__ void lm_init(T* __restrict__ row, int64_t n, T x, T y, T phi, T r, T b, T R00, T R10, T R01, T R11,
+__device__ __forceinline__ void row_store(T* row, int64_t n, int k, T v) { row[k * n] = v; }
+template <typename T, typename R>
+__device__ __forceinline__ void row_store(const BufRow<T, R>& b, int64_t, int k, T v);
+
+template <typename T, typename ROW>
+__device__ __forceinline__ void lm_init(const ROW& row, int64_t n, T x, T y, T phi, T r, T b, T R00, T R10, T R01, T R11,
                                         bool valid) {
     const T s = sin(phi + b), c = cos(phi + b);
     const T g00 = c, g01 = -r * s, g10 = s, g11 = r * c;
     const T a00 = g00 * R00 + g01 * R10, a01 = g00 * R01 + g01 * R11;
     const T a10 = g10 * R00 + g11 * R10, a11 = g10 * R01 + g11 * R11;
     if (valid) {
-        row[0] = x + r * c;
-        row[n] = y + r * s;
-        row[2 * n] = a00 * g00 + a01 * g01;
-        row[3 * n] = a00 * g10 + a01 * g11;
-        row[4 * n] = a10 * g10 + a11 * g11;
+        row_store<T>(row, n, 0, x + r * c);
+        row_store<T>(row, n, 1, y + r * s);
+        row_store<T>(row, n, 2, a00 * g00 + a01 * g01);
+        row_store<T>(row, n, 3, a00 * g10 + a01 * g11);
+        row_store<T>(row, n, 4, a10 * g10 + a11 * g11);
     }
 }
 
 // F2: the 2 x 2 EKF update of one landmark record (`cur`, its 5 values) and the log-weight increment.
-template <typename T>
-__device__ __forceinline__ void lm_update(T* __restrict__ row, int64_t n, const LmRow<T>& cur, T x, T y, T phi, T r, T b, T R00,
+template <typename T, typename ROW>
+__device__ __forceinline__ void lm_update(const ROW& row, int64_t n, const LmRow<T>& cur, T x, T y, T phi, T r, T b, T R00,
                                           T R10, T R01, T R11, bool valid, T& lw) {
     const T lx = cur.lx, ly = cur.ly, pxx = cur.pxx, pxy = cur.pxy, pyy = cur.pyy;
     const T dx = lx - x, dy = ly - y;
@@ -353,20 +387,26 @@ __device__ __forceinline__ void lm_update(T* __restrict__ row, int64_t n, const 
     const T w10 = t10 * c00, w11 = t10 * c01 + t11 * c11;
     const T y0 = c00 * v0, y1 = c01 * v0 + c11 * v1;                  // C' v
     if (valid) {
-        row[0] = lx + w00 * y0 + w01 * y1;                            // x += W v (:72,:74)
-        row[n] = ly + w10 * y0 + w11 * y1;
-        row[2 * n] = pxx - (w00 * w00 + w01 * w01);                   // P -= W1 W1' (:75)
-        row[3 * n] = pxy - (w00 * w10 + w01 * w11);
-        row[4 * n] = pyy - (w10 * w10 + w11 * w11);
+        row_store<T>(row, n, 0, lx + w00 * y0 + w01 * y1);                            // x += W v (:72,:74)
+        row_store<T>(row, n, 1, ly + w10 * y0 + w11 * y1);
+        row_store<T>(row, n, 2, pxx - (w00 * w00 + w01 * w01));               // P -= W1 W1' (:75)
+        row_store<T>(row, n, 3, pxy - (w00 * w10 + w01 * w11));
+        row_store<T>(row, n, 4, pyy - (w10 * w10 + w11 * w11));
     }
     lw += (T)-0.5 * (y0 * y0 + y1 * y1) - log(u00 * u11) - (T)1.8378770664093453;   // log(2 pi)
 }
 
 // The m known-id observations of one particle at pose (x, y, phi), in order: F2 on a landmark the filter has seen,
-// F3 on a first sighting.  The record of observation i+1 is requested before observation i is processed (two
-// records in flight per particle); a repeat of the same landmark in consecutive observations is re-read after
-// the store instead.  Records are read where the lazy resampling left them (obs_src: buffer + slot through the
-// landmark's ancestor table) and written to the particle's own slot of the buffer the staging chose.
+// F3 on a first sighting.  The sweep is bound by memory LATENCY (one particle per lane, four waves per SIMD at C4), so
+// the records of the next PF_DEPTH observations are kept in flight per particle: a ring of PF_DEPTH records in
+// registers, the record of observation i + PF_DEPTH requested before observation i is processed, the first PF_DEPTH
+// before the motion model runs (KnownRing::start).  A landmark that one of the PF_DEPTH observations before it writes
+// (a repeat inside the call) cannot be requested ahead: it is read after that store, at its turn.  Records are read
+// where the lazy resampling left them (obs_src: buffer + slot through the landmark's ancestor table) and written to
+// the particle's own slot of the buffer the staging chose.  The arithmetic and its order do not depend on the depth.
+#ifndef PF_DEPTH
+#define PF_DEPTH 4
+#endif
 template <typename T>
 __device__ __forceinline__ const T* obs_src(const T* lm0, const T* lm1, const int32_t* __restrict__ tabs, int64_t n, int64_t p,
                                             int32_t code, int32_t meta) {
@@ -375,39 +415,129 @@ __device__ __forceinline__ const T* obs_src(const T* lm0, const T* lm1, const in
     return ((meta & META_RBUF) ? lm1 : lm0) + (size_t)(code & ID_MASK) * 5 * n + slot;
 }
 
+// The sweep reads and writes records through BUFFER instructions: a wave-uniform descriptor per landmark (base = the
+// landmark's five rows in the buffer read or written, 5 n values), the field's row as the scalar offset k n sizeof(T),
+// the lane's slot as a 32-bit byte offset -- no vector address arithmetic at all (it was 12 of the ~200 vector
+// instructions per observation, in a kernel that is bound by instruction issue as much as by memory).  Non-temporal:
+// a record is touched once per step, 5 GB of other records pass before it is touched again.
+// (slam_pf_create bounds n so that 5 n sizeof(T) fits 32 bits.)
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 template <typename T>
-__device__ __forceinline__ void apply_known(T* lm0, T* lm1, const int32_t* __restrict__ tabs, int64_t n, int64_t p,
-                                            const double* s_obs, const int32_t* s_ids, const int32_t* s_meta, int m, T x, T y,
-                                            T phi, T R00, T R10, T R01, T R11, bool valid, T& lw) {
-    LmRow<T> pre = {0, 0, 0, 0, 0};
-    bool have = false;
-    if (m > 0 && !(s_ids[0] & NEW_FLAG)) {
-        pre = load_row<T>(obs_src<T>(lm0, lm1, tabs, n, p, s_ids[0], s_meta[0]), n);
-        have = true;
+__device__ __forceinline__ auto lm_rsrc(const T* base, int64_t n) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), (short)0, (int)(uint32_t)(5 * n * (int64_t)sizeof(T)), 0x00020000);
+}
+template <typename T, typename R>
+__device__ __forceinline__ T rec_load(R rs, uint32_t voff, uint32_t soff) {
+    if constexpr (sizeof(T) == 4) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 2));
+    else return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 2));
+}
+template <typename T, typename R>
+__device__ __forceinline__ void rec_store(T v, R rs, uint32_t voff, uint32_t soff) {
+    if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, 2);
+    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), rs, voff, soff, 2);
+}
+
+template <typename T, typename R>
+__device__ __forceinline__ void row_store(const BufRow<T, R>& b, int64_t, int k, T v) {
+    rec_store<T>(v, b.rs, b.voff, (uint32_t)k * b.row);
+}
+
+// The record of observation (code, meta) as particle p reads it: its own slot or, after a lazy resampling, its
+// ancestor's through the landmark's table.
+template <typename T>
+__device__ __forceinline__ LmRow<T> sweep_load(const T* lm0, const T* lm1, const int32_t* __restrict__ tabs, int64_t n, uint32_t p,
+                                               int32_t code, int32_t meta) {
+    const int t = meta & META_TAB;
+    uint32_t slot = p;
+    if (t) {                                                           // uniform
+        const auto rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(tabs + (size_t)(t - 1) * n), (short)0,
+                                                          (int)(uint32_t)(n * 4), 0x00020000);
+        slot = __builtin_amdgcn_raw_buffer_load_b32(rt, p * 4u, 0, 2);
     }
-    for (int i = 0; i < m; ++i) {
-        const int32_t code = s_ids[i], meta = s_meta[i];
-        const int l = code & ID_MASK;
-        const T r = (T)s_obs[2 * i], b = (T)s_obs[2 * i + 1];
-        T* row = ((meta & META_WBUF) ? lm1 : lm0) + (size_t)l * 5 * n + p;
-        LmRow<T> cur = pre;
-        const bool have_cur = have;
-        have = false;
-        if (i + 1 < m) {
-            const int32_t nc = s_ids[i + 1];
-            const int nl = nc & ID_MASK;
-            if (!(nc & NEW_FLAG) && nl != l) {            // uniform
-                pre = load_row<T>(obs_src<T>(lm0, lm1, tabs, n, p, nc, s_meta[i + 1]), n);
-                have = true;
+    const auto rs = lm_rsrc<T>(((meta & META_RBUF) ? lm1 : lm0) + (size_t)(code & ID_MASK) * 5 * n, n);
+    const uint32_t voff = slot * (uint32_t)sizeof(T), row = (uint32_t)n * (uint32_t)sizeof(T);
+    LmRow<T> r;
+    r.lx = rec_load<T>(rs, voff, 0u);
+    r.ly = rec_load<T>(rs, voff, row);
+    r.pxx = rec_load<T>(rs, voff, 2u * row);
+    r.pxy = rec_load<T>(rs, voff, 3u * row);
+    r.pyy = rec_load<T>(rs, voff, 4u * row);
+    return r;
+}
+
+template <typename T>
+struct KnownRing {
+    LmRow<T> ring[PF_DEPTH];
+    bool have[PF_DEPTH];
+
+    // a value read from LDS at a wave-uniform address IS uniform: say so, and everything derived from it -- the branches
+    // on the codes, the landmark's base address -- is scalar work
+    static __device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+    // may observation j's record be requested PF_DEPTH observations ahead?  (uniform: the codes sit in LDS)
+    static __device__ __forceinline__ bool ahead(const int32_t* s_ids, int j) {
+        const int32_t c = uni(s_ids[j]);
+        if (c & NEW_FLAG) return false;
+        const int l = c & ID_MASK;
+        bool ok = true;
+#pragma unroll
+        for (int k = 1; k <= PF_DEPTH; ++k)
+            if (j - k >= 0 && (uni(s_ids[j - k]) & ID_MASK) == l) ok = false;
+        return ok;
+    }
+
+    __device__ __forceinline__ void start(const T* lm0, const T* lm1, const int32_t* __restrict__ tabs, int64_t n, uint32_t p,
+                                          const int32_t* s_ids, const int32_t* s_meta, int m) {
+#pragma unroll
+        for (int u = 0; u < PF_DEPTH; ++u) {
+            have[u] = false;
+            ring[u] = LmRow<T>{0, 0, 0, 0, 0};
+            if (u < m && ahead(s_ids, u)) {
+                ring[u] = sweep_load<T>(lm0, lm1, tabs, n, p, uni(s_ids[u]), uni(s_meta[u]));
+                have[u] = true;
             }
         }
-        if (code & NEW_FLAG) {                         // F3: src/ekf.jl:94-103,112 without the pose term
-            lm_init<T>(row, n, x, y, phi, r, b, R00, R10, R01, R11, valid);
-            continue;
-        }
-        if (!have_cur) cur = load_row<T>(obs_src<T>(lm0, lm1, tabs, n, p, code, meta), n);
-        lm_update<T>(row, n, cur, x, y, phi, r, b, R00, R10, R01, R11, valid, lw);
     }
+
+    __device__ __forceinline__ void run(T* lm0, T* lm1, const int32_t* __restrict__ tabs, int64_t n, uint32_t p,
+                                        const T* s_obs, const int32_t* s_ids, const int32_t* s_meta, int m, T x, T y, T phi,
+                                        T R00, T R10, T R01, T R11, bool valid, T& lw) {
+        for (int i0 = 0; i0 < m; i0 += PF_DEPTH) {
+#pragma unroll
+            for (int u = 0; u < PF_DEPTH; ++u) {
+                const int i = i0 + u;
+                if (i >= m) break;                                 // uniform
+                const int32_t code = uni(s_ids[i]), meta = uni(s_meta[i]);
+                const int l = code & ID_MASK;
+                const T r = s_obs[2 * i], b = s_obs[2 * i + 1];
+                const BufRow<T, decltype(lm_rsrc<T>(lm0, n))> row{lm_rsrc<T>(((meta & META_WBUF) ? lm1 : lm0) + (size_t)l * 5 * n, n),
+                                                                  p * (uint32_t)sizeof(T), (uint32_t)n * (uint32_t)sizeof(T)};
+                LmRow<T> cur = ring[u];
+                const bool have_cur = have[u];
+                have[u] = false;
+                const int j = i + PF_DEPTH;
+                if (j < m && ahead(s_ids, j)) {                    // uniform
+                    ring[u] = sweep_load<T>(lm0, lm1, tabs, n, p, uni(s_ids[j]), uni(s_meta[j]));
+                    have[u] = true;
+                }
+                if (code & NEW_FLAG) {                             // F3: src/ekf.jl:94-103,112 without the pose term
+                    lm_init<T>(row, n, x, y, phi, r, b, R00, R10, R01, R11, valid);
+                    continue;
+                }
+                if (!have_cur) cur = sweep_load<T>(lm0, lm1, tabs, n, p, code, meta);
+                lm_update<T>(row, n, cur, x, y, phi, r, b, R00, R10, R01, R11, valid, lw);
+            }
+        }
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ void apply_known(T* lm0, T* lm1, const int32_t* __restrict__ tabs, int64_t n, int64_t p,
+                                            const T* s_obs, const int32_t* s_ids, const int32_t* s_meta, int m, T x, T y,
+                                            T phi, T R00, T R10, T R01, T R11, bool valid, T& lw) {
+    KnownRing<T> k;
+    k.start(lm0, lm1, tabs, n, (uint32_t)p, s_ids, s_meta, m);
+    k.run(lm0, lm1, tabs, n, (uint32_t)p, s_obs, s_ids, s_meta, m, x, y, phi, R00, R10, R01, R11, valid, lw);
 }
 
 // One particle's filter step: predict (PREDICT), the m known-id updates, the log-weight.  Shared by the legacy kernels
@@ -415,10 +545,13 @@ __device__ __forceinline__ void apply_known(T* lm0, T* lm1, const int32_t* __res
 template <typename T, bool PREDICT>
 __device__ __forceinline__ void step_core(T* __restrict__ pose, T* lm0, T* lm1, const int32_t* __restrict__ tabs,
                                           T* __restrict__ logw, int64_t n, int64_t first, uint32_t step, uint64_t seed, T V, T G,
-                                          T wheelbase, T sigV, T sigG, T dt, const double* s_obs, const int32_t* s_ids,
+                                          T wheelbase, T sigV, T sigG, T dt, const T* s_obs, const int32_t* s_ids,
                                           const int32_t* s_meta, int m, T R00, T R10, T R01, T R11, T pend, int64_t p, bool valid,
                                           T& x, T& y, T& phi, T& lw) {
     x = pose[p]; y = pose[n + p]; phi = pose[2 * n + p];
+    lw = logw[p] - pend;          // `pend`: the normalisation shift deferred by slam_pf_normalize (0 if none)
+    KnownRing<T> known;
+    known.start(lm0, lm1, tabs, n, (uint32_t)p, s_ids, s_meta, m);      // the first records are in flight during the motion model
     if (PREDICT) {
         T e1, e2;
         normals2<T>((uint64_t)(first + p), step, STREAM_PREDICT, seed, e1, e2);
@@ -430,8 +563,7 @@ __device__ __forceinline__ void step_core(T* __restrict__ pose, T* lm0, T* lm1, 
         x = xn; y = yn; phi = pn;
         if (valid) { pose[p] = x; pose[n + p] = y; pose[2 * n + p] = phi; }
     }
-    lw = logw[p] - pend;          // `pend`: the normalisation shift deferred by slam_pf_normalize (0 if none)
-    apply_known<T>(lm0, lm1, tabs, n, p, s_obs, s_ids, s_meta, m, x, y, phi, R00, R10, R01, R11, valid, lw);
+    known.run(lm0, lm1, tabs, n, (uint32_t)p, s_obs, s_ids, s_meta, m, x, y, phi, R00, R10, R01, R11, valid, lw);
     if (valid) logw[p] = lw;
 }
 
@@ -445,10 +577,11 @@ __global__ __launch_bounds__(256) void pf_step_kernel(T* __restrict__ pose, T* l
                                                        const int32_t* __restrict__ ids, int m, T R00, T R10, T R01, T R11,
                                                        double* __restrict__ part, T pend) {
     // the observation list may live in pinned HOST memory (zero-copy staging): one read per workgroup into LDS
-    extern __shared__ double s_obs[];              // [m][2] doubles, then [m] codes, then [m] meta words
-    int32_t* s_ids = reinterpret_cast<int32_t*>(s_obs + 2 * m);
+    extern __shared__ double s_raw[];              // room for [m][2] doubles, then [m] codes, then [m] meta words
+    T* s_obs = reinterpret_cast<T*>(s_raw);        // the observations in the state dtype: converted once per workgroup
+    int32_t* s_ids = reinterpret_cast<int32_t*>(s_raw + 2 * m);
     int32_t* s_meta = s_ids + m;
-    for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) s_obs[i] = z[i];
+    for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) s_obs[i] = (T)z[i];
     for (int i = threadIdx.x; i < m; i += blockDim.x) { s_ids[i] = ids[i]; s_meta[i] = ids[PF_OCAP + i]; }
     __syncthreads();
     const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -468,7 +601,7 @@ __global__ __launch_bounds__(256) void pf_step_kernel(T* __restrict__ pose, T* l
 template <typename T>
 __device__ __forceinline__ void proposal_core(T* __restrict__ pose, T* lm0, T* lm1, const int32_t* __restrict__ tabs,
                                               T* __restrict__ logw, int64_t n, int64_t first, uint32_t step, uint64_t seed, T V,
-                                              T G, T wheelbase, T lq00, T lq10, T lq11, T dt, const double* s_obs,
+                                              T G, T wheelbase, T lq00, T lq10, T lq11, T dt, const T* s_obs,
                                               const int32_t* s_ids, const int32_t* s_meta, int m, T R00, T R10, T R01, T R11,
                                               T pend, int64_t p, bool valid, T& xo, T& yo, T& po, T& lwo) {
     const T x = pose[p], y = pose[n + p], phi = pose[2 * n + p];
@@ -578,10 +711,11 @@ __global__ __launch_bounds__(256) void pf_proposal_kernel(T* __restrict__ pose, 
                                                            T wheelbase, T lq00, T lq10, T lq11, T dt,
                                                            const double* __restrict__ z, const int32_t* __restrict__ ids,
                                                            int m, T R00, T R10, T R01, T R11, double* __restrict__ part, T pend) {
-    extern __shared__ double s_obs[];              // [m][2] doubles, then [m] codes, then [m] meta words
-    int32_t* s_ids = reinterpret_cast<int32_t*>(s_obs + 2 * m);
+    extern __shared__ double s_raw[];              // room for [m][2] doubles, then [m] codes, then [m] meta words
+    T* s_obs = reinterpret_cast<T*>(s_raw);        // the observations in the state dtype: converted once per workgroup
+    int32_t* s_ids = reinterpret_cast<int32_t*>(s_raw + 2 * m);
     int32_t* s_meta = s_ids + m;
-    for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) s_obs[i] = z[i];
+    for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) s_obs[i] = (T)z[i];
     for (int i = threadIdx.x; i < m; i += blockDim.x) { s_ids[i] = ids[i]; s_meta[i] = ids[PF_OCAP + i]; }
     __syncthreads();
     const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1281,11 +1415,11 @@ __global__ __launch_bounds__(256) void pf_auto_step_kernel(PfAutoArgs a) {
     PfCtl* ctl = a.ctl;
     if (ctl->halt_seq != 0) return;                    // an earlier step waits for the host: the host replays this one
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->stamps[0] = wall_clock64();
-    __shared__ double s_obs[2 * PF_AUTO_MAXOBS];
+    __shared__ T s_obs[2 * PF_AUTO_MAXOBS];          // the observations in the state dtype: converted once per workgroup
     __shared__ int32_t s_ids[PF_AUTO_MAXOBS], s_meta[PF_AUTO_MAXOBS], s_l[PF_AUTO_MAXOBS], s_st[PF_AUTO_MAXOBS], s_first[PF_AUTO_MAXOBS];
     __shared__ int s_last;
     const int m = a.m;
-    for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) s_obs[i] = a.z[i];
+    for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) s_obs[i] = (T)a.z[i];
     plan_obs(a.ids, a.lmstate, m, s_l, s_st, s_ids, s_meta, s_first);
     const int pcur = ctl->pcur, tside = ctl->tside;
     const T pend = (T)ctl->shift_next;
@@ -1524,6 +1658,8 @@ extern "C" int slam_pf_create(slam_pf_t* out, int dtype, int64_t n_local, int64_
     ARG_CHECK(n_local > 0 && n_global >= n_local && first_id >= 0 && first_id + n_local <= n_global,
               "particle range [first, first + n_local) must lie inside [0, n_global)");
     ARG_CHECK(n_global < (1ll << 31), "n_global must fit 31 bits");
+    ARG_CHECK(5 * n_local * (dtype == SLAM_F32 ? 4 : 8) < (1ll << 32),
+              "n_local: one landmark's five rows (5 n values) must fit a 4 GiB buffer descriptor");
     ARG_CHECK(max_landmarks > 0 && max_landmarks < (1 << 20), "max_landmarks out of range");
     const int ndev = slam_device_count();
     if (ndev <= 0) {
