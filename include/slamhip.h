@@ -303,8 +303,9 @@ int slam_pf_resample_count(slam_pf_t h, int64_t* count);
 int slam_pf_set_resample_count(slam_pf_t h, int64_t count);
 /* The ranks' shared scalar page (host memory every rank has mapped, >= 2 * world * 64 bytes, zeroed): see above. */
 int slam_pf_attach_exchange(slam_pf_t h, int rank, int world, void* page, size_t bytes);
-/* Diagnostics: 100 MHz wall-clock stamps of the last auto step: kernel start, last workgroup arrived, statistics
- * folded, decision taken, bookkeeping done, published.  Waits for the queue. */
+/* Diagnostics: 100 MHz wall-clock stamps of the last auto step: kernel start, every workgroup's statistics collected,
+ * statistics folded, decision taken, bookkeeping done, published; [6] the collecting workgroup finished its own share,
+ * [7] = [0] + 100 x the number of polls it needed.  Waits for the queue. */
 int slam_pf_debug_stamps(slam_pf_t h, uint64_t out[8]);
 
 /* ---- SURVEY 8b's whole-filter calls (filter wholly on this shard) --------------------------------------------------

@@ -45,7 +45,7 @@ struct PfCtl {                   // device memory; written by the LAST workgroup
     long long seq;               // last completed step
     long long resample_seq;      // the step whose (lazy) resampling the conditional kernels apply
     long long halt_seq;          // != 0: that step wants a resampling the device cannot do; later steps are skipped
-    int32_t arrive;              // arrival counter of the step kernel's workgroups
+    int32_t arrive;              // (unused: the first form of the hand-over counted arrivals here)
     int32_t error;               // 1: the scalar exchange between the ranks timed out
     int32_t nresamples;          // resamplings so far
     int32_t pcur, tside;         // live pose buffer / ancestor-table side
@@ -126,10 +126,6 @@ struct slam_pf {
     int32_t* d_lmstate;          // [nl] per-landmark state word (table + 1 | buffer << 8 | seen << 9)
     PfMirror* h_mir;             // pinned: what the host may look at without synchronising
     PfMirror* h_mir_dev;
-    double* h_auto_obs;          // pinned [PF_LOG][2 * PF_AUTO_MAXOBS]: observation slots of the queued steps
-    int32_t* h_auto_ids;         // pinned [PF_LOG][PF_AUTO_MAXOBS]
-    double* h_auto_obs_dev;
-    int32_t* h_auto_ids_dev;
     int auto_on;                 // the device copy of the bookkeeping is the live one
     long long auto_seq;          // last step enqueued
     long long nresamples;        // resamplings so far (drives the systematic-resampling offset)
@@ -144,6 +140,26 @@ struct slam_pf {
 };
 
 namespace {
+
+// Timing experiment (make exp with -DPF_EXP_STAMPS): where does ONE workgroup of the auto step (the middle one) spend its
+// time?  g_xs: [0] its first instruction, [1] control block read, [2] observations planned, [3] pose predicted,
+// [4] map updates done, [5] statistics stored; [7] workgroup 0's first instruction.  g_wg: the same three points of
+// EVERY workgroup (printed by slam_pf_debug_stamps), which is how the 3-of-4 residency at 135 registers was found.
+#if defined(SLAMHIP_EXPERIMENTS) && defined(PF_EXP_STAMPS)
+__device__ unsigned long long g_xs[8];
+__device__ unsigned long long g_wg[3][4096];        // every workgroup: first instruction, map updates done, statistics stored
+#define PF_WG(k)                                                                                                   \
+    do {                                                                                                           \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_wg[k][blockIdx.x] = wall_clock64();                           \
+    } while (0)
+#define PF_XS(k)                                                                                                   \
+    do {                                                                                                           \
+        if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) g_xs[k] = wall_clock64();                             \
+    } while (0)
+#else
+#define PF_XS(k) do { } while (0)
+#define PF_WG(k) do { } while (0)
+#endif
 
 // ---- Philox4x32-10 -------------------------------------------------------------------------------
 __host__ __device__ inline void philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
@@ -168,15 +184,79 @@ __device__ inline T u01(uint32_t x) {      // 24 random bits, offset by half a s
     return ((T)(x >> 8) + (T)0.5) * (T)(1.0 / 16777216.0);
 }
 
+// ---- fp32 arithmetic of the sweep ----------------------------------------------------------------------------
+// The fp32 sweep is bound by instruction issue as much as by memory (about 4500 vector instructions per particle at C4
+// on four waves per SIMD), and a third of those were the IEEE-exact library forms of log, atan2, sin and cos (range
+// reduction for arguments up to 1e38, denormal and infinity handling).  The fp32 instantiation uses the hardware's
+// transcendental unit instead: v_log_f32 / v_sin_f32 / v_cos_f32 / v_sqrt_f32 / v_rcp_f32 (absolute error about 1e-6
+// on sin and cos of an angle of a few radians, 1 ulp on the others) and a degree-15 odd polynomial for atan (8e-8).
+// That is inside the rounding of the fp32 state itself; fp64 keeps the exact forms.  PF_FAST_MATH=0 builds the exact
+// forms for fp32 too.
+#ifndef PF_FAST_MATH
+#define PF_FAST_MATH 1
+#endif
+template <typename T>
+constexpr bool kFast = PF_FAST_MATH && sizeof(T) == 4;
+
+template <typename T>
+__device__ __forceinline__ T m_log(T x) {
+    if constexpr (kFast<T>) return 0.69314718f * __builtin_amdgcn_logf(x);
+    else return log(x);
+}
+template <typename T>
+__device__ __forceinline__ T m_sqrt(T x) {
+    if constexpr (kFast<T>) return __builtin_amdgcn_sqrtf(x);
+    else return sqrt(x);
+}
+template <typename T>
+__device__ __forceinline__ void m_sincos(T a, T& sn, T& cs) {            // |a| up to a few hundred radians
+    if constexpr (kFast<T>) {
+        const float rev = a * 0.15915494f;                               // the unit takes revolutions
+        sn = __builtin_amdgcn_sinf(rev);
+        cs = __builtin_amdgcn_cosf(rev);
+    } else {
+        sn = sin(a);
+        cs = cos(a);
+    }
+}
+template <typename T>
+__device__ __forceinline__ T m_atan2(T y, T x) {
+    if constexpr (kFast<T>) {
+        const float ax = fabsf(x), ay = fabsf(y);
+        const float t = fminf(ax, ay) * __builtin_amdgcn_rcpf(fmaxf(ax, ay));          // [0, 1]
+        const float q = t * t;
+        // atan t = t + t^3 P(t^2) on [0, 1], near-minimax (Lawson-weighted least squares), |error| < 8.3e-8 in fp32
+        float p = 0.002622197614982724f;
+        p = fmaf(p, q, -0.015132341533899307f);
+        p = fmaf(p, q, 0.041121527552604675f);
+        p = fmaf(p, q, -0.0736667662858963f);
+        p = fmaf(p, q, 0.10573917627334595f);
+        p = fmaf(p, q, -0.14185971021652222f);
+        p = fmaf(p, q, 0.1999039649963379f);
+        p = fmaf(p, q, -0.33332985639572144f);
+        float a = fmaf(t * q, p, t);
+        a = ay > ax ? 1.57079633f - a : a;
+        a = x < 0.0f ? 3.14159265f - a : a;
+        return copysignf(a, y);
+    } else {
+        return atan2(y, x);
+    }
+}
+
 template <typename T>
 __device__ inline void normals2(uint64_t gid, uint32_t step, uint32_t stream, uint64_t seed, T& e1, T& e2) {
     uint32_t r[4];
     philox((uint32_t)gid, (uint32_t)(gid >> 32), step, stream, (uint32_t)seed, (uint32_t)(seed >> 32), r);
     const T u1 = u01<T>(r[0]), u2 = u01<T>(r[1]);
-    const T rad = sqrt((T)-2.0 * log(u1));
-    const T ang = (T)(2.0 * PF_PI) * u2;
-    e1 = rad * cos(ang);
-    e2 = rad * sin(ang);
+    const T rad = m_sqrt<T>((T)-2.0 * m_log<T>(u1));
+    if constexpr (kFast<T>) {
+        e1 = rad * __builtin_amdgcn_cosf(u2);          // cos(2 pi u2): the unit takes revolutions
+        e2 = rad * __builtin_amdgcn_sinf(u2);
+    } else {
+        const T ang = (T)(2.0 * PF_PI) * u2;
+        e1 = rad * cos(ang);
+        e2 = rad * sin(ang);
+    }
 }
 
 template <typename T>
@@ -199,9 +279,12 @@ __global__ __launch_bounds__(256) void pf_predict_kernel(T* __restrict__ pose, i
     const T Vn = V + sigV * e1;                       // sim/sim-utils.jl:36
     const T Gn = G + sigG * e2;                       // :37
     const T x = pose[p], y = pose[n + p], phi = pose[2 * n + p];
-    pose[p] = x + Vn * dt * cos(Gn + phi);            // src/ekf.jl:39-41
-    pose[n + p] = y + Vn * dt * sin(Gn + phi);
-    pose[2 * n + p] = wrap_pi<T>(phi + Vn * dt * sin(Gn) / wheelbase);
+    T sgp, cgp, sg, cg;
+    m_sincos<T>(Gn + phi, sgp, cgp);
+    m_sincos<T>(Gn, sg, cg);
+    pose[p] = x + Vn * dt * cgp;                      // src/ekf.jl:39-41
+    pose[n + p] = y + Vn * dt * sgp;
+    pose[2 * n + p] = wrap_pi<T>(phi + Vn * dt * sg / wheelbase);
 }
 
 template <typename T>
@@ -266,8 +349,8 @@ __device__ __forceinline__ void fold_partials(const double* __restrict__ part, i
 // Per-block weight statistics with the block's OWN maximum as the shift (one pass; pf_fold_kernel rescales):
 // part[b] = {m_b, sum e, sum e^2, sum e x, sum e y, sum e sin(phi), sum e cos(phi)},  e = exp(logw - shift_b),
 // shift_b = m_b if `relative` else 0.
-// SC1: the partials are stored write-through at agent scope (global_store ... sc1) -- the form in which the workgroup
-// that arrives LAST at a counter may read them in the same launch without an L2 write-back (auto mode, pf_auto_tail).
+// SC1 (auto mode): the partials are stored write-through at agent scope (global_store ... sc1) together with a tag, the
+// form in which another workgroup of the SAME launch may read them without an L2 write-back (part_key, pf_auto_tail).
 // six block sums at once: one LDS exchange and one barrier pair for all of them.  Same order of additions as six
 // block_reduce calls (xor tree inside the wave, then wave 0 + wave 1 + ...), so the sums are the same bit for bit.
 __device__ __forceinline__ void block_sum6(double (&v)[6], double (*sh6)[6]) {
@@ -289,15 +372,41 @@ __device__ __forceinline__ void block_sum6(double (&v)[6], double (*sh6)[6]) {
     }
 }
 
+// ---- hand-over of the per-workgroup statistics inside ONE launch (auto mode) --------------------------------------
+// A workgroup's seven partials and a TAG fill one 64-byte line of `part`: tag = key(step) xor the (rotated) bit patterns
+// of the seven values, all eight stored write-through at agent scope and NOT waited for.  The launch's last workgroup
+// polls the lines (agent-scope loads) until every line's tag fits its values and this step's key: a line that is stale
+// (an earlier step's key), half written or torn does not fit.  Nothing else is needed -- no drain of the storing wave's
+// outstanding record stores (3-4 us behind 80 non-temporal stores), no arrival counter (1024 adds to one address:
+// another 3-5 us), which the first form of this hand-over paid on every workgroup's way out.
+__device__ __forceinline__ unsigned long long part_key(long long seq) {
+    return (unsigned long long)seq * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+}
+__device__ __forceinline__ unsigned long long part_hash(const double (&v)[7]) {
+    unsigned long long x = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v[i]);
+        x ^= (b << (9 * i + 3)) | (b >> (64 - (9 * i + 3)));
+    }
+    return x;
+}
+
 template <typename T, bool SC1 = false>
-__device__ __forceinline__ void block_weight_stats(T lw, T x, T y, T phi, bool valid, int relative, double* __restrict__ part) {
+__device__ __forceinline__ void block_weight_stats(T lw, T x, T y, T phi, bool valid, int relative, double* __restrict__ part,
+                                                   long long seq = 0) {
     __shared__ double sh[16];
     __shared__ double sh6[16][6];
     const double m = block_reduce(valid ? (double)lw : -__builtin_inf(), sh, true);
     const double shift = relative ? m : 0.0;
+#if defined(SLAMHIP_EXPERIMENTS) && defined(PF_EXP_NOSTATS)          // timing experiment: WRONG statistics
+    const double e = valid ? 1.0 + ((double)lw - shift) : 0.0;
+    double sn = (double)phi, cs = 1.0;
+#else
     const double e = valid ? exp((double)lw - shift) : 0.0;
     double sn, cs;
     sincos((double)phi, &sn, &cs);
+#endif
     double v[6] = {e, e * e, e * (double)x, e * (double)y, e * sn, e * cs};
     block_sum6(v, sh6);
     if (threadIdx.x == 0) {
@@ -308,6 +417,9 @@ __device__ __forceinline__ void block_weight_stats(T lw, T x, T y, T phi, bool v
             if (SC1) __hip_atomic_store(o + i, w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else o[i] = w[i];
         }
+        if (SC1)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(o + 7), part_hash(w) ^ part_key(seq), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -327,7 +439,8 @@ __device__ __forceinline__ void row_store(const BufRow<T, R>& b, int64_t, int k,
 template <typename T, typename ROW>
 __device__ __forceinline__ void lm_init(const ROW& row, int64_t n, T x, T y, T phi, T r, T b, T R00, T R10, T R01, T R11,
                                         bool valid) {
-    const T s = sin(phi + b), c = cos(phi + b);
+    T s, c;
+    m_sincos<T>(phi + b, s, c);
     const T g00 = c, g01 = -r * s, g10 = s, g11 = r * c;
     const T a00 = g00 * R00 + g01 * R10, a01 = g00 * R01 + g01 * R11;
     const T a10 = g10 * R00 + g11 * R10, a11 = g10 * R01 + g11 * R11;
@@ -360,7 +473,7 @@ __device__ __forceinline__ void lm_update(const ROW& row, int64_t n, const LmRow
         h00 = dx / d; h01 = dy / d; h10 = -dy / d2; h11 = dx / d2;
     }
     const T v0 = r - d;                                               // src/ekf.jl:58
-    const T v1 = wrap_pi<T>(b - (atan2(dy, dx) - phi));
+    const T v1 = wrap_pi<T>(b - (m_atan2<T>(dy, dx) - phi));
     const T t00 = pxx * h00 + pxy * h01, t01 = pxx * h10 + pxy * h11;  // PHt
     const T t10 = pxy * h00 + pyy * h01, t11 = pxy * h10 + pyy * h11;
     const T s00 = h00 * t00 + h01 * t10 + R00;                         // S = Hf PHt + R (:68)
@@ -393,7 +506,7 @@ __device__ __forceinline__ void lm_update(const ROW& row, int64_t n, const LmRow
         row_store<T>(row, n, 3, pxy - (w00 * w10 + w01 * w11));
         row_store<T>(row, n, 4, pyy - (w10 * w10 + w11 * w11));
     }
-    lw += (T)-0.5 * (y0 * y0 + y1 * y1) - log(u00 * u11) - (T)1.8378770664093453;   // log(2 pi)
+    lw += (T)-0.5 * (y0 * y0 + y1 * y1) - m_log<T>(u00 * u11) - (T)1.8378770664093453;   // log(2 pi)
 }
 
 // The m known-id observations of one particle at pose (x, y, phi), in order: F2 on a landmark the filter has seen,
@@ -422,6 +535,7 @@ __device__ __forceinline__ const T* obs_src(const T* lm0, const T* lm1, const in
 // a record is touched once per step, 5 GB of other records pass before it is touched again.
 // (slam_pf_create bounds n so that 5 n sizeof(T) fits 32 bits.)
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 template <typename T>
 __device__ __forceinline__ auto lm_rsrc(const T* base, int64_t n) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), (short)0, (int)(uint32_t)(5 * n * (int64_t)sizeof(T)), 0x00020000);
@@ -502,6 +616,9 @@ struct KnownRing {
     __device__ __forceinline__ void run(T* lm0, T* lm1, const int32_t* __restrict__ tabs, int64_t n, uint32_t p,
                                         const T* s_obs, const int32_t* s_ids, const int32_t* s_meta, int m, T x, T y, T phi,
                                         T R00, T R10, T R01, T R11, bool valid, T& lw) {
+#if defined(SLAMHIP_EXPERIMENTS) && defined(PF_EXP_NOOBS)           // timing experiment: no map updates
+        m = 0;
+#endif
         for (int i0 = 0; i0 < m; i0 += PF_DEPTH) {
 #pragma unroll
             for (int u = 0; u < PF_DEPTH; ++u) {
@@ -554,15 +671,23 @@ __device__ __forceinline__ void step_core(T* __restrict__ pose, T* lm0, T* lm1, 
     known.start(lm0, lm1, tabs, n, (uint32_t)p, s_ids, s_meta, m);      // the first records are in flight during the motion model
     if (PREDICT) {
         T e1, e2;
+#if defined(SLAMHIP_EXPERIMENTS) && defined(PF_EXP_NOPREDICT)       // timing experiment: no noise
+        e1 = (T)0.1; e2 = (T)-0.1;
+#else
         normals2<T>((uint64_t)(first + p), step, STREAM_PREDICT, seed, e1, e2);
+#endif
         const T Vn = V + sigV * e1;                       // sim/sim-utils.jl:36
         const T Gn = G + sigG * e2;                       // :37
-        const T xn = x + Vn * dt * cos(Gn + phi);         // src/ekf.jl:39-41
-        const T yn = y + Vn * dt * sin(Gn + phi);
-        const T pn = wrap_pi<T>(phi + Vn * dt * sin(Gn) / wheelbase);
+        T sgp, cgp, sg, cg;
+        m_sincos<T>(Gn + phi, sgp, cgp);
+        m_sincos<T>(Gn, sg, cg);
+        const T xn = x + Vn * dt * cgp;                   // src/ekf.jl:39-41
+        const T yn = y + Vn * dt * sgp;
+        const T pn = wrap_pi<T>(phi + Vn * dt * sg / wheelbase);
         x = xn; y = yn; phi = pn;
         if (valid) { pose[p] = x; pose[n + p] = y; pose[2 * n + p] = phi; }
     }
+    PF_XS(3);
     known.run(lm0, lm1, tabs, n, (uint32_t)p, s_obs, s_ids, s_meta, m, x, y, phi, R00, R10, R01, R11, valid, lw);
     if (valid) logw[p] = lw;
 }
@@ -606,11 +731,13 @@ __device__ __forceinline__ void proposal_core(T* __restrict__ pose, T* lm0, T* l
                                               T pend, int64_t p, bool valid, T& xo, T& yo, T& po, T& lwo) {
     const T x = pose[p], y = pose[n + p], phi = pose[2 * n + p];
     // motion mean (w = 0) and GL = Gu Lq
-    const T s = sin(G + phi), c = cos(G + phi);
+    T s, c, sG, cG;
+    m_sincos<T>(G + phi, s, c);
+    m_sincos<T>(G, sG, cG);
     const T vts = V * dt * s, vtc = V * dt * c;
     const T xm = x + vtc, ym = y + vts;
-    const T pm = wrap_pi<T>(phi + V * dt * sin(G) / wheelbase);
-    const T gu20 = dt * sin(G) / wheelbase, gu21 = V * dt * cos(G) / wheelbase;
+    const T pm = wrap_pi<T>(phi + V * dt * sG / wheelbase);
+    const T gu20 = dt * sG / wheelbase, gu21 = V * dt * cG / wheelbase;
     const T gl00 = dt * c * lq00 + (-vts) * lq10, gl01 = (-vts) * lq11;
     const T gl10 = dt * s * lq00 + vtc * lq10, gl11 = vtc * lq11;
     const T gl20 = gu20 * lq00 + gu21 * lq10, gl21 = gu21 * lq11;
@@ -637,7 +764,7 @@ __device__ __forceinline__ void proposal_core(T* __restrict__ pose, T* lm0, T* l
         const T b00 = -(h00 * gl00 + h01 * gl10), b01 = -(h00 * gl01 + h01 * gl11);
         const T b10 = -(h10 * gl00 + h11 * gl10) - gl20, b11 = -(h10 * gl01 + h11 * gl11) - gl21;
         const T v0 = (r - d) - (b00 * mu0 + b01 * mu1);
-        const T v1 = wrap_pi<T>(b - (atan2(dy, dx) - pm)) - (b10 * mu0 + b11 * mu1);
+        const T v1 = wrap_pi<T>(b - (m_atan2<T>(dy, dx) - pm)) - (b10 * mu0 + b11 * mu1);
         const T t00 = cur.pxx * h00 + cur.pxy * h01, t01 = cur.pxx * h10 + cur.pxy * h11;      // Pf Hf'
         const T t10 = cur.pxy * h00 + cur.pyy * h01, t11 = cur.pxy * h10 + cur.pyy * h11;
         const T f00 = h00 * t00 + h01 * t10 + R00;                                            // Sf, symmetrised
@@ -671,7 +798,7 @@ __device__ __forceinline__ void proposal_core(T* __restrict__ pose, T* lm0, T* l
         g00 = g00 - (w00 * w00 + w01 * w01);
         g01 = g01 - (w00 * w10 + w01 * w11);
         g11 = g11 - (w10 * w10 + w11 * w11);
-        lw += (T)-0.5 * (y0 * y0 + y1 * y1) - log(u00 * u11) - (T)1.8378770664093453;
+        lw += (T)-0.5 * (y0 * y0 + y1 * y1) - m_log<T>(u00 * u11) - (T)1.8378770664093453;
     }
     // w ~ N(mu, Sig), the control, the pose
     T e1, e2;
@@ -683,9 +810,12 @@ __device__ __forceinline__ void proposal_core(T* __restrict__ pose, T* lm0, T* l
     const T w1 = mu1 + l10 * e1 + l11 * e2;
     const T Vn = V + lq00 * w0;
     const T Gn = G + (lq10 * w0 + lq11 * w1);
-    const T xn = x + Vn * dt * cos(Gn + phi);         // src/ekf.jl:39-41
-    const T yn = y + Vn * dt * sin(Gn + phi);
-    const T pn = wrap_pi<T>(phi + Vn * dt * sin(Gn) / wheelbase);
+    T sgp, cgp, sgn, cgn;
+    m_sincos<T>(Gn + phi, sgp, cgp);
+    m_sincos<T>(Gn, sgn, cgn);
+    const T xn = x + Vn * dt * cgp;                   // src/ekf.jl:39-41
+    const T yn = y + Vn * dt * sgp;
+    const T pn = wrap_pi<T>(phi + Vn * dt * sgn / wheelbase);
     if (valid) { pose[p] = xn; pose[n + p] = yn; pose[2 * n + p] = pn; logw[p] = lw; }
     T unused = 0;
     apply_known<T>(lm0, lm1, tabs, n, p, s_obs, s_ids, s_meta, m, xn, yn, pn, R00, R10, R01, R11, valid, unused);
@@ -1136,12 +1266,12 @@ __global__ __launch_bounds__(256) void pf_materialise_kernel(T* lm0, T* lm1, con
 // device-resident control block (PfCtl) and a per-landmark state word:
 //   * every workgroup of the step kernel plans the observation codes itself, in LDS, from the state words (the host's
 //     pf_stage, a few dozen integer operations);
-//   * the per-block weight statistics are stored write-through (sc1) and the workgroup that arrives LAST at a counter
-//     folds them, forms shift / Neff / the decision, applies the state transitions of this step's observations and, if
-//     the filter resamples and lives wholly on this shard, prepares the lazy resampling (table list, fresh table,
-//     buffer flips) -- pf_auto_tail.  No release/acquire fence (an L2 write-back + invalidate on this multi-XCD part)
-//     is involved: write-through stores, every storing wave's vmcnt(0), one agent-scope counter add per workgroup, and
-//     sc1 loads in the workgroup whose add came last (MI355X guide, "Valid forms");
+//   * the per-block weight statistics are stored write-through (sc1) as one tagged 64-byte line per workgroup and the
+//     workgroup that is dispatched LAST collects them (polling until every line's tag fits, see part_key), folds them,
+//     forms shift / Neff / the decision, applies the state transitions of this step's observations and, if the filter
+//     resamples and lives wholly on this shard, prepares the lazy resampling (table list, fresh table, buffer flips)
+//     -- pf_auto_tail.  No release/acquire fence (an L2 write-back + invalidate on this multi-XCD part), no drain of
+//     the storing waves and no arrival counter is involved;
 //   * two conditional kernels follow every step (cdf; ancestors + lazy apply) and return at once unless the control
 //     block says that THIS step resamples.
 // A sharded filter (or an exhausted table pool) cannot resample on the device: the tail then records a HALT, the steps
@@ -1170,19 +1300,25 @@ struct PfAutoArgs {
     unsigned int step;
     int m, nl, force, lazy_ok, rank, world;
     double V, G, wheelbase, a0, a1, a2, dt, R00, R10, R01, R11, neff_frac;
-    const double* z;
-    const int32_t* ids;
     double* part;
     PfCtl* ctl;
     int32_t* lmstate;
     PfMirror* mir;
     double* xchg;
+    // The step's observations travel IN the kernel arguments (1.3 KB of the 4 KB a launch may carry): every one of the
+    // ~1000 workgroups reads them at its start, and from a pinned host page (the zero-copy staging of the legacy
+    // calls) that is ~5000 64-byte reads across PCIe per step -- measured: 19 us of a 46 us kernel before the first
+    // landmark record moves.  The argument segment is read through the scalar/L2 caches like any other constant.
+    double z[2 * PF_AUTO_MAXOBS];
+    int32_t ids[PF_AUTO_MAXOBS];
 };
+static_assert(sizeof(PfAutoArgs) <= 4096, "kernel argument segment");
 
 // The planning of pf_stage on the device: observation i of landmark l = ids[i] - 1 gets its code (landmark, first
 // sighting / repeat of a first sighting) and its meta word (where the record is read and written) from the landmark's
 // state word; a repeat inside the call sees the state its first occurrence leaves behind.
-__device__ __forceinline__ void plan_obs(const int32_t* __restrict__ ids, const int32_t* __restrict__ lmstate, int m, int32_t* s_l,
+template <typename IdPtr>
+__device__ __forceinline__ void plan_obs(IdPtr ids, const int32_t* __restrict__ lmstate, int m, int32_t* s_l,
                                          int32_t* s_st, int32_t* s_ids, int32_t* s_meta, int32_t* s_first) {
     const int tid = threadIdx.x;
     if (tid < m) {
@@ -1231,7 +1367,7 @@ __device__ __forceinline__ void block_reduce6(double (&v)[6], double (*sh6)[6]) 
     for (int i = 0; i < 6; ++i) v[i] = sh6[0][i] + sh6[1][i] + sh6[2][i] + sh6[3][i];
 }
 
-// Runs in the workgroup whose arrival came last (all 256 threads).  s_l / s_st / s_first: this step's plan (LDS).
+// Runs in the launch's last workgroup, after its own share of the sweep (all 256 threads).  s_l / s_st / s_first: this step's plan (LDS).
 template <typename T>
 __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t* s_l, const int32_t* s_st, const int32_t* s_first) {
     __shared__ double sh[4];
@@ -1242,23 +1378,46 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
     const int tid = threadIdx.x;
     PfCtl* ctl = a.ctl;
     const int nblocks = (int)gridDim.x;
-    if (tid == 0) ctl->stamps[1] = wall_clock64();
     // Every global load of the tail -- the table reference counts, this thread's landmark state words, its share of the
     // partials -- is issued up front: the memory system is still draining the sweep's stores and a load takes microseconds
     // to come back, so the tail pays that latency once, not once per phase.
     const int my_tref = tid < PF_TAB_MAX ? ctl->tref[tid] : 0;
     const int identity0 = ctl->identity;                      // landmarks without a table before this step
+    const unsigned long long key = part_key(a.seq);
+    const unsigned long long t_poll = wall_clock64();
+    if (tid == 0) ctl->stamps[6] = t_poll;                    // the collecting workgroup has done its own share
+    int rounds = 0;
+    __shared__ int s_perr;
+    if (tid == 0) s_perr = 0;
+    __syncthreads();
+    // This thread's four lines of 1024, polled until their tags fit (see part_key): 32 agent-scope loads in flight per try.
+    // A line beyond the grid reads as {-inf, 0, ...}.
     double q[4][7];
+    auto qv = [&](int u, int i) { return q[u][i]; };
+    auto collect = [&](int base) {
+        for (;;) {
+            bool ok = true;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int b = tid + 256 * u;
+            for (int u = 0; u < 4; ++u) {
+                const int b = base + tid + 256 * u;
+                unsigned long long tag = 0;
 #pragma unroll
-        for (int i = 0; i < 7; ++i) q[u][i] = b < nblocks ? ld_sc1(a.part + (size_t)b * 8 + i) : (i == 0 ? -__builtin_inf() : 0.0);
-    }
+                for (int i = 0; i < 7; ++i) q[u][i] = b < nblocks ? ld_sc1(a.part + (size_t)b * 8 + i) : (i == 0 ? -__builtin_inf() : 0.0);
+                if (b < nblocks) tag = ld_sc1(reinterpret_cast<const unsigned long long*>(a.part + (size_t)b * 8 + 7));
+                if (b < nblocks && (part_hash(q[u]) ^ tag) != key) ok = false;
+            }
+            ++rounds;
+            if (ok) break;
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t_poll > 200000000ull) { atomicOr(&s_perr, 1); break; }      // 2 s at 100 MHz: give up, report
+        }
+    };
+    collect(0);
     if (tid < PF_TAB_MAX) s_tref[tid] = my_tref;
     if (tid == 0) s_i[0] = identity0;
     __syncthreads();
-    if (tid == 0) ctl->stamps[6] = wall_clock64();
+    if (tid == 0) ctl->stamps[1] = wall_clock64();            // every workgroup's statistics are in
+    if (tid == 0) ctl->stamps[7] = ctl->stamps[0] + 100ull * (unsigned long long)rounds;      // (diagnostic: polls of thread 0)
     // ---- this step's state transitions (what pf_stage does on the host): one thread per observation; the state word
     //      of every observed landmark is still in LDS from the plan ----
     if (tid < a.m && s_first[tid]) {
@@ -1273,17 +1432,9 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
     // ---- fold the write-through partials (the order of fold_partials); 1024 records per pass ----
     double M = -__builtin_inf();
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    if (tid == 0) ctl->stamps[7] = wall_clock64();
     for (int base = 0; base < nblocks; base += 1024) {
-        if (base > 0) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int b = base + tid + 256 * u;
-#pragma unroll
-                for (int i = 0; i < 7; ++i) q[u][i] = b < nblocks ? ld_sc1(a.part + (size_t)b * 8 + i) : (i == 0 ? -__builtin_inf() : 0.0);
-            }
-        }
-        double m = fmax(fmax(q[0][0], q[1][0]), fmax(q[2][0], q[3][0]));
+        if (base > 0) collect(base);
+        double m = fmax(fmax(qv(0, 0), qv(1, 0)), fmax(qv(2, 0), qv(3, 0)));
         m = block_reduce(m, sh, true);
         const double Mn = fmax(M, m);
         const double fo = M == -__builtin_inf() ? 0.0 : exp(M - Mn);              // rescale what earlier passes summed
@@ -1291,17 +1442,17 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
         M = Mn;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const double f = q[u][0] == -__builtin_inf() ? 0.0 : exp(q[u][0] - M);
-            acc[0] += q[u][1] * f;
-            acc[1] += q[u][2] * f * f;
-            acc[2] += q[u][3] * f; acc[3] += q[u][4] * f; acc[4] += q[u][5] * f; acc[5] += q[u][6] * f;
+            const double f = qv(u, 0) == -__builtin_inf() ? 0.0 : exp(qv(u, 0) - M);
+            acc[0] += qv(u, 1) * f;
+            acc[1] += qv(u, 2) * f * f;
+            acc[2] += qv(u, 3) * f; acc[3] += qv(u, 4) * f; acc[4] += qv(u, 5) * f; acc[5] += qv(u, 6) * f;
         }
     }
     block_reduce6(acc, s_r6);
     if (tid == 0) {
         ctl->stamps[2] = wall_clock64();
         double gM = M, gs1 = acc[0], gs2 = acc[1];
-        int err = 0;
+        int err = s_perr;                                     // a workgroup's statistics never came: halt and report
         if (a.world > 1) {
             // all-gather of (max, sum, sum2) through the ranks' shared page: two parities (a rank is at most one
             // step ahead of the slowest), the sequence number is written last
@@ -1391,7 +1542,6 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
         } else if (outcome == 2) {
             ctl->halt_seq = a.seq;
         }
-        __hip_atomic_store(&ctl->arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed
         // what the host may read without synchronising
         // Write-through system-scope stores, drained, then the sequence number: no fence (a system-scope release would
         // write back this XCD's whole L2, which the sweep has just filled with dirty landmark records).
@@ -1410,17 +1560,29 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
     }
 }
 
+// (four waves per SIMD: at C4 the whole grid -- 1024 workgroups -- is then resident at once; one register more than 128
+//  and a quarter of the workgroups start when the first ones end, which was measured as +10 us per step)
 template <typename T, bool PROPOSAL>
-__global__ __launch_bounds__(256) void pf_auto_step_kernel(PfAutoArgs a) {
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void pf_auto_step_kernel(PfAutoArgs a) {
     PfCtl* ctl = a.ctl;
+    PF_XS(0);
+    PF_WG(0);
+#if defined(SLAMHIP_EXPERIMENTS) && defined(PF_EXP_STAMPS)
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_xs[7] = wall_clock64();
+#endif
     if (ctl->halt_seq != 0) return;                    // an earlier step waits for the host: the host replays this one
+    PF_XS(1);
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->stamps[0] = wall_clock64();
     __shared__ T s_obs[2 * PF_AUTO_MAXOBS];          // the observations in the state dtype: converted once per workgroup
     __shared__ int32_t s_ids[PF_AUTO_MAXOBS], s_meta[PF_AUTO_MAXOBS], s_l[PF_AUTO_MAXOBS], s_st[PF_AUTO_MAXOBS], s_first[PF_AUTO_MAXOBS];
-    __shared__ int s_last;
     const int m = a.m;
-    for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) s_obs[i] = (T)a.z[i];
-    plan_obs(a.ids, a.lmstate, m, s_l, s_st, s_ids, s_meta, s_first);
+    // the observations: read from the argument segment itself (constant address space, dynamic index) -- going through
+    // the by-value copy `a` would put the whole 1.3 KB struct into scratch memory
+    typedef const __attribute__((address_space(4))) PfAutoArgs* KargPtr;
+    const KargPtr ka = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) s_obs[i] = (T)ka->z[i];
+    plan_obs(&ka->ids[0], a.lmstate, m, s_l, s_st, s_ids, s_meta, s_first);
+    PF_XS(2);
     const int pcur = ctl->pcur, tside = ctl->tside;
     const T pend = (T)ctl->shift_next;
     T* pose = (T*)(pcur ? a.pose1 : a.pose0);
@@ -1438,14 +1600,14 @@ __global__ __launch_bounds__(256) void pf_auto_step_kernel(PfAutoArgs a) {
         step_core<T, true>(pose, (T*)a.lm0, (T*)a.lm1, tabs, (T*)a.logw, n, a.first, a.step, a.seed, (T)a.V, (T)a.G, (T)a.wheelbase,
                            (T)a.a0, (T)a.a1, (T)a.dt, s_obs, s_ids, s_meta, m, (T)a.R00, (T)a.R10, (T)a.R01, (T)a.R11, pend, p, valid, x,
                            y, phi, lw);
-    block_weight_stats<T, true>(lw, x, y, phi, valid, 1, a.part);
-    if (threadIdx.x == 0) {
-        // the partials were stored write-through by this lane: drain them, then arrive
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_last = __hip_atomic_fetch_add(&ctl->arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
-    }
-    __syncthreads();
-    if (s_last) pf_auto_tail<T>(a, s_l, s_st, s_first);
+    PF_XS(4);
+    PF_WG(1);
+    block_weight_stats<T, true>(lw, x, y, phi, valid, 1, a.part, a.seq);          // a tagged line, not waited for
+    PF_XS(5);
+    PF_WG(2);
+    // the workgroup that is dispatched last collects the lines (every other workgroup has been dispatched before it and
+    // finishes without it: the wait cannot deadlock, and it ends on a time-out)
+    if (blockIdx.x == gridDim.x - 1) pf_auto_tail<T>(a, s_l, s_st, s_first);
 }
 
 // The cdf of the step that resamples (pf_scan1_kernel behind the control block's gate).
@@ -1581,8 +1743,6 @@ extern "C" int slam_pf_destroy(slam_pf_t h) {
                     h->d_ctl, h->d_lmstate};
     if (h->xchg_host) (void)hipHostUnregister(h->xchg_host);
     if (h->h_mir) (void)hipHostFree(h->h_mir);
-    if (h->h_auto_obs) (void)hipHostFree(h->h_auto_obs);
-    if (h->h_auto_ids) (void)hipHostFree(h->h_auto_ids);
     for (void* p : devs)
         if (p) (void)hipFree(p);
     if (h->h_ids) (void)hipHostFree(h->h_ids);
@@ -1634,10 +1794,6 @@ static int pf_create_impl(slam_pf* h) {
     HIP_TRY(hipHostMalloc((void**)&h->h_mir, sizeof(PfMirror), hipHostMallocDefault));
     memset(h->h_mir, 0, sizeof(PfMirror));
     HIP_TRY(hipHostGetDevicePointer((void**)&h->h_mir_dev, h->h_mir, 0));
-    HIP_TRY(hipHostMalloc((void**)&h->h_auto_obs, sizeof(double) * 2 * PF_AUTO_MAXOBS * PF_LOG, hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void**)&h->h_auto_ids, sizeof(int32_t) * PF_AUTO_MAXOBS * PF_LOG, hipHostMallocDefault));
-    HIP_TRY(hipHostGetDevicePointer((void**)&h->h_auto_obs_dev, h->h_auto_obs, 0));
-    HIP_TRY(hipHostGetDevicePointer((void**)&h->h_auto_ids_dev, h->h_auto_ids, 0));
     // uniform weights over the GLOBAL particle set
     const double lw = -log((double)h->n_global);
     PF_DISPATCH(h,
@@ -1681,7 +1837,6 @@ extern "C" int slam_pf_create(slam_pf_t* out, int dtype, int64_t n_local, int64_
     h->d_part = h->d_out = h->h_out = h->d_cdf = h->d_bsum = nullptr; h->d_src = nullptr; h->d_anc = nullptr;
     h->seen.assign(max_landmarks, 0);
     h->d_ctl = nullptr; h->d_lmstate = nullptr; h->h_mir = h->h_mir_dev = nullptr;
-    h->h_auto_obs = h->h_auto_obs_dev = nullptr; h->h_auto_ids = h->h_auto_ids_dev = nullptr;
     h->auto_on = 0; h->auto_seq = 0; h->nresamples = 0; h->halted = 0; h->halt_gmax = 0.0; h->last_resampled_seq = 0;
     h->d_xchg = nullptr; h->xchg_host = nullptr; h->xchg_rank = 0; h->xchg_world = 1;
     for (int i = 0; i < 4; ++i) h->last_out[i] = 0.0;
@@ -2387,12 +2542,9 @@ static int pf_auto_import(slam_pf* h, bool halted) {
 }
 
 static int pf_auto_enqueue(slam_pf* h, const PfStepRec& r) {
-    const int slot = (int)(r.seq % PF_LOG);
-    double* hz = h->h_auto_obs + (size_t)slot * 2 * PF_AUTO_MAXOBS;
-    int32_t* hi = h->h_auto_ids + (size_t)slot * PF_AUTO_MAXOBS;
-    for (int i = 0; i < r.m; ++i) { hz[2 * i] = r.z[2 * i]; hz[2 * i + 1] = r.z[2 * i + 1]; hi[i] = r.ids[i]; }
     PfAutoArgs a;
     memset(&a, 0, sizeof(a));
+    for (int i = 0; i < r.m; ++i) { a.z[2 * i] = r.z[2 * i]; a.z[2 * i + 1] = r.z[2 * i + 1]; a.ids[i] = r.ids[i]; }
     a.pose0 = h->pose[0]; a.pose1 = h->pose[1]; a.lm0 = h->lm[0]; a.lm1 = h->lm[1]; a.logw = h->logw;
     a.tab0 = h->d_tab[0]; a.tab1 = h->d_tab[1];
     a.n = h->n; a.first = h->first; a.n_global = h->n_global; a.seq = r.seq;
@@ -2408,8 +2560,6 @@ static int pf_auto_enqueue(slam_pf* h, const PfStepRec& r) {
     }
     a.R00 = r.R[0]; a.R10 = r.R[1]; a.R01 = r.R[2]; a.R11 = r.R[3];
     a.neff_frac = r.neff_frac;
-    a.z = h->h_auto_obs_dev + (size_t)slot * 2 * PF_AUTO_MAXOBS;
-    a.ids = h->h_auto_ids_dev + (size_t)slot * PF_AUTO_MAXOBS;
     a.part = h->d_part; a.ctl = h->d_ctl; a.lmstate = h->d_lmstate; a.mir = h->h_mir_dev; a.xchg = h->d_xchg;
     const dim3 grid(grid_for(h->n));
     if (h->dtype == SLAM_F32) {
@@ -2696,8 +2846,9 @@ extern "C" int slam_pf_get_weights(slam_pf_t h, double* w) {
     return SLAM_OK;
 }
 
-/* Diagnostics: 100 MHz wall-clock stamps of the LAST auto step: [0] kernel start, [1] the last workgroup has arrived,
- * [2] statistics folded, [3] decision taken, [4] bookkeeping done, [5] published.  Waits for the queue. */
+/* Diagnostics: 100 MHz wall-clock stamps of the LAST auto step: [0] kernel start, [1] every workgroup's statistics are in,
+ * [2] statistics folded, [3] decision taken, [4] bookkeeping done, [5] published, [6] the collecting workgroup has done
+ * its own share, [7] = [0] + 100 x its number of polls.  Waits for the queue. */
 extern "C" int slam_pf_debug_stamps(slam_pf_t h, uint64_t out[8]) {
     ARG_CHECK(h != nullptr && out != nullptr, "null argument");
     HIP_TRY(hipSetDevice(h->device));
@@ -2707,5 +2858,26 @@ extern "C" int slam_pf_debug_stamps(slam_pf_t h, uint64_t out[8]) {
     PfCtl c;
     HIP_TRY(hipMemcpy(&c, h->d_ctl, sizeof(c), hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; ++i) out[i] = c.stamps[i];
+#if defined(SLAMHIP_EXPERIMENTS) && defined(PF_EXP_STAMPS)
+    unsigned long long xs[8];
+    HIP_TRY(hipMemcpyFromSymbol(xs, HIP_SYMBOL(g_xs), sizeof(xs)));
+    const unsigned long long t0 = c.stamps[0];
+    fprintf(stderr, "[pf stamps, us from workgroup 0's start] mid workgroup:");
+    for (int i = 0; i < 8; ++i) fprintf(stderr, " %.2f", ((double)xs[i] - (double)t0) * 0.01);
+    fprintf(stderr, "\n");
+    {
+        static unsigned long long wg[3][4096];
+        HIP_TRY(hipMemcpyFromSymbol(wg, HIP_SYMBOL(g_wg), sizeof(wg)));
+        const int nb = grid_for(h->n) < 4096 ? grid_for(h->n) : 4096;
+        for (int k = 0; k < 3; ++k) {
+            fprintf(stderr, "[pf wg %s, us] by block index, every 64th:", k == 0 ? "start" : k == 1 ? "updates done" : "stats stored");
+            for (int b = 0; b < nb; b += 64) fprintf(stderr, " %.1f", ((double)wg[k][b] - (double)t0) * 0.01);
+            fprintf(stderr, " | last: %.1f", ((double)wg[k][nb - 1] - (double)t0) * 0.01);
+            double mx = -1e30, mn = 1e30; int imx = 0;
+            for (int b = 0; b < nb; ++b) { const double v = ((double)wg[k][b] - (double)t0) * 0.01; if (v > mx) { mx = v; imx = b; } if (v < mn) mn = v; }
+            fprintf(stderr, " | min %.1f max %.1f (block %d)\n", mn, mx, imx);
+        }
+    }
+#endif
     return SLAM_OK;
 }

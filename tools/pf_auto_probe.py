@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Where does an auto step spend its time?  C4-sized filter: per-step wall time with the queue kept full, and the
-in-kernel stamps of the last step (kernel start -> last arrival -> folded -> decided -> bookkeeping -> published)."""
+in-kernel stamps of the last step (kernel start -> statistics collected -> folded -> decided -> bookkeeping -> published;
+[6] the collecting workgroup done with its own share, [7] its number of polls)."""
 import math, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
