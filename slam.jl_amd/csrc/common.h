@@ -145,7 +145,7 @@ int launch_pack(slam_ekf* h, const void* d_src, int lds, int n);     // column-m
 int launch_unpack(slam_ekf* h, void* d_dst, int ldd, int n);        // the full symmetric n x n matrix, column-major (device)
 int launch_predict(slam_ekf* h, double v, double g, double w, const double Q[4], double dt);
 int launch_augment(slam_ekf* h, int nn, const double R[4], const double* zn_dev);   // zn already on the device (obsbuf or znbuf)
-int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gate2, const double* z_src, bool compact);
+int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gate2, const double* z_host, bool compact);
 // z_src: device-readable (obsbuf or pinned host); compact (observe()): d_assoc -> idfbuf/obsbuf (matched, in order),
 // znbuf (new), d_count = {m, nn}, h_assoc (pinned) -- done by the last gate_final launch
 int ensure_pmax(slam_ekf* h);       // the pre-gate's variance bound is current

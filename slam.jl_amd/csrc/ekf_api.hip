@@ -510,8 +510,8 @@ extern "C" int slam_ekf_associate(slam_ekf_t h, const double* z, int nz, const d
         return SLAM_OK;
     }
     HIP_TRY(hipSetDevice(h->device));
-    if ((rc = stage_obs(h, z, nullptr, nz))) return rc;
-    if ((rc = launch_gate(h, nz, R, gate1, gate2, h->obsbuf, false))) return rc;
+    if ((rc = ensure_obs_capacity(h, nz))) return rc;
+    if ((rc = launch_gate(h, nz, R, gate1, gate2, z, false))) return rc;       // (z travels in the kernel arguments)
     HIP_TRY(hipMemcpyAsync(h->h_assoc, h->d_assoc, sizeof(int32_t) * (size_t)nz, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     memcpy(assoc, h->h_assoc, sizeof(int32_t) * (size_t)nz);
@@ -619,15 +619,10 @@ extern "C" int slam_ekf_observe(slam_ekf_t h, const double* z, int nz, const dou
     }
     if ((rc = ensure_update_workspace(h, nz))) return rc;
     if ((rc = ensure_obs_capacity(h, nz))) return rc;
-    // zero-copy staging: the kernels read z from, and write the decisions to, pinned host memory -- no blit
-    // kernels on the critical path.  The pinned buffers are free again once the compaction kernel has run.
-    if (h->stage_pending) {
-        HIP_TRY(hipEventSynchronize(h->stage_ev));
-        h->stage_pending = 0;
-    }
-    memcpy(h->h_obs, z, sizeof(double) * 2 * (size_t)nz);
+    // No staging copy: z travels in the gating kernel's arguments (its first workgroup leaves the device copy the
+    // compaction, the update and add_features read); the decisions come back through pinned host memory.
     h->obs_seq = h->obs_seq == 0x7fffffff ? 1 : h->obs_seq + 1;
-    if ((rc = launch_gate(h, nz, R, gate1, gate2, h->h_obs_dev, true))) return rc;      // gating + compaction
+    if ((rc = launch_gate(h, nz, R, gate1, gate2, z, true))) return rc;      // gating + compaction
     if ((rc = launch_update(h, nz, R, form, true))) return rc;
     // Wait for the decisions only (the update runs on behind them): the compaction publishes this call's sequence
     // number in pinned memory after the association vector.  The stream is queried now and then so that a failed

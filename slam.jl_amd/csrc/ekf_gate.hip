@@ -138,9 +138,18 @@ __device__ inline PreGate pre_gate(double dx, double dy, const double* pvv, doub
     return g;
 }
 
+// The observations of one launch travel IN the kernel arguments (2 KB of the 4 KB a launch may carry): every workgroup
+// needs all of them at its start, and reading them from the pinned host page the caller's z was staged in meant a few
+// thousand 64-byte reads across PCIe per sweep, on the critical path of a 9 us kernel.  First parameter: the kernel
+// indexes the argument segment itself (a dynamic index into the by-value copy would move the struct to scratch).
+constexpr int GATE_CHUNK = 128;        // observations per launch
+struct GateObs {
+    double z[2 * GATE_CHUNK];
+};
+
 template <typename T>
-__global__ __launch_bounds__(GATE_BLOCK * OBS_WAVES) void gate_kernel(const T* __restrict__ x, const T* __restrict__ P, int ld,
-                                                           int N, const double* __restrict__ z, int nz, double R0,
+__global__ __launch_bounds__(GATE_BLOCK * OBS_WAVES) void gate_kernel(GateObs zarg, const T* __restrict__ x, const T* __restrict__ P,
+                                                           int ld, int N, double* __restrict__ zdev, int nz, double R0,
                                                            double R1, double R2, double R3, double gate1, double gate2,
                                                            double* __restrict__ part, const double* __restrict__ pmax_ptr,
                                                            int pregate, int tlog) {
@@ -151,7 +160,13 @@ __global__ __launch_bounds__(GATE_BLOCK * OBS_WAVES) void gate_kernel(const T* _
     const int lane = tid & 63;
     const int wave = tid >> 6;
     constexpr int NT = GATE_BLOCK * OBS_WAVES;
-    for (int i = tid; i < 2 * nz; i += NT) zs[i] = z[i];
+    typedef const __attribute__((address_space(4))) GateObs* KargPtr;
+    const KargPtr ka = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    for (int i = tid; i < 2 * nz; i += NT) {
+        const double v = ka->z[i];
+        zs[i] = v;
+        if (blockIdx.x == 0) zdev[i] = v;            // the device copy the compaction, the update and add_features read
+    }
 
     const double R[4] = {R0, R1, R2, R3};
     double pose[3] = {(double)x[0], (double)x[1], (double)x[2]};
@@ -228,8 +243,8 @@ __global__ __launch_bounds__(GATE_BLOCK * OBS_WAVES) void gate_kernel(const T* _
 // One wave walks the observations in order, 64 at a time: matched ones (assoc >= 1) are compacted to the front
 // of zbuf/idf (zsrc may BE zbuf: a write position never passes the read position of a later chunk), new ones
 // (assoc < 0) go to zn.  count = {matched, new}.  Order is the observation order, as in data-association.jl:43-47.
-__device__ __forceinline__ void compact_wave(const int32_t* assoc, int nz, const double* __restrict__ zsrc,
-                                             double* __restrict__ zbuf, int32_t* __restrict__ idf,
+__device__ __forceinline__ void compact_wave(const int32_t* assoc, int nz, const double* zsrc,
+                                             double* zbuf, int32_t* __restrict__ idf,
                                              double* __restrict__ zn, int32_t* __restrict__ count,
                                              int32_t* __restrict__ assoc_host, int lane, int32_t* __restrict__ flag_host,
                                              int32_t seq) {
@@ -274,7 +289,7 @@ __device__ __forceinline__ void compact_wave(const int32_t* assoc, int nz, const
 // assoc[0 .. compact_total) into the update's inputs: no extra launch, and the fold stays nz-way parallel.
 __global__ __launch_bounds__(64) void gate_final_kernel(
     const double* __restrict__ part, int nblocks, int nz, int32_t* assoc, int32_t* assoc_all,     // (the two alias)
-    int compact_total, const double* __restrict__ zsrc, double* __restrict__ zbuf, int32_t* __restrict__ idf,
+    int compact_total, const double* zsrc, double* zbuf, int32_t* __restrict__ idf,
     double* __restrict__ zn, int32_t* __restrict__ count, int32_t* __restrict__ assoc_host, int32_t* arrive,
     int32_t* __restrict__ flag_host, int32_t seq) {
     const int i = blockIdx.x;
@@ -376,7 +391,8 @@ int ensure_pmax(slam_ekf* h) {
     return SLAM_OK;
 }
 
-int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gate2, const double* z_src, bool compact) {
+// z_host: the caller's observations (host memory).  The sweep leaves a device copy in h->obsbuf.
+int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gate2, const double* z_host, bool compact) {
     const int nblocks = (h->N + GATE_BLOCK - 1) / GATE_BLOCK;
     if (nblocks > h->gate_blocks_cap) {
         slam_set_error("internal: gate partial buffer too small");
@@ -396,19 +412,21 @@ int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gat
         if (rcp) return rcp;
     }
     // observations are swept in chunks so the LDS footprint stays bounded for any nz
-    constexpr int CHUNK = 256;
+    constexpr int CHUNK = GATE_CHUNK;
     for (int o = 0; o < nz; o += CHUNK) {
         const int cz = nz - o < CHUNK ? nz - o : CHUNK;
         const size_t shmem = (size_t)(2 * cz + 3 * GATE_WAVES * cz) * sizeof(double);
-        const double* zc = z_src + 2 * (size_t)o;
+        GateObs zarg;
+        memcpy(zarg.z, z_host + 2 * (size_t)o, sizeof(double) * 2 * (size_t)cz);
+        double* zc = h->obsbuf + 2 * (size_t)o;
         {
             KTimer t(h, SLAM_K_GATE);
             if (h->dtype == SLAM_F32)
-                hipLaunchKernelGGL(gate_kernel<float>, dim3(nblocks), dim3(GATE_BLOCK * OBS_WAVES), shmem, h->stream,
+                hipLaunchKernelGGL(gate_kernel<float>, dim3(nblocks), dim3(GATE_BLOCK * OBS_WAVES), shmem, h->stream, zarg,
                                    (const float*)h->x, (const float*)h->P, h->ld, h->N, zc, cz, R[0], R[1], R[2], R[3],
                                    gate1, gate2, h->gate_part, (const double*)h->d_pmax, pregate, 7);
             else
-                hipLaunchKernelGGL(gate_kernel<double>, dim3(nblocks), dim3(GATE_BLOCK * OBS_WAVES), shmem, h->stream,
+                hipLaunchKernelGGL(gate_kernel<double>, dim3(nblocks), dim3(GATE_BLOCK * OBS_WAVES), shmem, h->stream, zarg,
                                    (const double*)h->x, (const double*)h->P, h->ld, h->N, zc, cz, R[0], R[1], R[2], R[3],
                                    gate1, gate2, h->gate_part, (const double*)h->d_pmax, pregate, 6);
         }
@@ -417,7 +435,7 @@ int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gat
             KTimer t(h, SLAM_K_GATE_FIN);
             const bool last = o + CHUNK >= nz;
             hipLaunchKernelGGL(gate_final_kernel, dim3(cz), dim3(64), 0, h->stream, (const double*)h->gate_part, nblocks, cz,
-                               h->d_assoc + o, h->d_assoc, (compact && last) ? nz : 0, z_src, h->obsbuf, h->idfbuf, h->znbuf,
+                               h->d_assoc + o, h->d_assoc, (compact && last) ? nz : 0, h->obsbuf, h->obsbuf, h->idfbuf, h->znbuf,
                                h->d_count, h->h_assoc_dev, h->d_count + 2, h->h_flag_dev, h->obs_seq);
         }
         HIP_TRY(hipGetLastError());

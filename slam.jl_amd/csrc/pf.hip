@@ -659,22 +659,26 @@ __device__ __forceinline__ void apply_known(T* lm0, T* lm1, const int32_t* __res
 
 // One particle's filter step: predict (PREDICT), the m known-id updates, the log-weight.  Shared by the legacy kernels
 // (observation codes staged by the host) and the auto mode's kernel (codes planned on the device).
-template <typename T, bool PREDICT>
+// PRELOADED (the auto mode's kernel): x, y, phi hold the particle's pose, lw its stored log-weight and e1, e2 its two
+// normal deviates on entry -- requested / computed before the observation plan's barriers, off the critical path.
+template <typename T, bool PREDICT, bool PRELOADED = false>
 __device__ __forceinline__ void step_core(T* __restrict__ pose, T* lm0, T* lm1, const int32_t* __restrict__ tabs,
                                           T* __restrict__ logw, int64_t n, int64_t first, uint32_t step, uint64_t seed, T V, T G,
                                           T wheelbase, T sigV, T sigG, T dt, const T* s_obs, const int32_t* s_ids,
                                           const int32_t* s_meta, int m, T R00, T R10, T R01, T R11, T pend, int64_t p, bool valid,
-                                          T& x, T& y, T& phi, T& lw) {
-    x = pose[p]; y = pose[n + p]; phi = pose[2 * n + p];
-    lw = logw[p] - pend;          // `pend`: the normalisation shift deferred by slam_pf_normalize (0 if none)
+                                          T& x, T& y, T& phi, T& lw, T e1 = 0, T e2 = 0) {
+    if (!PRELOADED) {
+        x = pose[p]; y = pose[n + p]; phi = pose[2 * n + p];
+        lw = logw[p];
+    }
+    lw -= pend;                   // `pend`: the normalisation shift deferred by slam_pf_normalize (0 if none)
     KnownRing<T> known;
     known.start(lm0, lm1, tabs, n, (uint32_t)p, s_ids, s_meta, m);      // the first records are in flight during the motion model
     if (PREDICT) {
-        T e1, e2;
 #if defined(SLAMHIP_EXPERIMENTS) && defined(PF_EXP_NOPREDICT)       // timing experiment: no noise
         e1 = (T)0.1; e2 = (T)-0.1;
 #else
-        normals2<T>((uint64_t)(first + p), step, STREAM_PREDICT, seed, e1, e2);
+        if (!PRELOADED) normals2<T>((uint64_t)(first + p), step, STREAM_PREDICT, seed, e1, e2);
 #endif
         const T Vn = V + sigV * e1;                       // sim/sim-utils.jl:36
         const T Gn = G + sigG * e2;                       // :37
@@ -1570,7 +1574,11 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void pf_auto_step_kern
 #if defined(SLAMHIP_EXPERIMENTS) && defined(PF_EXP_STAMPS)
     if (blockIdx.x == 0 && threadIdx.x == 0) g_xs[7] = wall_clock64();
 #endif
-    if (ctl->halt_seq != 0) return;                    // an earlier step waits for the host: the host replays this one
+    // the control words this step needs, in one go (one cache line, one round trip)
+    const long long halted = ctl->halt_seq;
+    const int pcur = ctl->pcur, tside = ctl->tside;
+    const double shift_next = ctl->shift_next;
+    if (halted != 0) return;                           // an earlier step waits for the host: the host replays this one
     PF_XS(1);
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->stamps[0] = wall_clock64();
     __shared__ T s_obs[2 * PF_AUTO_MAXOBS];          // the observations in the state dtype: converted once per workgroup
@@ -1581,25 +1589,31 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void pf_auto_step_kern
     typedef const __attribute__((address_space(4))) PfAutoArgs* KargPtr;
     const KargPtr ka = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) s_obs[i] = (T)ka->z[i];
-    plan_obs(&ka->ids[0], a.lmstate, m, s_l, s_st, s_ids, s_meta, s_first);
-    PF_XS(2);
-    const int pcur = ctl->pcur, tside = ctl->tside;
-    const T pend = (T)ctl->shift_next;
+    const T pend = (T)shift_next;
     T* pose = (T*)(pcur ? a.pose1 : a.pose0);
     const int32_t* tabs = tside ? a.tab1 : a.tab0;
     const int64_t n = a.n;
     const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = pi < n;
     const int64_t p = valid ? pi : n - 1;              // idle lanes shadow the last particle, stores are masked
-    T x, y, phi, lw;
+    // the particle's pose and weight are requested, and its noise drawn, BEFORE the plan's two barriers and its dependent
+    // loads (ids -> state words): the motion model then starts as soon as the plan stands
+    T x = 0, y = 0, phi = 0, lw = 0, e1 = 0, e2 = 0;
+    if (!PROPOSAL) {
+        x = pose[p]; y = pose[n + p]; phi = pose[2 * n + p];
+        lw = ((const T*)a.logw)[p];
+        normals2<T>((uint64_t)(a.first + p), a.step, STREAM_PREDICT, a.seed, e1, e2);
+    }
+    plan_obs(&ka->ids[0], a.lmstate, m, s_l, s_st, s_ids, s_meta, s_first);
+    PF_XS(2);
     if (PROPOSAL)
         proposal_core<T>(pose, (T*)a.lm0, (T*)a.lm1, tabs, (T*)a.logw, n, a.first, a.step, a.seed, (T)a.V, (T)a.G, (T)a.wheelbase, (T)a.a0,
                          (T)a.a1, (T)a.a2, (T)a.dt, s_obs, s_ids, s_meta, m, (T)a.R00, (T)a.R10, (T)a.R01, (T)a.R11, pend, p, valid, x,
                          y, phi, lw);
     else
-        step_core<T, true>(pose, (T*)a.lm0, (T*)a.lm1, tabs, (T*)a.logw, n, a.first, a.step, a.seed, (T)a.V, (T)a.G, (T)a.wheelbase,
-                           (T)a.a0, (T)a.a1, (T)a.dt, s_obs, s_ids, s_meta, m, (T)a.R00, (T)a.R10, (T)a.R01, (T)a.R11, pend, p, valid, x,
-                           y, phi, lw);
+        step_core<T, true, true>(pose, (T*)a.lm0, (T*)a.lm1, tabs, (T*)a.logw, n, a.first, a.step, a.seed, (T)a.V, (T)a.G,
+                                 (T)a.wheelbase, (T)a.a0, (T)a.a1, (T)a.dt, s_obs, s_ids, s_meta, m, (T)a.R00, (T)a.R10, (T)a.R01,
+                                 (T)a.R11, pend, p, valid, x, y, phi, lw, e1, e2);
     PF_XS(4);
     PF_WG(1);
     block_weight_stats<T, true>(lw, x, y, phi, valid, 1, a.part, a.seq);          // a tagged line, not waited for
