@@ -525,13 +525,21 @@ __device__ __forceinline__ void fill_lds_p(char* sm, int buf, const u32x4b (&g)[
 }
 
 template <bool DBG>
-__device__ __forceinline__ void mfma_chunk_p(const DdCtx& c, const char* sm, int buf, f32x16 (&acc)[2]) {
+__device__ __forceinline__ void mfma_chunk_p(const DdCtx& c, const char* sm, int buf, f32x16 (&acc)[2], bool negate = false) {
     if (DBG && (c.dbg & 2)) return;
     // row r of an array sits at r * 32, its k-half h at ((h ^ (r >> 3)) & 1) * 16; all rows here are l31 + multiples of 32
     const char* base = sm + buf * (2 * IMG_CHUNK) + c.l31 * 32 + ((c.lh ^ (c.l31 >> 3)) & 1) * 16;
     bf16x8 a[3];
 #pragma unroll
     for (int sp = 0; sp < 3; ++sp) a[sp] = *reinterpret_cast<const bf16x8*>(base + IMG_CHUNK + sp * IMG_ARR + (32 * c.wc) * 32);
+    if (DBG && negate) {       // WRAP experiment: the second walk over the image takes back what the first one subtracted
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) {
+            u32x4b t = __builtin_bit_cast(u32x4b, a[sp]);
+            t ^= 0x80008000u;
+            a[sp] = __builtin_bit_cast(bf16x8, t);
+        }
+    }
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         bf16x8 b[3];
@@ -548,9 +556,12 @@ __device__ __forceinline__ void mfma_chunk_p(const DdCtx& c, const char* sm, int
     }
 }
 
-template <bool DBG, int NCH, int POFF>
+// WRAP (timing experiment, experiments build only): the image's 8 chunks are walked twice -- the LDS fills, fragment
+// reads and MFMAs of a panel of 256 columns, i.e. of TWO steps' down-dates applied in one pass over P (wrong numbers).
+template <bool DBG, int NCH, int POFF, bool WRAP = false>
 __device__ __forceinline__ void dd_stream_p(DdCtx& c, const int2* __restrict__ list, int L, int nper, int& slot, char* sm) {
     auto fetch = [&](int sl) { return sl < L ? list[sl] : make_int2(-1, -1); };
+    auto request_chunk_p = [&](const DdCtx& cc, int2 t, int chunk, u32x4b (&gg)[3]) { ::request_chunk_p(cc, t, WRAP ? (chunk & 7) : chunk, gg); };
     constexpr int PCH = NCH - POFF > 0 ? NCH - POFF : 0;
     int2 tile = fetch(slot);
     int2 next = fetch(slot + nper);
@@ -572,7 +583,7 @@ __device__ __forceinline__ void dd_stream_p(DdCtx& c, const int2* __restrict__ l
         for (int ch = 0; ch < NCH; ++ch) {
             const int pb = (base + ch) & 1;
             if (ch == PCH && !(DBG && (c.dbg & 4))) load_p_mfma(c, tile.x * TILE, tile.y * TILE, pold);
-            mfma_chunk_p<DBG>(c, sm, pb, acc);
+            mfma_chunk_p<DBG>(c, sm, pb, acc, WRAP && ch >= 8);
             if (ch < NCH - 1) {
                 fill_lds_p(sm, pb ^ 1, g);
                 __syncthreads();
@@ -699,7 +710,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
         char* sm = reinterpret_cast<char*>(&smem[0][0][0][0]);
         if (img) {                     // the W1 kernel left the panel pre-split, as this path's LDS image
             switch (kp / KB) {
-                case 8: dd_stream_p<DBG, 8, 7>(c, list, L, nper, slot, sm); break;
+                case 8:
+#ifdef SLAMHIP_EXPERIMENTS
+                    if (DBG && (c.dbg & 128)) { dd_stream_p<DBG, 16, 15, true>(c, list, L, nper, slot, sm); break; }
+#endif
+                    dd_stream_p<DBG, 8, 7>(c, list, L, nper, slot, sm); break;
                 case 7: dd_stream_p<DBG, 7, 6>(c, list, L, nper, slot, sm); break;
                 case 6: dd_stream_p<DBG, 6, 5>(c, list, L, nper, slot, sm); break;
                 default: dd_stream_p<DBG, 5, 4>(c, list, L, nper, slot, sm); break;
@@ -964,7 +979,7 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
             if (wgs > L) wgs = L;
             hipLaunchKernelGGL((downdate_f32_mfma<true, 4, 3, true>), dim3(8 * wgs), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,
                                (const float*)X, (const float*)Y, pitch, kp_total, lst, L,
-                               h->d_status, h->debug_flags & 0x5f, (unsigned long long*)nullptr, dcount, joseph, IMGARGS);
+                               h->d_status, h->debug_flags & 0xdf, (unsigned long long*)nullptr, dcount, joseph, IMGARGS);
         }
         else if (h->debug_flags)      // timing experiments only (SLAMHIP_DEBUG): parts of the kernel switched off
             hipLaunchKernelGGL(downdate_f32_mfma<true>, dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,

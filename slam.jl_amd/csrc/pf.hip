@@ -747,11 +747,29 @@ __device__ __forceinline__ void proposal_core(T* __restrict__ pose, T* lm0, T* l
     const T gl20 = gu20 * lq00 + gu21 * lq10, gl21 = gu21 * lq11;
     T mu0 = 0, mu1 = 0, g00 = 1, g01 = 0, g11 = 1;
     T lw = logw[p] - pend;
-    for (int i = 0; i < m; ++i) {
-        const int32_t code = s_ids[i];
+    // pass 1 reads the PRIOR map only (nothing is written): the records of the next PF_DEPTH observations are kept in
+    // flight as in the sweep's second pass (KnownRing), through the same buffer descriptors
+    auto uni = [](int32_t v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto prior_row = [&](int j) {
+        return sweep_load<T>(lm0, lm1, tabs, n, (uint32_t)p, uni(s_ids[j]), uni(s_meta[j]) >> META_PRIOR_SHIFT);
+    };
+    auto informative = [&](int j) { return j < m && !(uni(s_ids[j]) & (NEW_FLAG | FRESH_FLAG)); };
+    LmRow<T> ring[PF_DEPTH];
+#pragma unroll
+    for (int u = 0; u < PF_DEPTH; ++u) {
+        ring[u] = LmRow<T>{0, 0, 0, 0, 0};
+        if (informative(u)) ring[u] = prior_row(u);
+    }
+    for (int i0 = 0; i0 < m; i0 += PF_DEPTH)
+#pragma unroll
+    for (int u = 0; u < PF_DEPTH; ++u) {
+        const int i = i0 + u;
+        if (i >= m) break;                             // uniform
+        const int32_t code = uni(s_ids[i]);
+        const LmRow<T> cur = ring[u];
+        if (informative(i + PF_DEPTH)) ring[u] = prior_row(i + PF_DEPTH);
         if (code & (NEW_FLAG | FRESH_FLAG)) continue;  // a landmark first seen in this call says nothing about the pose
         const T r = (T)s_obs[2 * i], b = (T)s_obs[2 * i + 1];
-        const LmRow<T> cur = load_row<T>(obs_src<T>(lm0, lm1, tabs, n, p, code, s_meta[i] >> META_PRIOR_SHIFT), n);   // the prior map
         const T dx = cur.lx - xm, dy = cur.ly - ym;
         const T d2 = dx * dx + dy * dy;
         T d, h00, h01, h10, h11;

@@ -434,7 +434,7 @@ def test_edge_cases(pkg, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_many_observations_and_large_k(pkg, dtype):
-    """nz > 256 exercises the chunked gating sweep; k = 2m > 128 the global-memory factor path."""
+    """nz > 128 exercises the chunked gating sweep (three launches of at most 128 observations); k = 2m > 128 the global-memory factor path."""
     rng = np.random.default_rng(21)
     N = 300
     x, P = random_state(rng, N, spread=400.0)
@@ -456,7 +456,7 @@ def test_many_observations_and_large_k(pkg, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_observe_with_many_observations(pkg, dtype):
-    """observe() with nz = 300 > 256: the gating sweep runs in two chunks and the compaction waits for the last one;
+    """observe() with nz = 300 > 128: the gating sweep runs in three chunks and the compaction waits for the last one;
     k = 2m > 128 takes the global-memory factorisation inside the fused factor/panel launch.  Distinct, well
     separated landmarks (so S is well conditioned at this k); state against the oracle's three calls."""
     rng = np.random.default_rng(33)
