@@ -596,6 +596,41 @@ def test_auto_mode_equals_the_synchronous_driver(pkg, dtype, proposal):
         g.shard.close()
 
 
+@pytest.mark.parametrize("n", [200, 1024 * 256 + 700])
+def test_auto_mode_grid_sizes_of_the_statistics_hand_over(pkg, n):
+    """The step kernel's last workgroup collects one tagged statistics line per workgroup, 1024 lines per pass: a grid of ONE
+    workgroup (it collects its own line) and one of 1027 workgroups (a second pass, a ragged last workgroup) against the
+    synchronous driver -- same particles, same Neff, same resampling steps; legacy calls in between reuse the partials
+    buffer (their lines carry no tag of the next auto step)."""
+    nl, seed, dtype = 6, 13, "f32"
+    lm = scene(nl, 23)
+    f = {}
+    for name in ("auto", "sync"):
+        sh = pkg.PFShard(n, nl, seed, dtype=dtype)
+        sh.set_pose([0.5, 1.5, -0.2])
+        sh.init_landmarks(lm, 0.01, 0.1)
+        f[name] = pkg.FastSLAM(sh, None, neff_frac=0.75)
+    rng = np.random.default_rng(8)
+    pose = np.array([0.5, 1.5, -0.2])
+    for t in range(9):
+        pose = np.array([pose[0] + 0.6 * math.cos(pose[2]), pose[1] + 0.6 * math.sin(pose[2]), pose[2]])
+        ids = np.array([1 + t % 6, 1 + (t + 2) % 6, 1 + t % 6])
+        z = observe(lm, pose, ids, rng)
+        force = True if t in (2, 6) else None
+        f["auto"].step_async(6.0, 0.02, 4.0, Q, 0.1, z, ids, R, force_resample=force)
+        want = f["sync"].step(6.0, 0.02, 4.0, Q, 0.1, z, ids, R, force_resample=force)
+        if t in (3, 8):
+            neff, did = f["auto"].flush()
+            assert did == want[1] and neff == pytest.approx(want[0], rel=1e-6), f"step {t}"
+            _compare(f["auto"].shard, f["sync"].shard, f"n {n} step {t}", exact_logw=False)
+        if t == 4:                                            # a legacy call on both: statistics through the same buffer
+            sa, sb = f["auto"].shard.weight_stats(), f["sync"].shard.weight_stats()
+            assert sa[0] == sb[0] and sa[1] == pytest.approx(sb[1], rel=1e-12)
+    assert f["auto"].resamples == f["sync"].resamples >= 2
+    for g in f.values():
+        g.shard.close()
+
+
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_auto_mode_with_an_exhausted_table_pool_and_legacy_calls_in_between(pkg, dtype):
     """One observation per step over 100 landmarks with a resampling at every step needs more live ancestor tables than
