@@ -190,7 +190,9 @@ int slam_ekf_debug_stamps(slam_ekf_t h, int enable, uint64_t* out8);
  * n_global particles (one process per GPU).  Random numbers are Philox4x32-10 keyed by
  * (seed, step, global id), so results do not depend on the split.  Collectives (three scalars
  * per step; all log-weights and the migrating particle records on a resampling step) are
- * issued by the host between these calls (torch.distributed over RCCL): see slam.jl_amd/pf.py. */
+ * issued by the host between these calls (torch.distributed over RCCL): see slam.jl_amd/pf.py.
+ * Limits: n_global < 2^31; one landmark's five rows of a shard (5 * n_local values) must fit a 4 GiB buffer descriptor,
+ * i.e. n_local < 2^32 / (5 * sizeof(T)) -- 214 M particles in fp32, 107 M in fp64 (SLAM_E_BADARG otherwise). */
 typedef struct slam_pf* slam_pf_t;
 
 int slam_pf_create(slam_pf_t* h, int dtype, int64_t n_local, int64_t n_global, int64_t first_id,
