@@ -540,10 +540,10 @@ template <typename T>
 __device__ __forceinline__ auto lm_rsrc(const T* base, int64_t n) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), (short)0, (int)(uint32_t)(5 * n * (int64_t)sizeof(T)), 0x00020000);
 }
-template <typename T, typename R>
+template <typename T, int AUX = 2, typename R>
 __device__ __forceinline__ T rec_load(R rs, uint32_t voff, uint32_t soff) {
-    if constexpr (sizeof(T) == 4) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 2));
-    else return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 2));
+    if constexpr (sizeof(T) == 4) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, AUX));
+    else return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, AUX));
 }
 template <typename T, typename R>
 __device__ __forceinline__ void rec_store(T v, R rs, uint32_t voff, uint32_t soff) {
@@ -562,20 +562,29 @@ template <typename T>
 __device__ __forceinline__ LmRow<T> sweep_load(const T* lm0, const T* lm1, const int32_t* __restrict__ tabs, int64_t n, uint32_t p,
                                                int32_t code, int32_t meta) {
     const int t = meta & META_TAB;
-    uint32_t slot = p;
+    const auto rs = lm_rsrc<T>(((meta & META_RBUF) ? lm1 : lm0) + (size_t)(code & ID_MASK) * 5 * n, n);
+    const uint32_t row = (uint32_t)n * (uint32_t)sizeof(T);
+    LmRow<T> r;
     if (t) {                                                           // uniform
+        // through a table: several particles -- of other waves too -- read the same ancestor's record, so these loads
+        // keep the default cache policy (one-box A/B against non-temporal: 74.0 against 80.3 us per resampling step)
         const auto rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(tabs + (size_t)(t - 1) * n), (short)0,
                                                           (int)(uint32_t)(n * 4), 0x00020000);
-        slot = __builtin_amdgcn_raw_buffer_load_b32(rt, p * 4u, 0, 2);
+        const uint32_t slot = __builtin_amdgcn_raw_buffer_load_b32(rt, p * 4u, 0, 2);
+        const uint32_t voff = slot * (uint32_t)sizeof(T);
+        r.lx = rec_load<T, 0>(rs, voff, 0u);
+        r.ly = rec_load<T, 0>(rs, voff, row);
+        r.pxx = rec_load<T, 0>(rs, voff, 2u * row);
+        r.pxy = rec_load<T, 0>(rs, voff, 3u * row);
+        r.pyy = rec_load<T, 0>(rs, voff, 4u * row);
+    } else {
+        const uint32_t voff = p * (uint32_t)sizeof(T);
+        r.lx = rec_load<T>(rs, voff, 0u);
+        r.ly = rec_load<T>(rs, voff, row);
+        r.pxx = rec_load<T>(rs, voff, 2u * row);
+        r.pxy = rec_load<T>(rs, voff, 3u * row);
+        r.pyy = rec_load<T>(rs, voff, 4u * row);
     }
-    const auto rs = lm_rsrc<T>(((meta & META_RBUF) ? lm1 : lm0) + (size_t)(code & ID_MASK) * 5 * n, n);
-    const uint32_t voff = slot * (uint32_t)sizeof(T), row = (uint32_t)n * (uint32_t)sizeof(T);
-    LmRow<T> r;
-    r.lx = rec_load<T>(rs, voff, 0u);
-    r.ly = rec_load<T>(rs, voff, row);
-    r.pxx = rec_load<T>(rs, voff, 2u * row);
-    r.pxy = rec_load<T>(rs, voff, 3u * row);
-    r.pyy = rec_load<T>(rs, voff, 4u * row);
     return r;
 }
 
@@ -1391,7 +1400,8 @@ __device__ __forceinline__ void block_reduce6(double (&v)[6], double (*sh6)[6]) 
 
 // Runs in the launch's last workgroup, after its own share of the sweep (all 256 threads).  s_l / s_st / s_first: this step's plan (LDS).
 template <typename T>
-__device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t* s_l, const int32_t* s_st, const int32_t* s_first) {
+__device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t* s_l, const int32_t* s_st, const int32_t* s_first,
+                                             int pcur, int tside) {
     __shared__ double sh[4];
     __shared__ double s_r6[4][6];
     __shared__ double s_g[12];
@@ -1405,6 +1415,7 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
     // to come back, so the tail pays that latency once, not once per phase.
     const int my_tref = tid < PF_TAB_MAX ? ctl->tref[tid] : 0;
     const int identity0 = ctl->identity;                      // landmarks without a table before this step
+    const int nres0 = ctl->nresamples;                        // (requested here, with the rest: used by the bookkeeping only)
     const unsigned long long key = part_key(a.seq);
     const unsigned long long t_poll = wall_clock64();
     if (tid == 0) ctl->stamps[6] = t_poll;                    // the collecting workgroup has done its own share
@@ -1556,10 +1567,10 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
         if (s_i[3]) ctl->error = 1;
         ctl->identity = outcome == 1 ? 0 : s_i[0];                          // (a lazy resampling gives every landmark a table)
         if (outcome == 1) {
-            ctl->u0 = resample_offset((uint32_t)ctl->nresamples, a.seed);
-            ctl->nresamples += 1;
-            ctl->pcur ^= 1;
-            ctl->tside ^= 1;
+            ctl->u0 = resample_offset((uint32_t)nres0, a.seed);
+            ctl->nresamples = nres0 + 1;
+            ctl->pcur = pcur ^ 1;
+            ctl->tside = tside ^ 1;
             ctl->resample_seq = a.seq;
         } else if (outcome == 2) {
             ctl->halt_seq = a.seq;
@@ -1569,7 +1580,7 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
         // write back this XCD's whole L2, which the sweep has just filled with dirty landmark records).
         PfMirror* mir = a.mir;
         __hip_atomic_store(&mir->neff, s_g[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&mir->nresamples, (long long)ctl->nresamples, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mir->nresamples, (long long)(nres0 + (outcome == 1 ? 1 : 0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (outcome == 1) __hip_atomic_store(&mir->resampled_seq, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (s_i[3]) __hip_atomic_store(&mir->error, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1639,7 +1650,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void pf_auto_step_kern
     PF_WG(2);
     // the workgroup that is dispatched last collects the lines (every other workgroup has been dispatched before it and
     // finishes without it: the wait cannot deadlock, and it ends on a time-out)
-    if (blockIdx.x == gridDim.x - 1) pf_auto_tail<T>(a, s_l, s_st, s_first);
+    if (blockIdx.x == gridDim.x - 1) pf_auto_tail<T>(a, s_l, s_st, s_first, pcur, tside);
 }
 
 // The cdf of the step that resamples (pf_scan1_kernel behind the control block's gate).
@@ -1675,7 +1686,9 @@ __global__ __launch_bounds__(256) void pf_auto_resample_kernel(T* pose0, T* pose
                                                                 int32_t* __restrict__ anc_out, T lw_uniform) {
     if (ctl->resample_seq != seq) return;
     __shared__ double s_off[AUTO_NB_MAX + 1];
+    __shared__ int s_tl[PF_TAB_MAX];                       // the live tables to compose (once per workgroup, not once per use)
     for (int i = threadIdx.x; i < nb; i += 256) s_off[i] = bsum[i];
+    if (threadIdx.x < PF_TAB_MAX) s_tl[threadIdx.x] = ctl->tl_idx[threadIdx.x];
     __syncthreads();
     if (threadIdx.x == 0) {
         double run = 0.0;
@@ -1710,19 +1723,35 @@ __global__ __launch_bounds__(256) void pf_auto_resample_kernel(T* pose0, T* pose
     anc_out[p] = a;
     // the tail has already flipped the buffers: the live ones are the destination
     const int pnew = ctl->pcur, tnew = ctl->tside;
-    const T* pose_old = pnew ? pose0 : pose1;
-    T* pose_new = pnew ? pose1 : pose0;
-    const int32_t* tin = tnew ? tab0 : tab1;
-    int32_t* tout = tnew ? tab1 : tab0;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) pose_new[(size_t)r * n + p] = pose_old[(size_t)r * n + a];
+    const T* __restrict__ pose_old = pnew ? pose0 : pose1;
+    T* __restrict__ pose_new = pnew ? pose1 : pose0;
+    const int32_t* __restrict__ tin = tnew ? tab0 : tab1;
+    int32_t* __restrict__ tout = tnew ? tab1 : tab0;
     const int fresh = ctl->tl_fresh, count = ctl->tl_count;
+    // Gathers in batches: ALL loads of a batch are issued before its first store.  (Written as load -> store per table,
+    // with the table's index fetched from the control block each time, the compiler kept every pair in order behind a
+    // full wait -- possible aliasing -- and the 31 live tables of the benchmark cost 31 serial round trips: 21 us.)
+    T pv[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) pv[r] = pose_old[(size_t)r * n + a];
+    constexpr int TB = 8;
+    int32_t tv[TB];
+#pragma unroll
+    for (int u = 0; u < TB; ++u) tv[u] = u < count ? tin[(size_t)s_tl[u] * n + a] : 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) pose_new[(size_t)r * n + p] = pv[r];
     if (fresh >= 0) tout[(size_t)fresh * n + p] = a;
-    for (int i = 0; i < count; ++i) {
-        const size_t t = (size_t)ctl->tl_idx[i];
-        tout[t * n + p] = tin[t * n + a];
-    }
     logw[p] = lw_uniform;
+    for (int i0 = 0; i0 < count; i0 += TB) {
+        int32_t tn[TB];
+#pragma unroll
+        for (int u = 0; u < TB; ++u) tn[u] = i0 + TB + u < count ? tin[(size_t)s_tl[i0 + TB + u] * n + a] : 0;    // the next batch
+#pragma unroll
+        for (int u = 0; u < TB; ++u)
+            if (i0 + u < count) tout[(size_t)s_tl[i0 + u] * n + p] = tv[u];
+#pragma unroll
+        for (int u = 0; u < TB; ++u) tv[u] = tn[u];
+    }
 }
 
 template <typename T>
