@@ -19,13 +19,14 @@ for t in range(64):
     z = np.vstack([np.hypot(lm[ids - 1, 0], lm[ids - 1, 1]), np.arctan2(lm[ids - 1, 1], lm[ids - 1, 0]) - 0.3])
     obs.append(pkg.PFShard.prepare_obs(z, ids))
 Qs, Rs = pkg.small(Q), pkg.small(R)
+PROPOSAL = bool(int(os.environ.get("PF_PROBE_PROPOSAL", "0")))       # the FastSLAM-2.0 step instead of the 1.0 step
 for force in (False, True):
     for k in range(2000):
-        pf.step_async(8.0, 0.0, 4.0, Qs, 0.025, None, None, Rs, force_resample=force, prepared=obs[k % 64])
+        pf.step_async(8.0, 0.0, 4.0, Qs, 0.025, None, None, Rs, force_resample=force, proposal=PROPOSAL, prepared=obs[k % 64])
     pf.flush()
     t0 = time.perf_counter()
     for k in range(2000):
-        pf.step_async(8.0, 0.0, 4.0, Qs, 0.025, None, None, Rs, force_resample=force, prepared=obs[k % 64])
+        pf.step_async(8.0, 0.0, 4.0, Qs, 0.025, None, None, Rs, force_resample=force, proposal=PROPOSAL, prepared=obs[k % 64])
     t1 = time.perf_counter()
     pf.flush()
     t2 = time.perf_counter()
