@@ -1,4 +1,6 @@
-# one-box A/B of the particle sweep: the library against other builds (arguments), pf_auto_probe.py each, twice
+# One-box A/B of the particle step: the product library against other builds (arguments: .so files, e.g. pf.hip compiled
+# with -DPF_DEPTH=8 or -DPF_FAST_MATH=0 and linked with the other objects), tools/pf_auto_probe.py on each, twice.
+# PF_PROBE_PROPOSAL=1 in the environment times the FastSLAM-2.0 step instead.
 mkdir -p gpurun_out
 {
 for rep in 1 2; do
