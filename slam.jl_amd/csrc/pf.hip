@@ -128,6 +128,7 @@ struct slam_pf {
     PfMirror* h_mir_dev;
     int auto_on;                 // the device copy of the bookkeeping is the live one
     long long auto_seq;          // last step enqueued
+    long long pub_seq;           // last step whose publication to the mirror is enqueued (with it, or by the publish kernel)
     long long nresamples;        // resamplings so far (drives the systematic-resampling offset)
     std::vector<PfStepRec> log;       // queued steps not yet confirmed by the device (replayed after a halt)
     double* d_xchg;              // device address of the ranks' shared scalar page (sharded filter), or null
@@ -327,6 +328,8 @@ constexpr int PF_OCAP = 1024;               // observations per call; the meta w
 constexpr int PF_TAB_MAX = 64;              // live ancestor tables before the maps are materialised
 constexpr int PF_AUTO_MAXOBS = 64;          // observations per slam_pf_step_auto call (planned per workgroup in LDS)
 constexpr int PF_LOG = 32;                  // steps the host may run ahead of the device
+constexpr int PF_PUBLISH_EVERY = 8;         // a step publishes to the host's mirror when its number is a multiple of this
+                                            // (or when it halts / fails); slam_pf_flush asks for the last one
 constexpr int32_t LS_TAB = 0xff, LS_BUF = 1 << 8, LS_SEEN = 1 << 9;     // per-landmark state word of the auto mode
 static_assert(PF_CTL_TABS == PF_TAB_MAX && PF_CTL_MAXOBS == PF_AUTO_MAXOBS, "control-block sizes");
 
@@ -1331,7 +1334,7 @@ struct PfAutoArgs {
     long long n, first, n_global, seq;
     unsigned long long seed;
     unsigned int step;
-    int m, nl, force, lazy_ok, rank, world;
+    int m, nl, force, lazy_ok, rank, world, publish;
     double V, G, wheelbase, a0, a1, a2, dt, R00, R10, R01, R11, neff_frac;
     double* part;
     PfCtl* ctl;
@@ -1400,6 +1403,28 @@ __device__ __forceinline__ void block_reduce6(double (&v)[6], double (*sh6)[6]) 
     for (int i = 0; i < 6; ++i) v[i] = sh6[0][i] + sh6[1][i] + sh6[2][i] + sh6[3][i];
 }
 
+// One lane writes a step's outcome to the host's mirror (pinned memory).
+__device__ __forceinline__ void pf_publish(PfMirror* mir, double neff, long long nresamples, long long resampled_seq, int error,
+                                           long long halt_seq, long long seq) {
+    __hip_atomic_store(&mir->neff, neff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&mir->nresamples, nresamples, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&mir->resampled_seq, resampled_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (error) __hip_atomic_store(&mir->error, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (halt_seq) {
+        __hip_atomic_store(&mir->halt_seq, halt_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __hip_atomic_store(&mir->done_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// slam_pf_flush's request: the outcome of the LAST completed step, whatever its number.  (After a halt nothing is to be
+// said: the halting step has published itself and the steps behind it were skipped.)
+__global__ void pf_auto_publish_kernel(const PfCtl* __restrict__ ctl, PfMirror* mir) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || ctl->halt_seq != 0) return;
+    pf_publish(mir, ctl->stats[7], (long long)ctl->nresamples, ctl->resample_seq, ctl->error, 0ll, ctl->seq);
+}
+
 // Runs in the launch's last workgroup, after its own share of the sweep (all 256 threads).  s_l / s_st / s_first: this step's plan (LDS).
 template <typename T>
 __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t* s_l, const int32_t* s_st, const int32_t* s_first,
@@ -1418,6 +1443,7 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
     const int my_tref = tid < PF_TAB_MAX ? ctl->tref[tid] : 0;
     const int identity0 = ctl->identity;                      // landmarks without a table before this step
     const int nres0 = ctl->nresamples;                        // (requested here, with the rest: used by the bookkeeping only)
+    const long long res0 = ctl->resample_seq;
     const unsigned long long key = part_key(a.seq);
     const unsigned long long t_poll = wall_clock64();
     if (tid == 0) ctl->stamps[6] = t_poll;                    // the collecting workgroup has done its own share
@@ -1577,20 +1603,15 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
         } else if (outcome == 2) {
             ctl->halt_seq = a.seq;
         }
-        // what the host may read without synchronising
+        // What the host may read without synchronising -- only every PF_PUBLISH_EVERY-th step, a halting or a failing one
+        // (a.publish): two dependent PCIe writes at the very end of the kernel are ~2 us of every step otherwise, and the
+        // host needs the mirror only to recycle its log (a quarter of the log's depth is granularity enough) and in
+        // slam_pf_flush, which asks for the last step with pf_auto_publish_kernel.
         // Write-through system-scope stores, drained, then the sequence number: no fence (a system-scope release would
         // write back this XCD's whole L2, which the sweep has just filled with dirty landmark records).
-        PfMirror* mir = a.mir;
-        __hip_atomic_store(&mir->neff, s_g[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&mir->nresamples, (long long)(nres0 + (outcome == 1 ? 1 : 0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (outcome == 1) __hip_atomic_store(&mir->resampled_seq, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (s_i[3]) __hip_atomic_store(&mir->error, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (outcome == 2) {
-            __hip_atomic_store(&mir->halt_seq, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __hip_atomic_store(&mir->done_seq, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (a.publish || outcome == 2 || s_i[3])
+            pf_publish(a.mir, s_g[4], (long long)(nres0 + (outcome == 1 ? 1 : 0)), outcome == 1 ? a.seq : res0, s_i[3],
+                       outcome == 2 ? a.seq : 0ll, a.seq);
         ctl->stamps[5] = wall_clock64();
     }
 }
@@ -1900,7 +1921,7 @@ extern "C" int slam_pf_create(slam_pf_t* out, int dtype, int64_t n_local, int64_
     h->d_part = h->d_out = h->h_out = h->d_cdf = h->d_bsum = nullptr; h->d_src = nullptr; h->d_anc = nullptr;
     h->seen.assign(max_landmarks, 0);
     h->d_ctl = nullptr; h->d_lmstate = nullptr; h->h_mir = h->h_mir_dev = nullptr;
-    h->auto_on = 0; h->auto_seq = 0; h->nresamples = 0; h->halted = 0; h->halt_gmax = 0.0; h->last_resampled_seq = 0;
+    h->auto_on = 0; h->auto_seq = 0; h->pub_seq = 0; h->nresamples = 0; h->halted = 0; h->halt_gmax = 0.0; h->last_resampled_seq = 0;
     h->d_xchg = nullptr; h->xchg_host = nullptr; h->xchg_rank = 0; h->xchg_world = 1;
     for (int i = 0; i < 4; ++i) h->last_out[i] = 0.0;
     const int rc = pf_create_impl(h);
@@ -2568,6 +2589,7 @@ static int pf_auto_enter(slam_pf* h) {
     h->h_mir->neff = keep.neff;
     for (int i = 0; i < 8; ++i) h->h_mir->stats[i] = keep.stats[i];
     h->h_mir->done_seq = h->log.empty() ? h->auto_seq : h->log.front().seq - 1;      // (a replay: the logged steps are still to come)
+    h->pub_seq = h->h_mir->done_seq;                        // (publications asked for before a halt were not made)
     h->h_mir->nresamples = h->nresamples;
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
     h->auto_on = 1;
@@ -2614,6 +2636,8 @@ static int pf_auto_enqueue(slam_pf* h, const PfStepRec& r) {
     a.seed = h->seed; a.step = r.rng_step;
     a.m = r.m; a.nl = h->nl; a.force = r.force; a.lazy_ok = pf_auto_lazy_ok(h) ? 1 : 0;
     a.rank = h->xchg_rank; a.world = h->xchg_world;
+    a.publish = (r.seq % PF_PUBLISH_EVERY) == 0 ? 1 : 0;
+    if (a.publish && r.seq > h->pub_seq) h->pub_seq = r.seq;
     a.V = r.V; a.G = r.G; a.wheelbase = r.wheelbase; a.dt = r.dt;
     if (r.proposal) {
         const double lq00 = sqrt(r.Q[0]), lq10 = 0.5 * (r.Q[1] + r.Q[2]) / lq00;
@@ -2711,6 +2735,11 @@ static int pf_auto_handle_halt(slam_pf* h) {
 
 static int pf_auto_flush(slam_pf* h) {
     while (h->auto_on) {
+        if (h->pub_seq < h->auto_seq) {                    // the last step does not publish by itself: ask for it
+            hipLaunchKernelGGL(pf_auto_publish_kernel, dim3(1), dim3(64), 0, h->stream, (const PfCtl*)h->d_ctl, h->h_mir_dev);
+            HIP_TRY(hipGetLastError());
+            h->pub_seq = h->auto_seq;
+        }
         int rc = pf_auto_wait(h, h->auto_seq);
         if (rc) return rc;
         if (h->h_mir->halt_seq != 0) {
@@ -2820,6 +2849,11 @@ extern "C" int slam_pf_halt_info(slam_pf_t h, double out[2]) {
 
 extern "C" int slam_pf_resample_count(slam_pf_t h, int64_t* count) {
     ARG_CHECK(h != nullptr && count != nullptr, "null argument");
+    if (h->auto_on && !h->halted) {                        // the mirror is current only after a publication: ask for one
+        HIP_TRY(hipSetDevice(h->device));
+        const int rc = pf_auto_flush(h);
+        if (rc && rc != SLAM_PF_HALTED) return rc;
+    }
     *count = h->auto_on ? (int64_t)h->h_mir->nresamples : (int64_t)h->nresamples;
     return SLAM_OK;
 }
