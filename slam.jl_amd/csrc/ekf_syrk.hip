@@ -540,11 +540,15 @@ __device__ __forceinline__ void mfma_chunk_p(const DdCtx& c, const char* sm, int
             a[sp] = __builtin_bit_cast(bf16x8, t);
         }
     }
+    bf16x8 b[3];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
-        bf16x8 b[3];
+        // (experiment, bit 8: the second row block reuses the first one's fragments -- a third fewer LDS reads, wrong numbers:
+        //  what a 64 x 64 register tile per wave would save on the fragment side)
+        if (!(DBG && (c.dbg & 8) && rb == 1)) {
 #pragma unroll
         for (int sp = 0; sp < 3; ++sp) b[sp] = *reinterpret_cast<const bf16x8*>(base + sp * IMG_ARR + (64 * c.wr + 32 * rb) * 32);
+        }
         if (!(c.xflags & 2)) __builtin_amdgcn_s_setprio(3);
         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[rb], 0, 0, 0);      // (m, m)
         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[rb], 0, 0, 0);      // (h, l)
