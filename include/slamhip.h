@@ -295,13 +295,14 @@ int slam_pf_stream(slam_pf_t h, void** stream);
 int slam_pf_step_auto(slam_pf_t h, double V, double G, double wheelbase, const double Q[4], double dt, const double* z,
                       const int32_t* ids, int m, const double R[4], double neff_frac, int force, int proposal);
 /* Wait for everything queued.  out (may be NULL) = {Neff of the last step, 1 if it resampled, resamplings so far,
- * steps so far}. */
+ * steps so far}.  (A queued step reports to the host only every eighth step, when it halts or fails; this call asks the
+ * device for the last step's outcome.) */
 int slam_pf_flush(slam_pf_t h, double out[4]);
 int slam_pf_halt_info(slam_pf_t h, double out[2]);      /* {largest normalised log-weight, resamplings so far}        */
 int slam_pf_resume(slam_pf_t h, int64_t resamplings);   /* resamplings: the caller's count after its own resampling   */
 /* The systematic-resampling offset of resampling k is Philox(counter (0, 0, k, 2), key seed): the count is part of the
  * filter state (slam.jl_amd/pf.py: FastSLAM.resamples). */
-int slam_pf_resample_count(slam_pf_t h, int64_t* count);
+int slam_pf_resample_count(slam_pf_t h, int64_t* count);        /* (waits for the queue, like slam_pf_flush) */
 int slam_pf_set_resample_count(slam_pf_t h, int64_t count);
 /* The ranks' shared scalar page (host memory every rank has mapped, >= 2 * world * 64 bytes, zeroed): see above. */
 int slam_pf_attach_exchange(slam_pf_t h, int rank, int world, void* page, size_t bytes);
