@@ -803,7 +803,6 @@ __global__ __launch_bounds__(256) void downdate_f64_mfma(double* __restrict__ P,
     if (tile.x < 0) return;
     __shared__ double sX[DT][DK + 1];
     __shared__ double sY[DT][DK + 1];
-    __shared__ double sT[DT][DT + 1];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kk = lane >> 4;
@@ -814,17 +813,22 @@ __global__ __launch_bounds__(256) void downdate_f64_mfma(double* __restrict__ P,
     double* Pt = P + tile_base(tile.x, tile.y, ld >> 6, 6);        // the tile: one contiguous 64 x 64 column-major block
     // P tile -> registers (rows/columns >= n are padding inside the allocation: P is allocated in whole tiles)
     f64x4 pold[2][2], acc[2][2];
+    auto load_p = [&]() {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cl = 32 * wc + 16 * cb + 4 * r + kk, rl = 32 * wr + 16 * rb + li;
+                    pold[cb][rb][r] = Pt[cl * DT + rl];             // (non-temporal loads/stores: no change here, 15.8 ms either way)
+                }
+    };
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int cl = 32 * wc + 16 * cb + 4 * r + kk, rl = 32 * wr + 16 * rb + li;
-                pold[cb][rb][r] = Pt[cl * DT + rl];                 // (non-temporal loads/stores: no change here, 15.8 ms either way)
-                acc[cb][rb][r] = 0.0;
-            }
-        }
+        for (int rb = 0; rb < 2; ++rb) acc[cb][rb] = f64x4{0.0, 0.0, 0.0, 0.0};
+    load_p();          // (requested AFTER the k-loop instead, at four workgroups per CU: 15.0 / 15.5 against 15.7 / 15.0 ms -- noise)
     for (int seg = 0; seg <= joseph; ++seg)
     for (int kc = seg * khalf; kc < seg * khalf + k16; kc += DK) {
         // 64 x 16 elements per panel, 4 per thread, coalesced along k
@@ -861,22 +865,11 @@ __global__ __launch_bounds__(256) void downdate_f64_mfma(double* __restrict__ P,
                 const int cl = 32 * wc + 16 * cb + 4 * r + kk, rl = 32 * wr + 16 * rb + li;
                 const double val = pold[cb][rb][r] - acc[cb][rb][r];
                 if (!diag || rl >= cl) Pt[cl * DT + rl] = val;
-                if (diag) sT[rl][cl] = val;
+                // in-tile mirror of a diagonal tile: element (row rl, column cl) of the lower triangle also goes to (row cl,
+                // column rl) -- a strided store straight from the registers (1 tile in 390 at C5; a staging buffer for it
+                // cost 33 KB of LDS in EVERY workgroup and held the kernel at three workgroups per CU)
+                if (diag && rl > cl) Pt[rl * DT + cl] = val;
             }
-    if (!diag) return;          // tiles above the diagonal are not maintained (see the header comment)
-    __syncthreads();
-    // in-tile mirror: element (row = rl, col = cl) of the lower triangle goes to P[row = cl', col = rl'] ...
-    // thread (tx, ty) stores the value of element (ty + 16v, tx + 16u) at its mirror position; tx runs along rows
-    const int tx = tid & 15, ty = tid >> 4;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const int rl = ty + 16 * v;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int cl = tx + 16 * u;
-            if (rl > cl) Pt[rl * DT + cl] = sT[rl][cl];             // element (row cl, column rl) of the diagonal tile
-        }
-    }
     (void)n;
 }
 
