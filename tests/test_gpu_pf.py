@@ -707,8 +707,9 @@ def test_whole_filter_calls(pkg):
     b.close()
 
 
-def test_auto_mode_two_ranks_on_one_card(pkg, tmp_path):
-    """The sharded auto mode rehearsed with two processes on ONE card (gloo for the resampling collectives): the ranks'
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_auto_mode_two_ranks_on_one_card(pkg, tmp_path, nranks):
+    """The sharded auto mode rehearsed with two (and four) processes on ONE card (gloo for the resampling collectives): the ranks'
     GPUs exchange their per-step scalars through the shared pinned page (device writes, device polls -- here both
     'GPUs' are the same card), a resampling step halts, the hosts resample through the collectives, resume, and the
     skipped steps are replayed.  The two shards together must equal the one-rank synchronous filter."""
@@ -718,7 +719,7 @@ def test_auto_mode_two_ranks_on_one_card(pkg, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / "auto2")
     outs = {}
-    for world, mode, port in ((1, "sync", 29711), (2, "auto", 29712)):
+    for world, mode, port in ((1, "sync", 29711 + 10 * nranks), (nranks, "auto", 29712 + 10 * nranks)):
         procs = []
         for r in range(world):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
