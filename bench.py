@@ -306,7 +306,7 @@ def hbm_bytes(rec):
     return (2.0 * rec["fetch_kb"] + rec["write_kb"]) * 1024.0
 
 
-def literal_cpu_legs(budget_s=12.0):
+def literal_cpu_legs(budget_s=12.0, landmarks=10000, nobs=64):
     """the LITERAL dense restatement (oracle/ekf_ref.py: dense 2 x n Jacobians, dense H*P*H' per pair, as
     the reference computes) timed at C2 (N = 1000, 16 observations, fp64) on a bounded sample -- one observation against
     all 1000 landmarks for the association, one dense batched update -- and the probe for a `julia` binary."""
@@ -334,10 +334,26 @@ def literal_cpu_legs(budget_s=12.0):
                        f"extrapolated to the 16000 of a step) + one dense batched update ({t_upd * 1e3:.0f} ms); the literal form is "
                        f"O(nz N n^2) and is not timed at N = 10k"}]
     jl = shutil.which("julia")
-    legs.append({"kind": "julia", "available": bool(jl), "path": jl,
-                 "note": "the reference is Julia 0.5/0.6 source that does not parse on Julia >= 1.0; no julia binary on this node"
-                         if not jl else "a julia binary exists, but the reference's own sources do not parse on Julia >= 1.0 and the "
-                                        "repo ships no Julia restatement of them: not timed"})
+    leg = {"kind": "julia", "available": bool(jl), "path": jl}
+    if not jl:
+        leg["note"] = ("no julia binary on this node.  oracle/ekf_ref.jl (a Julia-1.x restatement of src/ekf.jl, "
+                       "src/data-association.jl and the observation model; the reference's own 0.5/0.6 sources do not parse on "
+                       "Julia >= 1.0) would be timed here: `julia oracle/ekf_ref.jl --bench N nz seconds`")
+    else:
+        # the Julia restatement on this node's host cores, same workload shape, bounded to ~15 s
+        import subprocess
+        env = dict(os.environ, JULIA_NUM_THREADS=str(min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))))
+        try:
+            r = subprocess.run([jl, os.path.join(ROOT, "oracle", "ekf_ref.jl"), "--bench", str(landmarks), str(nobs), "15"],
+                               capture_output=True, text=True, timeout=600, env=env)
+            line = next((ln for ln in r.stdout.splitlines() if ln.startswith("{")), None)
+            if r.returncode == 0 and line:
+                leg.update(json.loads(line))
+            else:
+                leg["note"] = "oracle/ekf_ref.jl failed: " + (r.stderr or r.stdout)[-400:]
+        except Exception as e:  # noqa: BLE001 -- a reported baseline, never fatal
+            leg["note"] = f"oracle/ekf_ref.jl could not be run: {e}"
+    legs.append(leg)
     return legs
 
 
@@ -600,7 +616,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(x, P, zs, args.cpu_budget)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-            out["cpu_baseline"]["other_legs"] = literal_cpu_legs()
+            out["cpu_baseline"]["other_legs"] = literal_cpu_legs(landmarks=N, nobs=nz)
         if fast is not None:
             fast["roofline"]["traffic"] = hbm_bytes((pmc or {}).get("pf_step"))
             out["fastslam"] = fast

@@ -304,8 +304,34 @@ int slam_pf_resume(slam_pf_t h, int64_t resamplings);   /* resamplings: the call
  * filter state (slam.jl_amd/pf.py: FastSLAM.resamples). */
 int slam_pf_resample_count(slam_pf_t h, int64_t* count);        /* (waits for the queue, like slam_pf_flush) */
 int slam_pf_set_resample_count(slam_pf_t h, int64_t count);
-/* The ranks' shared scalar page (host memory every rank has mapped, >= 2 * world * 64 bytes, zeroed): see above. */
+/* The ranks' shared scalar page (host memory every rank has mapped, >= 2 * world * 64 bytes, zeroed): see above.
+ * (The legacy form of the per-step exchange; with slam_pf_attach_peers the scalars travel GPU to GPU.) */
 int slam_pf_attach_exchange(slam_pf_t h, int rank, int world, void* page, size_t bytes);
+
+/* ---- sharding behind the C ABI: peers (SURVEY 8b `n_devices`, 8e) --------------------------------------------------
+ * The particle types the reference declares (Particle / PFSlamState, src/common.jl:14-20,31-34) say nothing about
+ * devices; SURVEY 8e: one process per GPU, rank r owns the global particle ids [r n, (r + 1) n).  The library links no
+ * collective library: at set-up every rank exports ONE blob (SLAM_PF_PEER_BLOB_BYTES: hipIpc handles of its pose /
+ * landmark / log-weight / ancestor-table buffers and of an inbox page; raw pointers for shards of the same process),
+ * the CALLER moves the blobs between the ranks (MPI_Allgather, files, torch.distributed -- 1 KB per rank, once), and
+ * every rank attaches all `world` blobs in rank order (<= 8 ranks, equal slices).  After that
+ *   - the per-step scalars (max, sum w, sum w^2) are written by each rank's GPU into every peer's inbox over xGMI and
+ *     polled in LOCAL device memory (no host page, no PCIe);
+ *   - a step that resamples does so ON THE DEVICE, like a one-GPU filter: the all-gather of the log-weights is the
+ *     scan kernel's loads from the peers' buffers, remote ancestors' poses and ancestor-table entries are read from
+ *     their owners, and the particles' MAPS do not move at all -- a table entry is a global particle id and a remote
+ *     ancestor's landmark record is read from its owner when that landmark is next updated.  slam_pf_step_auto never
+ *     returns SLAM_PF_HALTED for this reason (only when the ancestor-table pool is exhausted, or SLAMHIP_PF_EAGER=1).
+ * Entry points that need plain maps (slam_pf_download with landmarks, slam_pf_pack, slam_pf_resample_apply, the legacy
+ * sweeps slam_pf_update_known / slam_pf_step / slam_pf_step_proposal, slam_pf_update_unknown, slam_pf_detach_peers) are
+ * COLLECTIVE while peers are attached: every rank must call them in the same order (they first bring remote records
+ * home, with barriers among the ranks' streams).  Detach (collectively) before any rank destroys its handle.
+ * slam_pf_comm_info: out = {ranks, 1 if peers are attached, SLAM_PF_HALTED returns so far, resamplings so far}. */
+#define SLAM_PF_PEER_BLOB_BYTES 1024
+int slam_pf_export_peer(slam_pf_t h, void* blob);
+int slam_pf_attach_peers(slam_pf_t h, int rank, int world, const void* blobs);
+int slam_pf_detach_peers(slam_pf_t h);
+int slam_pf_comm_info(slam_pf_t h, int64_t out[4]);
 /* Diagnostics: 100 MHz wall-clock stamps of the last auto step: kernel start, every workgroup's statistics collected,
  * statistics folded, decision taken, bookkeeping done, published; [6] the collecting workgroup finished its own share,
  * [7] = [0] + 100 x the number of polls it needed.  Waits for the queue. */

@@ -16,7 +16,7 @@ export SlamState, EKFSlamState, set_state!, predict, update, add_features, assoc
        compute_association, predict_observation, mpi_to_pi,
        ekf_predict!, ekf_update!, augment!, observe!, cov_block, cov_diag, feature_ellipses, vehicle_ellipse,
        PFSlamState, set_pose!, init_landmarks!, pf_predict!, update_known!, step!, step_async!, flush!,
-       resample!, mean_pose, weights, particles
+       resample!, mean_pose, weights, particles, peer_blob, attach_peers!, detach_peers!, comm_info
 
 const libslamhip = get(ENV, "SLAMHIP_LIB", joinpath(@__DIR__, "libslamhip.so"))
 
@@ -257,30 +257,68 @@ end
 # ---- PFSlamState: the FastSLAM-1.0 particle filter -----------------------------------------------
 # The reference declares `Particle` / `PFSlamState` (src/common.jl:14-20,31-34) and no filter code (README.md:6);
 # the algorithm is the one specified from the reference's EKF building blocks (include/slamhip.h, "FastSLAM").
-# These wrappers cover a filter that lives on ONE GPU -- every call is one `ccall`; a filter sharded over several
-# GPUs additionally needs the collectives between the calls (slam.jl_amd/pf.py shows the sequence).
+# Every call is one `ccall`.  A filter SHARDED over several GPUs (one Julia process per GPU, or one task per GPU in
+# one process) needs no collective library either: each rank constructs its slice (`rank`, `world`), the ranks swap
+# their `peer_blob`s once (MPI.Allgather, a shared file, Distributed -- 1 KB per rank) and `attach_peers!`; from then on
+# the per-step scalars travel GPU to GPU and a resampling step stays on the device (include/slamhip.h, "peers").
+
+const SLAM_PF_PEER_BLOB_BYTES = 1024
 
 """
-    PFSlamState{T}(n, max_landmarks; seed = 0, device = 0)
+    PFSlamState{T}(n, max_landmarks; seed = 0, device = 0, rank = 0, world = 1)
 
-`PFSlamState{T}` (src/common.jl:31-34) with `n` particles, device resident (structure of arrays:
-`pose[3][n]`, `logw[n]`, `lm[max_landmarks][5][n]`).
+`PFSlamState{T}` (src/common.jl:31-34) with `n` particles IN ALL, device resident (structure of arrays:
+`pose[3][n]`, `logw[n]`, `lm[max_landmarks][5][n]`).  `world > 1`: this process owns the global particle ids
+`rank * n / world ... (rank + 1) * n / world - 1` on its GPU; see `peer_blob` / `attach_peers!`.
 """
 mutable struct PFSlamState{T<:Union{Float32,Float64}} <: SlamState
     handle::Ptr{Cvoid}
-    n::Int
+    n::Int                  # particles on THIS rank
     max_landmarks::Int
-    function PFSlamState{T}(n::Integer, max_landmarks::Integer; seed::Integer = 0, device::Integer = 0) where {T}
+    rank::Int
+    world::Int
+    function PFSlamState{T}(n::Integer, max_landmarks::Integer; seed::Integer = 0, device::Integer = 0, rank::Integer = 0,
+                            world::Integer = 1) where {T}
+        n % world == 0 || error("n must be divisible by the number of ranks")
+        per = div(n, world)
         h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:slam_pf_create, libslamhip), Cint,
                     (Ref{Ptr{Cvoid}}, Cint, Int64, Int64, Int64, Cint, Cint, UInt64),
-                    h, T === Float32 ? SLAM_F32 : SLAM_F64, n, n, 0, max_landmarks, device, seed))
-        s = new{T}(h[], n, max_landmarks)
+                    h, T === Float32 ? SLAM_F32 : SLAM_F64, per, n, rank * per, max_landmarks, device, seed))
+        s = new{T}(h[], per, max_landmarks, rank, world)
         finalizer(s) do st
             ccall((:slam_pf_destroy, libslamhip), Cint, (Ptr{Cvoid},), st.handle)
         end
         return s
     end
+end
+
+"This rank's peer blob (IPC handles of its buffers and inbox): every rank needs every rank's."
+function peer_blob(s::PFSlamState)
+    blob = zeros(UInt8, SLAM_PF_PEER_BLOB_BYTES)
+    check(ccall((:slam_pf_export_peer, libslamhip), Cint, (Ptr{Cvoid}, Ptr{UInt8}), s.handle, blob))
+    blob
+end
+
+"`blobs`: the `world` peer blobs in rank order.  Afterwards `step_async!` resamples the sharded filter on the device."
+function attach_peers!(s::PFSlamState, blobs::AbstractVector)
+    length(blobs) == s.world || error("one blob per rank")
+    all = reduce(vcat, [Vector{UInt8}(b) for b in blobs])
+    check(ccall((:slam_pf_attach_peers, libslamhip), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}), s.handle, s.rank, s.world, all))
+    s
+end
+
+"Collective: remote records come home, the peers are detached (call on every rank before any rank lets its state go)."
+function detach_peers!(s::PFSlamState)
+    check(ccall((:slam_pf_detach_peers, libslamhip), Cint, (Ptr{Cvoid},), s.handle))
+    s
+end
+
+"[ranks, 1 if peers are attached, SLAM_PF_HALTED returns so far, resamplings so far]"
+function comm_info(s::PFSlamState)
+    out = zeros(Int64, 4)
+    check(ccall((:slam_pf_comm_info, libslamhip), Cint, (Ptr{Cvoid}, Ptr{Int64}), s.handle, out))
+    out
 end
 
 "Every particle at `pose`, uniform weights (Particle.pose, src/common.jl:15)."

@@ -13,6 +13,7 @@ from ._lib import NotPositiveDefinite, SlamHipError, device_count  # noqa: F401
 from .ekf import (DeviceRef, EKFSlamState, SlamState, add_features, associate, augment_,  # noqa: F401
                   compute_association, ekf_predict_, ekf_update_, mpi_to_pi, predict, predict_observation,
                   observe, update)
-from .pf import FastSLAM, PFShard, PFSlamState, TorchComm, philox_uniform, shared_page, small  # noqa: F401
+from .pf import (FastSLAM, PFShard, PFSlamState, TorchComm, attach_local_peers, philox_uniform, shared_page,  # noqa: F401
+                 small)
 from . import sim  # noqa: F401
 from . import telemetry  # noqa: F401

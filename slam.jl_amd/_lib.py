@@ -22,6 +22,7 @@ SLAM_E_NOTPD = -3
 SLAM_E_HIP = -4
 SLAM_E_NOMEM = -5
 SLAM_PF_HALTED = 1
+SLAM_PF_PEER_BLOB_BYTES = 1024
 SLAM_F32, SLAM_F64 = 0, 1
 SLAM_FORM_CHOLESKY, SLAM_FORM_JOSEPH = 0, 1
 KERNEL_IDS = {"gate": 0, "gate_final": 1, "predict": 2, "augment": 3, "pht": 4, "factor": 5, "w1": 6, "syrk": 7}
@@ -130,6 +131,10 @@ SIGNATURES = {
     "slam_pf_resample_count": (C.c_int, [_h, C.POINTER(C.c_int64)]),
     "slam_pf_set_resample_count": (C.c_int, [_h, C.c_int64]),
     "slam_pf_attach_exchange": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    "slam_pf_export_peer": (C.c_int, [_h, C.c_void_p]),
+    "slam_pf_attach_peers": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p]),
+    "slam_pf_detach_peers": (C.c_int, [_h]),
+    "slam_pf_comm_info": (C.c_int, [_h, C.POINTER(C.c_int64)]),
     "slam_pf_debug_stamps": (C.c_int, [_h, C.POINTER(C.c_uint64)]),
     "slam_pf_resample": (C.c_int, [_h, C.c_double, C.POINTER(C.c_int)]),
     "slam_pf_get_mean_pose": (C.c_int, [_h, _dp]),

@@ -32,6 +32,21 @@ void slam_set_error(const char* fmt, ...);
         }                                                                              \
     } while (0)
 
+// ---- roctx ranges around the C-ABI calls (tracing) -------------------
+// rocprofv3 --marker-trace shows one range per library call, named after the entry point.  The marker library
+// (librocprofiler-sdk-roctx / libroctx64) is looked up with dlopen at the first call -- already loaded by the tool or
+// the application, or loaded here when SLAMHIP_ROCTX=1 -- so libslamhip.so itself still depends on libamdhip64 only;
+// without it the ranges cost one predictable branch.
+void slam_roctx_push(const char* name);
+void slam_roctx_pop(void);
+struct SlamRange {
+    explicit SlamRange(const char* name) { slam_roctx_push(name); }
+    ~SlamRange() { slam_roctx_pop(); }
+    SlamRange(const SlamRange&) = delete;
+    SlamRange& operator=(const SlamRange&) = delete;
+};
+#define SLAM_RANGE() SlamRange slam_range_scope_(__func__)
+
 // ---- geometry of the buffers -------------------------------------------------
 // Covariance tile edge of the rank-k down-date; the panel buffers (PHt, W1, ...)
 // are padded to whole tiles with zero rows so the down-date needs no row guards.
@@ -40,6 +55,23 @@ void slam_set_error(const char* fmt, ...);
 #define SLAM_KPAD 32
 
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// A/B knobs of the measurement tooling (tile order, workgroups per list, super-row height, the scalar factorisation ...):
+// read from the environment ONLY in the experiments build (`make exp`, libslamhip_exp.so); the product library always
+// takes the default, so no untested code path can be switched on from outside.  What the product library does read:
+// SLAMHIP_X bits 8 / 32 / 64 (fp32 matrix cores instead of the split-bf16 down-date; pre-gate never / always) and
+// SLAMHIP_PF_EAGER -- each has a test of its own.
+#ifdef SLAMHIP_EXPERIMENTS
+#include <stdlib.h>
+static inline int slam_exp_env(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+constexpr int SLAM_XFLAGS_MASK = ~0;
+#else
+static inline int slam_exp_env(const char*, int dflt) { return dflt; }
+constexpr int SLAM_XFLAGS_MASK = 8 | 32 | 64;
+#endif
 
 struct TimingPair {
     hipEvent_t a, b;

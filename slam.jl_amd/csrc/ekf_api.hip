@@ -24,6 +24,40 @@ void slam_set_error(const char* fmt, ...) {
 
 extern "C" const char* slam_last_error(void) { return g_err; }
 
+// ---- roctx (see common.h) ----------------------------------------------------------
+#include <dlfcn.h>
+#include <mutex>
+namespace {
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)(void);
+roctx_push_fn g_roctx_push = nullptr;
+roctx_pop_fn g_roctx_pop = nullptr;
+std::once_flag g_roctx_once;
+void roctx_resolve() {
+    const char* names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
+    const char* env = getenv("SLAMHIP_ROCTX");
+    const bool want = env && atoi(env) != 0;
+    if (env && !want) return;                                     // SLAMHIP_ROCTX=0: never
+    void* lib = nullptr;
+    for (const char* n : names)
+        if ((lib = dlopen(n, RTLD_LAZY | RTLD_NOLOAD))) break;      // the profiler (or the application) has it loaded already
+    if (!lib && want)
+        for (const char* n : names)
+            if ((lib = dlopen(n, RTLD_LAZY | RTLD_GLOBAL))) break;
+    if (!lib) return;
+    g_roctx_push = (roctx_push_fn)dlsym(lib, "roctxRangePushA");
+    g_roctx_pop = (roctx_pop_fn)dlsym(lib, "roctxRangePop");
+    if (!g_roctx_push || !g_roctx_pop) g_roctx_push = nullptr, g_roctx_pop = nullptr;
+}
+}  // namespace
+void slam_roctx_push(const char* name) {
+    std::call_once(g_roctx_once, roctx_resolve);
+    if (g_roctx_push) (void)g_roctx_push(name);
+}
+void slam_roctx_pop(void) {
+    if (g_roctx_pop) (void)g_roctx_pop();
+}
+
 extern "C" int slam_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {
@@ -268,8 +302,11 @@ extern "C" int slam_ekf_create(slam_ekf_t* out, int dtype, int max_landmarks, in
     h->debug_flags = getenv("SLAMHIP_DEBUG") ? atoi(getenv("SLAMHIP_DEBUG")) : 0;
 #endif
     h->dd_prof = nullptr;
-    h->xflags = getenv("SLAMHIP_X") ? atoi(getenv("SLAMHIP_X")) : 0;
+    h->xflags = (getenv("SLAMHIP_X") ? atoi(getenv("SLAMHIP_X")) : 0) & SLAM_XFLAGS_MASK;
+    h->factor_blocked = 1;
+#ifdef SLAMHIP_EXPERIMENTS
     h->factor_blocked = !(getenv("SLAMHIP_FACTOR") && !strcmp(getenv("SLAMHIP_FACTOR"), "scalar"));
+#endif
     h->timing = 0;
     for (int i = 0; i < SLAM_K_COUNT; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
     const int rc = create_impl(h);
@@ -328,14 +365,17 @@ static int set_state_impl(slam_ekf* h, const void* x, const void* P, int n, int 
 }
 
 extern "C" int slam_ekf_set_state(slam_ekf_t h, const void* x, const void* P, int n, int ldP) {
+    SLAM_RANGE();
     return set_state_impl(h, x, P, n, ldP, hipMemcpyHostToDevice);
 }
 
 extern "C" int slam_ekf_set_state_device(slam_ekf_t h, const void* d_x, const void* d_P, int n, int ldP) {
+    SLAM_RANGE();
     return set_state_impl(h, d_x, d_P, n, ldP, hipMemcpyDeviceToDevice);
 }
 
 extern "C" int slam_ekf_get_state(slam_ekf_t h, void* x, void* P, int n, int ldP) {
+    SLAM_RANGE();
     ARG_CHECK(h != nullptr, "null handle");
     ARG_CHECK(n == 3 + 2 * h->N, "n does not match the state (3 + 2*N)");
     ARG_CHECK(P == nullptr || ldP >= n, "ldP < n");
@@ -387,6 +427,7 @@ static int get_gathered(slam_ekf* h, int r0, int c0, int nr, int nc, int diag, v
 }
 
 extern "C" int slam_ekf_get_block(slam_ekf_t h, int r0, int c0, int nr, int nc, void* out, int ld_out) {
+    SLAM_RANGE();
     ARG_CHECK(h != nullptr, "null handle");
     const int n = 3 + 2 * h->N;
     ARG_CHECK(nr >= 0 && nc >= 0, "negative block size");
@@ -416,6 +457,7 @@ extern "C" int slam_ekf_get_pose(slam_ekf_t h, double pose[3]) {
 
 /* feature_ellipses(x, cov) and the vehicle ellipse of monitor()  (sim/browser/wsserver.jl:60-65,72-85). */
 extern "C" int slam_ekf_ellipses(slam_ekf_t h, double* features, double vehicle[6]) {
+    SLAM_RANGE();
     ARG_CHECK(h != nullptr, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     const size_t cnt = (size_t)h->N + 1;
@@ -492,6 +534,7 @@ static int stage_obs(slam_ekf* h, const double* z, const int32_t* idf, int nobs)
 }
 
 extern "C" int slam_ekf_predict(slam_ekf_t h, double v, double g, double wheelbase, const double Q[4], double dt) {
+    SLAM_RANGE();
     ARG_CHECK(h != nullptr && Q != nullptr, "null argument");
     HIP_TRY(hipSetDevice(h->device));
     return launch_predict(h, v, g, wheelbase, Q, dt);
@@ -499,6 +542,7 @@ extern "C" int slam_ekf_predict(slam_ekf_t h, double v, double g, double wheelba
 
 extern "C" int slam_ekf_associate(slam_ekf_t h, const double* z, int nz, const double R[4], double gate1, double gate2,
                                   int32_t* assoc) {
+    SLAM_RANGE();
     ARG_CHECK(h != nullptr, "null handle");
     ARG_CHECK(nz >= 0, "nz < 0");
     if (nz == 0) return SLAM_OK;
@@ -560,6 +604,7 @@ static int read_status(slam_ekf* h, int sticky) {
 }
 
 extern "C" int slam_ekf_update(slam_ekf_t h, const double* zf, const int32_t* idf, int m, const double R[4], int form) {
+    SLAM_RANGE();
     ARG_CHECK(h != nullptr, "null handle");
     ARG_CHECK(m >= 0, "m < 0");
     ARG_CHECK(form == SLAM_FORM_CHOLESKY || form == SLAM_FORM_JOSEPH, "unknown update form");
@@ -580,6 +625,7 @@ extern "C" int slam_ekf_update(slam_ekf_t h, const double* zf, const int32_t* id
 }
 
 extern "C" int slam_ekf_augment(slam_ekf_t h, const double* zn, int nn, const double R[4]) {
+    SLAM_RANGE();
     ARG_CHECK(h != nullptr, "null handle");
     ARG_CHECK(nn >= 0, "nn < 0");
     if (nn == 0) return SLAM_OK;
@@ -605,6 +651,7 @@ extern "C" int slam_ekf_augment(slam_ekf_t h, const double* zn, int nn, const do
  * new features to append. */
 extern "C" int slam_ekf_observe(slam_ekf_t h, const double* z, int nz, const double R[4], double gate1, double gate2, int form,
                                 int32_t* assoc) {
+    SLAM_RANGE();
     ARG_CHECK(h != nullptr, "null handle");
     ARG_CHECK(nz >= 0, "nz < 0");
     ARG_CHECK(form == SLAM_FORM_CHOLESKY || form == SLAM_FORM_JOSEPH, "unknown update form");
@@ -677,6 +724,7 @@ extern "C" int slam_ekf_set_async(slam_ekf_t h, int async_updates) {
 }
 
 extern "C" int slam_ekf_sync(slam_ekf_t h) {
+    SLAM_RANGE();
     ARG_CHECK(h != nullptr, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     if (h->pending_status) return read_status(h, 1);

@@ -885,7 +885,7 @@ __global__ __launch_bounds__(256) void downdate_f64_mfma(double* __restrict__ P,
 //          split-bf16 path (one-box A/B tools/gpu_order.sh: -3 %; with one workgroup per tile: -11 %).
 void build_tile_order(int T, std::vector<int2>& out, int order) {
     constexpr int NX = 8;
-    const int SR = getenv("SLAMHIP_SR") ? atoi(getenv("SLAMHIP_SR")) : 4;      // tile rows per super-row (experiment knob)
+    const int SR = slam_exp_env("SLAMHIP_SR", 4);      // tile rows per super-row (experiments build only)
     const int nsr = (T + SR - 1) / SR;
     std::vector<std::vector<int2>> lists(NX);
     if (order == 2) {
@@ -969,10 +969,10 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
         if (per_xcd < 1) per_xcd = 1;
 #ifdef SLAMHIP_EXPERIMENTS
         if (h->debug_flags & 32) {  // timing experiments on the split-bf16 path (1 no stores, 2 no MFMAs, 4 no P loads, 16 no split), launched like the product's
-            const bool bandB = !(getenv("SLAMHIP_ORDER") && atoi(getenv("SLAMHIP_ORDER")) == 0);
+            const bool bandB = slam_exp_env("SLAMHIP_ORDER", 2) != 0;
             const int2* lst = bandB ? (const int2*)h->tiles + h->tilesB_off : (const int2*)h->tiles;
             const int L = bandB ? h->tilesB_len : h->tiles_len;
-            int wgs = getenv("SLAMHIP_WGS") ? atoi(getenv("SLAMHIP_WGS")) : L;
+            int wgs = slam_exp_env("SLAMHIP_WGS", L);
             if (wgs > L) wgs = L;
             hipLaunchKernelGGL((downdate_f32_mfma<true, 4, 3, true>), dim3(8 * wgs), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,
                                (const float*)X, (const float*)Y, pitch, kp_total, lst, L,
@@ -1004,10 +1004,10 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
                 // CUs do not get equal shares of the memory system; tools/micro_tilewalk.hip shows the same 17 % on a
                 // bare read + rewrite of the tiles); the dispatcher keeps every CU busy to the end.  SLAMHIP_WGS =
                 // workgroups per XCD list (64 = two per CU) and SLAMHIP_ORDER=0 restore the old launch for A/B runs.
-                const bool bandB = !(getenv("SLAMHIP_ORDER") && atoi(getenv("SLAMHIP_ORDER")) == 0);
+                const bool bandB = slam_exp_env("SLAMHIP_ORDER", 2) != 0;
                 const int2* lst = bandB ? (const int2*)h->tiles + h->tilesB_off : (const int2*)h->tiles;
                 const int L = bandB ? h->tilesB_len : h->tiles_len;
-                int wgs = getenv("SLAMHIP_WGS") ? atoi(getenv("SLAMHIP_WGS")) : L;
+                int wgs = slam_exp_env("SLAMHIP_WGS", L);
                 if (wgs > L) wgs = L;
                 if (wgs < 1) wgs = 1;
                 hipLaunchKernelGGL((downdate_f32_mfma<false, 4, 3, true>), dim3(8 * wgs), dim3(NTHREADS), 0, h->stream,
@@ -1025,7 +1025,7 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
                                (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
                                h->d_status, h->xflags << 8, (unsigned long long*)nullptr, dcount, joseph, IMGARGS);
     } else {
-        const bool bandB = getenv("SLAMHIP_ORDER64") && atoi(getenv("SLAMHIP_ORDER64")) == 2;      // experiment knob (speed only)
+        const bool bandB = slam_exp_env("SLAMHIP_ORDER64", 0) == 2;      // experiments build only (speed only)
         const int2* lst = bandB ? (const int2*)h->tiles + h->tilesB_off : (const int2*)h->tiles;
         const int L = bandB ? h->tilesB_len : h->tiles_len;
         hipLaunchKernelGGL(downdate_f64_mfma, dim3(8 * L), dim3(256), 0, h->stream, (double*)h->P, h->ld, n,

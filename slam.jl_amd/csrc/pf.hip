@@ -20,6 +20,7 @@
 // resampling step, the log-weights of all particles; both collectives are issued by the host
 // (torch.distributed over RCCL), this library provides the local pieces.
 #include <stdlib.h>
+#include <unistd.h>
 
 #include <vector>
 
@@ -36,6 +37,27 @@
 constexpr int PF_CTL_TABS = 64;             // = PF_TAB_MAX (asserted below)
 constexpr int PF_CTL_MAXOBS = 64;           // = PF_AUTO_MAXOBS
 
+// ---- sharded filter: every rank's buffers as THIS rank's GPU addresses them (slam_pf_attach_peers) ---------------------
+// One process per GPU; at attach time the ranks exchange IPC handles of their state buffers and of an "inbox" page, so every
+// rank's kernels can read every peer's log-weights, poses, ancestor tables and landmark records over xGMI and WRITE into
+// every peer's inbox (per-step scalars, hand-shake words): posted writes to the peer, polls of local memory.
+constexpr int PF_MAX_WORLD = 8;
+struct PfInbox {                 // lives in its owner's device memory; slot [r] is written by rank r (its own too)
+    double scal[2][PF_MAX_WORLD][8];                 // per-step scalars, two parities: {max, sum w, sum w^2, step}
+    unsigned long long ready[PF_MAX_WORLD][8];       // [r][0]: last resampling step whose step kernel rank r has COMPLETED
+    unsigned long long bar[PF_MAX_WORLD][8];         // [r][0]: rank r's count of peer barriers (materialise)
+};
+struct PfPeers {                 // device memory of each rank, filled at attach time
+    void* pose[PF_MAX_WORLD][2];
+    void* lm[PF_MAX_WORLD][2];
+    void* logw[PF_MAX_WORLD][2];
+    int32_t* tab[PF_MAX_WORLD][2];
+    PfInbox* inbox[PF_MAX_WORLD];
+};
+constexpr int PF_ERR_HANDOVER = 1;   // a workgroup's statistics line never came (2 s)
+constexpr int PF_ERR_EXCHANGE = 2;   // a rank's per-step scalars never came (20 s): a rank is gone
+constexpr int PF_ERR_PEER = 3;       // a peer hand-shake (resampling / materialise barrier) timed out
+
 struct PfCtl {                   // device memory; written by the LAST workgroup of a step kernel, read by later kernels
     double shift_next;           // normalisation shift the next kernel that reads logw subtracts on the way
     double shift_scan;           // shift of the step that decided to resample (the cdf is formed through it)
@@ -46,9 +68,11 @@ struct PfCtl {                   // device memory; written by the LAST workgroup
     long long resample_seq;      // the step whose (lazy) resampling the conditional kernels apply
     long long halt_seq;          // != 0: that step wants a resampling the device cannot do; later steps are skipped
     int32_t arrive;              // (unused: the first form of the hand-over counted arrivals here)
-    int32_t error;               // 1: the scalar exchange between the ranks timed out
+    int32_t error;               // PF_ERR_*: the filter is dead, every later kernel returns at once
     int32_t nresamples;          // resamplings so far
     int32_t pcur, tside;         // live pose buffer / ancestor-table side
+    int32_t lwcur;               // live log-weight buffer (flips with every device-side resampling: the peers of a sharded
+                                 // filter still read the old weights while this rank already writes the uniform ones)
     int32_t identity;            // landmarks without an ancestor table
     int32_t tl_count, tl_fresh;  // the pending lazy resampling: live tables to compose, index of the fresh one (-1: none)
     int32_t tl_idx[PF_CTL_TABS];
@@ -85,7 +109,9 @@ struct slam_pf {
     hipStream_t stream;
     void* pose[2];       // [3][n]
     void* lm[2];         // [nl][5][n]
-    void* logw;          // [n]
+    void* logw;          // [n]: the LIVE one of logw2 (what the legacy entry points work on)
+    void* logw2[2];
+    int lwcur;
     int cur;             // landmarks: the buffer legacy (non-lazy) kernels work on; valid when !lazy_dirty
     int pcur;            // poses: which of the two buffers is live
     // Lazy resampling (whole filter on this shard): a resampling step permutes POSES and composes ancestor tables; a
@@ -131,9 +157,16 @@ struct slam_pf {
     long long pub_seq;           // last step whose publication to the mirror is enqueued (with it, or by the publish kernel)
     long long nresamples;        // resamplings so far (drives the systematic-resampling offset)
     std::vector<PfStepRec> log;       // queued steps not yet confirmed by the device (replayed after a halt)
-    double* d_xchg;              // device address of the ranks' shared scalar page (sharded filter), or null
+    double* d_xchg;              // device address of the ranks' shared scalar page (sharded filter, legacy form), or null
     void* xchg_host;
     int xchg_rank, xchg_world;
+    // peers (slam_pf_attach_peers): the sharded filter resamples on the device
+    PfPeers* d_peers;            // device copy of the table below (null: no peers attached)
+    PfPeers peers;
+    PfInbox* inbox;              // this rank's inbox (device memory, exported)
+    void* peer_open[PF_MAX_WORLD][9];   // what hipIpcOpenMemHandle returned (closed at detach); null for in-process peers
+    long long bar_count;         // peer barriers enqueued so far (the same on every rank: the calls are collective)
+    long long halts;             // SLAM_PF_HALTED returns so far
     double last_out[4];          // {Neff, resampled?, resamplings, step} of the last confirmed step
     int halted;                  // a sharded filter's step wants a resampling: the caller exchanges, then slam_pf_resume
     double halt_gmax;            // largest normalised log-weight of the halted step
@@ -559,11 +592,36 @@ __device__ __forceinline__ void row_store(const BufRow<T, R>& b, int64_t, int k,
     rec_store<T>(v, b.rs, b.voff, (uint32_t)k * b.row);
 }
 
+// How the sweep of a SHARDED filter resolves an ancestor-table entry: the entry is a GLOBAL particle id; its owner's
+// buffers are addressed through the peer table (this rank's own slice through the local descriptors, as before).
+struct PfShardCtx {
+    const PfPeers* peers;
+    uint32_t first, n;           // this rank's slice [first, first + n)
+    int rank, world;
+};
+template <typename T>
+__device__ __forceinline__ T ld_sys(const T* p) {          // a load that a peer GPU's store is visible to (sc0 sc1)
+    if constexpr (sizeof(T) == 4)
+        return __builtin_bit_cast(T, __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    else
+        return __builtin_bit_cast(T, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_SYSTEM));
+}
+// owner of global id g when the ranks own equal slices of n (world <= 8: seven compares instead of a division)
+__device__ __forceinline__ uint32_t pf_owner(uint32_t g, uint32_t n, int world) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 1; k < PF_MAX_WORLD; ++k) r += (k < world && g >= (uint32_t)k * n) ? 1u : 0u;
+    return r;
+}
+
 // The record of observation (code, meta) as particle p reads it: its own slot or, after a lazy resampling, its
-// ancestor's through the landmark's table.
-template <typename T, int AUX = 2>      // AUX: cache policy of a record read from the particle's own slot (2 = non-temporal)
+// ancestor's through the landmark's table.  SH (sharded filter with peers): the ancestor may live on another rank --
+// its record is then read from that rank's buffer over xGMI (system-scope loads; the owner wrote it in a kernel that
+// had completed before the resampling that created the entry, see pf_peer_gate_kernel).
+template <typename T, int AUX = 2, bool SH = false>      // AUX: cache policy of a record read from the particle's own slot (2 = non-temporal)
 __device__ __forceinline__ LmRow<T> sweep_load(const T* lm0, const T* lm1, const int32_t* __restrict__ tabs, int64_t n, uint32_t p,
-                                               int32_t code, int32_t meta) {
+                                               int32_t code, int32_t meta, const PfShardCtx& sc) {
     const int t = meta & META_TAB;
     const auto rs = lm_rsrc<T>(((meta & META_RBUF) ? lm1 : lm0) + (size_t)(code & ID_MASK) * 5 * n, n);
     const uint32_t row = (uint32_t)n * (uint32_t)sizeof(T);
@@ -573,13 +631,30 @@ __device__ __forceinline__ LmRow<T> sweep_load(const T* lm0, const T* lm1, const
         // keep the default cache policy (one-box A/B against non-temporal: 74.0 against 80.3 us per resampling step)
         const auto rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(tabs + (size_t)(t - 1) * n), (short)0,
                                                           (int)(uint32_t)(n * 4), 0x00020000);
-        const uint32_t slot = __builtin_amdgcn_raw_buffer_load_b32(rt, p * 4u, 0, 2);
-        const uint32_t voff = slot * (uint32_t)sizeof(T);
-        r.lx = rec_load<T, 0>(rs, voff, 0u);
-        r.ly = rec_load<T, 0>(rs, voff, row);
-        r.pxx = rec_load<T, 0>(rs, voff, 2u * row);
-        r.pxy = rec_load<T, 0>(rs, voff, 3u * row);
-        r.pyy = rec_load<T, 0>(rs, voff, 4u * row);
+        uint32_t slot = __builtin_amdgcn_raw_buffer_load_b32(rt, p * 4u, 0, 2);
+        bool local = true;
+        if constexpr (SH) {
+            const uint32_t owner = pf_owner(slot, sc.n, sc.world);
+            local = owner == (uint32_t)sc.rank;
+            if (!local) {
+                const T* base = (const T*)sc.peers->lm[owner][(meta & META_RBUF) ? 1 : 0] + (size_t)(code & ID_MASK) * 5 * n +
+                                (slot - owner * sc.n);
+                r.lx = ld_sys(base);
+                r.ly = ld_sys(base + n);
+                r.pxx = ld_sys(base + 2 * n);
+                r.pxy = ld_sys(base + 3 * n);
+                r.pyy = ld_sys(base + 4 * n);
+            }
+            slot -= sc.first;
+        }
+        if (local) {
+            const uint32_t voff = slot * (uint32_t)sizeof(T);
+            r.lx = rec_load<T, 0>(rs, voff, 0u);
+            r.ly = rec_load<T, 0>(rs, voff, row);
+            r.pxx = rec_load<T, 0>(rs, voff, 2u * row);
+            r.pxy = rec_load<T, 0>(rs, voff, 3u * row);
+            r.pyy = rec_load<T, 0>(rs, voff, 4u * row);
+        }
     } else {
         const uint32_t voff = p * (uint32_t)sizeof(T);
         r.lx = rec_load<T, AUX>(rs, voff, 0u);
@@ -591,7 +666,7 @@ __device__ __forceinline__ LmRow<T> sweep_load(const T* lm0, const T* lm1, const
     return r;
 }
 
-template <typename T>
+template <typename T, bool SH = false>
 struct KnownRing {
     LmRow<T> ring[PF_DEPTH];
     bool have[PF_DEPTH];
@@ -613,13 +688,13 @@ struct KnownRing {
     }
 
     __device__ __forceinline__ void start(const T* lm0, const T* lm1, const int32_t* __restrict__ tabs, int64_t n, uint32_t p,
-                                          const int32_t* s_ids, const int32_t* s_meta, int m) {
+                                          const int32_t* s_ids, const int32_t* s_meta, int m, const PfShardCtx& sc) {
 #pragma unroll
         for (int u = 0; u < PF_DEPTH; ++u) {
             have[u] = false;
             ring[u] = LmRow<T>{0, 0, 0, 0, 0};
             if (u < m && ahead(s_ids, u)) {
-                ring[u] = sweep_load<T>(lm0, lm1, tabs, n, p, uni(s_ids[u]), uni(s_meta[u]));
+                ring[u] = sweep_load<T, 2, SH>(lm0, lm1, tabs, n, p, uni(s_ids[u]), uni(s_meta[u]), sc);
                 have[u] = true;
             }
         }
@@ -627,7 +702,7 @@ struct KnownRing {
 
     __device__ __forceinline__ void run(T* lm0, T* lm1, const int32_t* __restrict__ tabs, int64_t n, uint32_t p,
                                         const T* s_obs, const int32_t* s_ids, const int32_t* s_meta, int m, T x, T y, T phi,
-                                        T R00, T R10, T R01, T R11, bool valid, T& lw) {
+                                        T R00, T R10, T R01, T R11, bool valid, T& lw, const PfShardCtx& sc) {
 #if defined(SLAMHIP_EXPERIMENTS) && defined(PF_EXP_NOOBS)           // timing experiment: no map updates
         m = 0;
 #endif
@@ -646,46 +721,46 @@ struct KnownRing {
                 have[u] = false;
                 const int j = i + PF_DEPTH;
                 if (j < m && ahead(s_ids, j)) {                    // uniform
-                    ring[u] = sweep_load<T>(lm0, lm1, tabs, n, p, uni(s_ids[j]), uni(s_meta[j]));
+                    ring[u] = sweep_load<T, 2, SH>(lm0, lm1, tabs, n, p, uni(s_ids[j]), uni(s_meta[j]), sc);
                     have[u] = true;
                 }
                 if (code & NEW_FLAG) {                             // F3: src/ekf.jl:94-103,112 without the pose term
                     lm_init<T>(row, n, x, y, phi, r, b, R00, R10, R01, R11, valid);
                     continue;
                 }
-                if (!have_cur) cur = sweep_load<T>(lm0, lm1, tabs, n, p, code, meta);
+                if (!have_cur) cur = sweep_load<T, 2, SH>(lm0, lm1, tabs, n, p, code, meta, sc);
                 lm_update<T>(row, n, cur, x, y, phi, r, b, R00, R10, R01, R11, valid, lw);
             }
         }
     }
 };
 
-template <typename T>
+template <typename T, bool SH = false>
 __device__ __forceinline__ void apply_known(T* lm0, T* lm1, const int32_t* __restrict__ tabs, int64_t n, int64_t p,
                                             const T* s_obs, const int32_t* s_ids, const int32_t* s_meta, int m, T x, T y,
-                                            T phi, T R00, T R10, T R01, T R11, bool valid, T& lw) {
-    KnownRing<T> k;
-    k.start(lm0, lm1, tabs, n, (uint32_t)p, s_ids, s_meta, m);
-    k.run(lm0, lm1, tabs, n, (uint32_t)p, s_obs, s_ids, s_meta, m, x, y, phi, R00, R10, R01, R11, valid, lw);
+                                            T phi, T R00, T R10, T R01, T R11, bool valid, T& lw, const PfShardCtx& sc) {
+    KnownRing<T, SH> k;
+    k.start(lm0, lm1, tabs, n, (uint32_t)p, s_ids, s_meta, m, sc);
+    k.run(lm0, lm1, tabs, n, (uint32_t)p, s_obs, s_ids, s_meta, m, x, y, phi, R00, R10, R01, R11, valid, lw, sc);
 }
 
 // One particle's filter step: predict (PREDICT), the m known-id updates, the log-weight.  Shared by the legacy kernels
 // (observation codes staged by the host) and the auto mode's kernel (codes planned on the device).
 // PRELOADED (the auto mode's kernel): x, y, phi hold the particle's pose, lw its stored log-weight and e1, e2 its two
 // normal deviates on entry -- requested / computed before the observation plan's barriers, off the critical path.
-template <typename T, bool PREDICT, bool PRELOADED = false>
+template <typename T, bool PREDICT, bool PRELOADED = false, bool SH = false>
 __device__ __forceinline__ void step_core(T* __restrict__ pose, T* lm0, T* lm1, const int32_t* __restrict__ tabs,
                                           T* __restrict__ logw, int64_t n, int64_t first, uint32_t step, uint64_t seed, T V, T G,
                                           T wheelbase, T sigV, T sigG, T dt, const T* s_obs, const int32_t* s_ids,
                                           const int32_t* s_meta, int m, T R00, T R10, T R01, T R11, T pend, int64_t p, bool valid,
-                                          T& x, T& y, T& phi, T& lw, T e1 = 0, T e2 = 0) {
+                                          T& x, T& y, T& phi, T& lw, T e1 = 0, T e2 = 0, const PfShardCtx& sc = PfShardCtx{}) {
     if (!PRELOADED) {
         x = pose[p]; y = pose[n + p]; phi = pose[2 * n + p];
         lw = logw[p];
     }
     lw -= pend;                   // `pend`: the normalisation shift deferred by slam_pf_normalize (0 if none)
-    KnownRing<T> known;
-    known.start(lm0, lm1, tabs, n, (uint32_t)p, s_ids, s_meta, m);      // the first records are in flight during the motion model
+    KnownRing<T, SH> known;
+    known.start(lm0, lm1, tabs, n, (uint32_t)p, s_ids, s_meta, m, sc);  // the first records are in flight during the motion model
     if (PREDICT) {
 #if defined(SLAMHIP_EXPERIMENTS) && defined(PF_EXP_NOPREDICT)       // timing experiment: no noise
         e1 = (T)0.1; e2 = (T)-0.1;
@@ -704,7 +779,7 @@ __device__ __forceinline__ void step_core(T* __restrict__ pose, T* lm0, T* lm1, 
         if (valid) { pose[p] = x; pose[n + p] = y; pose[2 * n + p] = phi; }
     }
     PF_XS(3);
-    known.run(lm0, lm1, tabs, n, (uint32_t)p, s_obs, s_ids, s_meta, m, x, y, phi, R00, R10, R01, R11, valid, lw);
+    known.run(lm0, lm1, tabs, n, (uint32_t)p, s_obs, s_ids, s_meta, m, x, y, phi, R00, R10, R01, R11, valid, lw, sc);
     if (valid) logw[p] = lw;
 }
 
@@ -739,12 +814,13 @@ __global__ __launch_bounds__(256) void pf_step_kernel(T* __restrict__ pose, T* l
 }
 
 // One particle's FastSLAM-2.0 step (see pf_proposal_kernel).  Shared by the legacy kernel and the auto mode's kernel.
-template <typename T>
+template <typename T, bool SH = false>
 __device__ __forceinline__ void proposal_core(T* __restrict__ pose, T* lm0, T* lm1, const int32_t* __restrict__ tabs,
                                               T* __restrict__ logw, int64_t n, int64_t first, uint32_t step, uint64_t seed, T V,
                                               T G, T wheelbase, T lq00, T lq10, T lq11, T dt, const T* s_obs,
                                               const int32_t* s_ids, const int32_t* s_meta, int m, T R00, T R10, T R01, T R11,
-                                              T pend, int64_t p, bool valid, T& xo, T& yo, T& po, T& lwo) {
+                                              T pend, int64_t p, bool valid, T& xo, T& yo, T& po, T& lwo,
+                                              const PfShardCtx& sc = PfShardCtx{}) {
     const T x = pose[p], y = pose[n + p], phi = pose[2 * n + p];
     // motion mean (w = 0) and GL = Gu Lq
     T s, c, sG, cG;
@@ -765,7 +841,7 @@ __device__ __forceinline__ void proposal_core(T* __restrict__ pose, T* lm0, T* l
     auto prior_row = [&](int j) {
         // (default cache policy: the second pass reads the same records again -- one-box A/B against non-temporal:
         //  69.0 against 73.5 us per step)
-        return sweep_load<T, 0>(lm0, lm1, tabs, n, (uint32_t)p, uni(s_ids[j]), uni(s_meta[j]) >> META_PRIOR_SHIFT);
+        return sweep_load<T, 0, SH>(lm0, lm1, tabs, n, (uint32_t)p, uni(s_ids[j]), uni(s_meta[j]) >> META_PRIOR_SHIFT, sc);
     };
     auto informative = [&](int j) { return j < m && !(uni(s_ids[j]) & (NEW_FLAG | FRESH_FLAG)); };
     LmRow<T> ring[PF_DEPTH];
@@ -854,7 +930,7 @@ __device__ __forceinline__ void proposal_core(T* __restrict__ pose, T* lm0, T* l
     const T pn = wrap_pi<T>(phi + Vn * dt * sgn / wheelbase);
     if (valid) { pose[p] = xn; pose[n + p] = yn; pose[2 * n + p] = pn; logw[p] = lw; }
     T unused = 0;
-    apply_known<T>(lm0, lm1, tabs, n, p, s_obs, s_ids, s_meta, m, xn, yn, pn, R00, R10, R01, R11, valid, unused);
+    apply_known<T, SH>(lm0, lm1, tabs, n, p, s_obs, s_ids, s_meta, m, xn, yn, pn, R00, R10, R01, R11, valid, unused, sc);
     xo = xn; yo = yn; po = pn; lwo = lw;
 }
 
@@ -1273,9 +1349,10 @@ __global__ __launch_bounds__(256) void pf_lazy_apply_kernel(const T* __restrict_
 
 // work[l]: -1 nothing to do, else (table + 1) | source buffer << 8 | destination buffer << 9
 constexpr int MAT_LMS = 12;      // landmarks per thread
-template <typename T>
+// SH (sharded filter with peers): a table entry is a global particle id; a remote ancestor's record is read from its owner.
+template <typename T, bool SH>
 __global__ __launch_bounds__(256) void pf_materialise_kernel(T* lm0, T* lm1, const int32_t* __restrict__ tabs, int64_t n, int nl,
-                                                              const int32_t* __restrict__ work) {
+                                                              const int32_t* __restrict__ work, PfShardCtx sc) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const int l0 = blockIdx.y * MAT_LMS, l1 = l0 + MAT_LMS < nl ? l0 + MAT_LMS : nl;
@@ -1283,12 +1360,25 @@ __global__ __launch_bounds__(256) void pf_materialise_kernel(T* lm0, T* lm1, con
         const int32_t w = work[l];
         if (w < 0) continue;                                   // (uniform)
         const int t = w & META_TAB;
-        const int64_t slot = t ? (int64_t)tabs[(size_t)(t - 1) * n + p] : p;
-        const T* src = ((w & META_RBUF) ? lm1 : lm0) + (size_t)l * 5 * n + slot;
+        int64_t slot = t ? (int64_t)tabs[(size_t)(t - 1) * n + p] : p;
+        const T* src = ((w & META_RBUF) ? lm1 : lm0) + (size_t)l * 5 * n;
+        bool remote = false;
+        if constexpr (SH) {
+            if (t) {
+                const uint32_t owner = pf_owner((uint32_t)slot, sc.n, sc.world);
+                remote = owner != (uint32_t)sc.rank;
+                slot -= (int64_t)owner * sc.n;
+                if (remote) src = (const T*)sc.peers->lm[owner][(w & META_RBUF) ? 1 : 0] + (size_t)l * 5 * n;
+            }
+        }
+        src += slot;
         T* dst = ((w & META_WBUF) ? lm1 : lm0) + (size_t)l * 5 * n + p;
         T v[5];
 #pragma unroll
-        for (int c = 0; c < 5; ++c) v[c] = src[(size_t)c * n];
+        for (int c = 0; c < 5; ++c) {
+            if constexpr (SH) v[c] = remote ? ld_sys(src + (size_t)c * n) : src[(size_t)c * n];
+            else v[c] = src[(size_t)c * n];
+        }
 #pragma unroll
         for (int c = 0; c < 5; ++c) dst[(size_t)c * n] = v[c];
     }
@@ -1329,7 +1419,7 @@ __host__ __device__ inline double resample_offset(uint32_t count, uint64_t seed)
 }
 
 struct PfAutoArgs {
-    void *pose0, *pose1, *lm0, *lm1, *logw;
+    void *pose0, *pose1, *lm0, *lm1, *logw0, *logw1;
     int32_t *tab0, *tab1;
     long long n, first, n_global, seq;
     unsigned long long seed;
@@ -1341,6 +1431,8 @@ struct PfAutoArgs {
     int32_t* lmstate;
     PfMirror* mir;
     double* xchg;
+    const PfPeers* peers;        // sharded filter with peers attached (else null)
+    PfInbox* inbox;              // this rank's inbox
     // The step's observations travel IN the kernel arguments (1.3 KB of the 4 KB a launch may carry): every one of the
     // ~1000 workgroups reads them at its start, and from a pinned host page (the zero-copy staging of the legacy
     // calls) that is ~5000 64-byte reads across PCIe per step -- measured: 19 us of a 46 us kernel before the first
@@ -1409,7 +1501,7 @@ __device__ __forceinline__ void pf_publish(PfMirror* mir, double neff, long long
     __hip_atomic_store(&mir->neff, neff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&mir->nresamples, nresamples, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&mir->resampled_seq, resampled_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (error) __hip_atomic_store(&mir->error, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (error) __hip_atomic_store(&mir->error, (long long)error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (halt_seq) {
         __hip_atomic_store(&mir->halt_seq, halt_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1428,7 +1520,7 @@ __global__ void pf_auto_publish_kernel(const PfCtl* __restrict__ ctl, PfMirror* 
 // Runs in the launch's last workgroup, after its own share of the sweep (all 256 threads).  s_l / s_st / s_first: this step's plan (LDS).
 template <typename T>
 __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t* s_l, const int32_t* s_st, const int32_t* s_first,
-                                             int pcur, int tside) {
+                                             int pcur, int tside, int lwcur) {
     __shared__ double sh[4];
     __shared__ double s_r6[4][6];
     __shared__ double s_g[12];
@@ -1470,7 +1562,7 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
             ++rounds;
             if (ok) break;
             __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t_poll > 200000000ull) { atomicOr(&s_perr, 1); break; }      // 2 s at 100 MHz: give up, report
+            if (wall_clock64() - t_poll > 200000000ull) { atomicOr(&s_perr, PF_ERR_HANDOVER); break; }      // 2 s at 100 MHz: give up, report
         }
     };
     collect(0);
@@ -1479,17 +1571,6 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
     __syncthreads();
     if (tid == 0) ctl->stamps[1] = wall_clock64();            // every workgroup's statistics are in
     if (tid == 0) ctl->stamps[7] = ctl->stamps[0] + 100ull * (unsigned long long)rounds;      // (diagnostic: polls of thread 0)
-    // ---- this step's state transitions (what pf_stage does on the host): one thread per observation; the state word
-    //      of every observed landmark is still in LDS from the plan ----
-    if (tid < a.m && s_first[tid]) {
-        const int32_t st = s_st[tid];
-        const int tab = st & LS_TAB, rb = (st & LS_BUF) ? 1 : 0;
-        if (tab) {
-            atomicSub(&s_tref[tab - 1], 1);
-            atomicAdd(&s_i[0], 1);                            // released its table: a landmark without one ("identity")
-        }
-        a.lmstate[s_l[tid]] = LS_SEEN | ((tab ? (rb ^ 1) : rb) ? LS_BUF : 0);
-    }
     // ---- fold the write-through partials (the order of fold_partials); 1024 records per pass ----
     double M = -__builtin_inf();
     double acc[6] = {0, 0, 0, 0, 0, 0};
@@ -1509,29 +1590,59 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
             acc[2] += qv(u, 3) * f; acc[3] += qv(u, 4) * f; acc[4] += qv(u, 5) * f; acc[5] += qv(u, 6) * f;
         }
     }
+    // ---- this step's state transitions (what pf_stage does on the host): one thread per observation; the state word
+    //      of every observed landmark is still in LDS from the plan.  Written only HERE, after the LAST collect(): every
+    //      workgroup of the launch has then stored its statistics line, i.e. has long finished planning from the state
+    //      words (a grid of more than 1024 workgroups is not resident at once: a workgroup beyond the first 1024 lines
+    //      may not even have started when collect(0) returns). ----
+    if (tid < a.m && s_first[tid]) {
+        const int32_t st = s_st[tid];
+        const int tab = st & LS_TAB, rb = (st & LS_BUF) ? 1 : 0;
+        if (tab) {
+            atomicSub(&s_tref[tab - 1], 1);
+            atomicAdd(&s_i[0], 1);                            // released its table: a landmark without one ("identity")
+        }
+        a.lmstate[s_l[tid]] = LS_SEEN | ((tab ? (rb ^ 1) : rb) ? LS_BUF : 0);
+    }
     block_reduce6(acc, s_r6);
     if (tid == 0) {
         ctl->stamps[2] = wall_clock64();
         double gM = M, gs1 = acc[0], gs2 = acc[1];
         int err = s_perr;                                     // a workgroup's statistics never came: halt and report
-        if (a.world > 1) {
-            // all-gather of (max, sum, sum2) through the ranks' shared page: two parities (a rank is at most one
-            // step ahead of the slowest), the sequence number is written last
-            double* page = a.xchg + (size_t)(a.seq & 1) * a.world * 8;
-            double* mine = page + (size_t)a.rank * 8;
-            __hip_atomic_store(mine + 0, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(mine + 1, acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(mine + 2, acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (a.world > 1 && !err) {
+            // all-gather of (max, sum, sum2) among the ranks, two parities (a rank is at most one step ahead of the
+            // slowest), the sequence number written last.  With peers attached every rank WRITES its four words into
+            // every rank's inbox (posted stores over xGMI; its own inbox too) and polls its OWN device memory; the legacy
+            // form goes through one page of pinned host memory that every rank has mapped.
             // (no fence: a system-scope release is a write-back of this XCD's whole L2, which the sweep has just filled
             //  with dirty landmark records; the three write-through stores are drained, then the sequence number goes out)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(mine + 3, (double)a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const int par = (int)(a.seq & 1);
+            if (a.peers) {
+                for (int r = 0; r < a.world; ++r) {
+                    double* mine = &a.peers->inbox[r]->scal[par][a.rank][0];
+                    __hip_atomic_store(mine + 0, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(mine + 1, acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(mine + 2, acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (int r = 0; r < a.world; ++r)
+                    __hip_atomic_store(&a.peers->inbox[r]->scal[par][a.rank][3], (double)a.seq, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                double* mine = a.xchg + ((size_t)par * a.world + a.rank) * 8;
+                __hip_atomic_store(mine + 0, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(mine + 1, acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(mine + 2, acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(mine + 3, (double)a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            const double* page = a.peers ? &a.inbox->scal[par][0][0] : a.xchg + (size_t)par * a.world * 8;
             const unsigned long long t0 = wall_clock64();
             for (int r = 0; r < a.world && !err; ++r) {
                 const double* slot = page + (size_t)r * 8;
                 while (__hip_atomic_load(slot + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (double)a.seq) {
                     __builtin_amdgcn_s_sleep(20);
-                    if (wall_clock64() - t0 > 2000000000ull) { err = 1; break; }     // 20 s at 100 MHz: a rank is gone
+                    if (wall_clock64() - t0 > 2000000000ull) { err = PF_ERR_EXCHANGE; break; }     // 20 s at 100 MHz: a rank is gone
                 }
             }
             if (!err) {
@@ -1552,8 +1663,9 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
         s_g[3] = gM + lg;                                                   // the normalisation shift
         s_g[4] = gs1 * gs1 / gs2;                                           // Neff
         s_g[5] = (double)((T)gM - (T)(gM + lg));                            // the largest log-weight after the shift, as stored
+        // (a failed step: outcome 2 = halt, with the error code in the control block; its statistics are not published)
         const int want = err ? 1 : (a.force >= 0 ? a.force : (s_g[4] < a.neff_frac * (double)a.n_global ? 1 : 0));
-        s_i[1] = want ? ((a.lazy_ok && a.world == 1 && !err) ? 1 : 2) : 0;
+        s_i[1] = want ? ((a.lazy_ok && !err) ? 1 : 2) : 0;
         s_i[2] = -1;
         s_i[3] = err;
     }
@@ -1584,21 +1696,25 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
     if (tid == 0) {
         ctl->stamps[4] = wall_clock64();
         const int outcome = s_i[1];
-        ctl->stats[0] = s_g[0]; ctl->stats[1] = s_g[1]; ctl->stats[2] = s_g[2];
-        // (weighted pose sums relative to the LOCAL maximum: shard-local, summed over the ranks by the caller)
-        ctl->stats[3] = acc[2]; ctl->stats[4] = acc[3]; ctl->stats[5] = acc[4]; ctl->stats[6] = acc[5];
-        ctl->stats[7] = s_g[4];
+        if (!s_i[3]) {                     // (a failed hand-over / exchange: the numbers are partial and are not recorded)
+            ctl->stats[0] = s_g[0]; ctl->stats[1] = s_g[1]; ctl->stats[2] = s_g[2];
+            // (weighted pose sums relative to the LOCAL maximum: shard-local, summed over the ranks by the caller)
+            ctl->stats[3] = acc[2]; ctl->stats[4] = acc[3]; ctl->stats[5] = acc[4]; ctl->stats[6] = acc[5];
+            ctl->stats[7] = s_g[4];
+            ctl->shift_scan = s_g[3];
+            ctl->gmax_norm = s_g[5];
+            ctl->shift_next = outcome == 1 ? 0.0 : s_g[3];                  // a resampling leaves uniform weights behind
+        } else {
+            ctl->error = s_i[3];
+        }
         ctl->seq = a.seq;
-        ctl->shift_scan = s_g[3];
-        ctl->gmax_norm = s_g[5];
-        ctl->shift_next = outcome == 1 ? 0.0 : s_g[3];                      // a resampling leaves uniform weights behind
-        if (s_i[3]) ctl->error = 1;
         ctl->identity = outcome == 1 ? 0 : s_i[0];                          // (a lazy resampling gives every landmark a table)
         if (outcome == 1) {
             ctl->u0 = resample_offset((uint32_t)nres0, a.seed);
             ctl->nresamples = nres0 + 1;
             ctl->pcur = pcur ^ 1;
             ctl->tside = tside ^ 1;
+            ctl->lwcur = lwcur ^ 1;
             ctl->resample_seq = a.seq;
         } else if (outcome == 2) {
             ctl->halt_seq = a.seq;
@@ -1618,7 +1734,7 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
 
 // (four waves per SIMD: at C4 the whole grid -- 1024 workgroups -- is then resident at once; one register more than 128
 //  and a quarter of the workgroups start when the first ones end, which was measured as +10 us per step)
-template <typename T, bool PROPOSAL>
+template <typename T, bool PROPOSAL, bool SH>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void pf_auto_step_kernel(PfAutoArgs a) {
     PfCtl* ctl = a.ctl;
     PF_XS(0);
@@ -1628,9 +1744,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void pf_auto_step_kern
 #endif
     // the control words this step needs, in one go (one cache line, one round trip)
     const long long halted = ctl->halt_seq;
-    const int pcur = ctl->pcur, tside = ctl->tside;
+    const int pcur = ctl->pcur, tside = ctl->tside, lwcur = ctl->lwcur;
     const double shift_next = ctl->shift_next;
-    if (halted != 0) return;                           // an earlier step waits for the host: the host replays this one
+    if (halted != 0 || ctl->error != 0) return;        // an earlier step waits for the host (which replays this one), or failed
     PF_XS(1);
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->stamps[0] = wall_clock64();
     __shared__ T s_obs[2 * PF_AUTO_MAXOBS];          // the observations in the state dtype: converted once per workgroup
@@ -1643,71 +1759,133 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void pf_auto_step_kern
     for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) s_obs[i] = (T)ka->z[i];
     const T pend = (T)shift_next;
     T* pose = (T*)(pcur ? a.pose1 : a.pose0);
+    T* logw = (T*)(lwcur ? a.logw1 : a.logw0);
     const int32_t* tabs = tside ? a.tab1 : a.tab0;
     const int64_t n = a.n;
     const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = pi < n;
     const int64_t p = valid ? pi : n - 1;              // idle lanes shadow the last particle, stores are masked
+    PfShardCtx sc{};
+    if constexpr (SH) sc = PfShardCtx{a.peers, (uint32_t)a.first, (uint32_t)a.n, a.rank, a.world};
     // the particle's pose and weight are requested, and its noise drawn, BEFORE the plan's two barriers and its dependent
     // loads (ids -> state words): the motion model then starts as soon as the plan stands
     T x = 0, y = 0, phi = 0, lw = 0, e1 = 0, e2 = 0;
     if (!PROPOSAL) {
         x = pose[p]; y = pose[n + p]; phi = pose[2 * n + p];
-        lw = ((const T*)a.logw)[p];
+        lw = logw[p];
         normals2<T>((uint64_t)(a.first + p), a.step, STREAM_PREDICT, a.seed, e1, e2);
     }
     plan_obs(&ka->ids[0], a.lmstate, m, s_l, s_st, s_ids, s_meta, s_first);
     PF_XS(2);
     if (PROPOSAL)
-        proposal_core<T>(pose, (T*)a.lm0, (T*)a.lm1, tabs, (T*)a.logw, n, a.first, a.step, a.seed, (T)a.V, (T)a.G, (T)a.wheelbase, (T)a.a0,
-                         (T)a.a1, (T)a.a2, (T)a.dt, s_obs, s_ids, s_meta, m, (T)a.R00, (T)a.R10, (T)a.R01, (T)a.R11, pend, p, valid, x,
-                         y, phi, lw);
+        proposal_core<T, SH>(pose, (T*)a.lm0, (T*)a.lm1, tabs, logw, n, a.first, a.step, a.seed, (T)a.V, (T)a.G, (T)a.wheelbase, (T)a.a0,
+                             (T)a.a1, (T)a.a2, (T)a.dt, s_obs, s_ids, s_meta, m, (T)a.R00, (T)a.R10, (T)a.R01, (T)a.R11, pend, p, valid, x,
+                             y, phi, lw, sc);
     else
-        step_core<T, true, true>(pose, (T*)a.lm0, (T*)a.lm1, tabs, (T*)a.logw, n, a.first, a.step, a.seed, (T)a.V, (T)a.G,
-                                 (T)a.wheelbase, (T)a.a0, (T)a.a1, (T)a.dt, s_obs, s_ids, s_meta, m, (T)a.R00, (T)a.R10, (T)a.R01,
-                                 (T)a.R11, pend, p, valid, x, y, phi, lw, e1, e2);
+        step_core<T, true, true, SH>(pose, (T*)a.lm0, (T*)a.lm1, tabs, logw, n, a.first, a.step, a.seed, (T)a.V, (T)a.G,
+                                     (T)a.wheelbase, (T)a.a0, (T)a.a1, (T)a.dt, s_obs, s_ids, s_meta, m, (T)a.R00, (T)a.R10, (T)a.R01,
+                                     (T)a.R11, pend, p, valid, x, y, phi, lw, e1, e2, sc);
     PF_XS(4);
     PF_WG(1);
     block_weight_stats<T, true>(lw, x, y, phi, valid, 1, a.part, a.seq);          // a tagged line, not waited for
     PF_XS(5);
     PF_WG(2);
-    // the workgroup that is dispatched last collects the lines (every other workgroup has been dispatched before it and
-    // finishes without it: the wait cannot deadlock, and it ends on a time-out)
-    if (blockIdx.x == gridDim.x - 1) pf_auto_tail<T>(a, s_l, s_st, s_first, pcur, tside);
+    // the workgroup with the highest index collects the lines.  The wait cannot deadlock because NO other workgroup waits
+    // for anything: each runs to its end on its own, whenever the dispatcher starts it (the dispatch order is not relied
+    // on), and the collection ends on a time-out
+    if (blockIdx.x == gridDim.x - 1) pf_auto_tail<T>(a, s_l, s_st, s_first, pcur, tside, lwcur);
 }
 
-// The cdf of the step that resamples (pf_scan1_kernel behind the control block's gate).
+// ---- the resampling of a SHARDED filter on the device --------------------------------------------------------------
+// Every rank takes the same decision from the same table of scalars (pf_auto_tail), so on a resampling step every rank
+// runs the same three conditional kernels behind its step kernel:
+//   gate      ONE workgroup: tells every peer "my step kernel of step s has COMPLETED" (stream order: its stores are in
+//             memory, the end of a kernel writes the L2s back) and waits until every peer has said so.  One workgroup,
+//             not a poll in every workgroup of the next kernel: ranks that share a card (the rehearsal) would fill it
+//             with spinning workgroups and the peer's kernel that has to send the word would never start.
+//   scan      the cdf of ALL n_global weights, every rank for itself: the all-gather of the log-weights is the kernel's
+//             loads -- a rank's slice is read straight from its owner's buffer over xGMI (1 MiB in all at C4).  Same
+//             blocks, same order of additions as on one rank: the ancestors are the same whatever the number of ranks.
+//   resample  this rank's ancestors (global ids), their poses and table entries read from their owners' buffers; the
+//             MAPS do not move: a table entry is a global particle id and the sweep reads a remote ancestor's record
+//             from its owner when the landmark is next updated (sweep_load<SH>).  Uniform weights go to the OTHER
+//             log-weight buffer, poses and tables to their other sides: a peer that is still reading this rank's
+//             step-s state reads buffers nobody writes.  Why no further hand-shake is needed: a rank writes those old
+//             sides again at its resampling s' > s at the earliest, which needs every rank's scalars of step s', which
+//             a rank publishes only after its own resampling s has completed (stream order).
+__global__ __launch_bounds__(64) void pf_peer_gate_kernel(PfCtl* ctl, long long seq, const PfPeers* __restrict__ peers,
+                                                          PfInbox* inbox, int rank, int world) {
+    if (ctl->resample_seq != seq || ctl->error != 0) return;
+    const int r = threadIdx.x;
+    if (r < world) {
+        __hip_atomic_store(&peers->inbox[r]->ready[rank][0], (unsigned long long)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(&inbox->ready[r][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < (unsigned long long)seq) {
+            __builtin_amdgcn_s_sleep(20);
+            if (wall_clock64() - t0 > 2000000000ull) { ctl->error = PF_ERR_PEER; break; }      // 20 s: a rank is gone
+        }
+    }
+}
+
+// A barrier among the ranks on their streams (materialise): every rank counts its calls, tells every peer, waits for all.
+__global__ __launch_bounds__(64) void pf_peer_barrier_kernel(PfCtl* ctl, unsigned long long count, const PfPeers* __restrict__ peers,
+                                                             PfInbox* inbox, int rank, int world) {
+    const int r = threadIdx.x;
+    if (r < world) {
+        __hip_atomic_store(&peers->inbox[r]->bar[rank][0], count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(&inbox->bar[r][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < count) {
+            __builtin_amdgcn_s_sleep(20);
+            if (wall_clock64() - t0 > 2000000000ull) { ctl->error = PF_ERR_PEER; break; }
+        }
+    }
+}
+
+// The cdf of the step that resamples (pf_scan1_kernel behind the control block's gate), over the weights of the WHOLE
+// filter: logw0 / logw1 are this rank's two buffers (n_local values each), the other slices come from `peers`.
 template <typename T>
-__global__ __launch_bounds__(SCAN_BLOCK) void pf_auto_scan1_kernel(const T* __restrict__ logw, int64_t n, const PfCtl* __restrict__ ctl,
+__global__ __launch_bounds__(SCAN_BLOCK) void pf_auto_scan1_kernel(const T* __restrict__ logw0, const T* __restrict__ logw1,
+                                                                    int64_t n_local, int64_t n_global, const PfCtl* __restrict__ ctl,
                                                                     long long seq, double* __restrict__ cdf,
-                                                                    double* __restrict__ bsum) {
-    if (ctl->resample_seq != seq) return;
+                                                                    double* __restrict__ bsum, const PfPeers* __restrict__ peers,
+                                                                    int rank, int world) {
+    if (ctl->resample_seq != seq || ctl->error != 0) return;
     __shared__ double sh[SCAN_BLOCK];
     const int64_t i = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
     const T pend = (T)ctl->shift_scan;
     const double gmax = ctl->gmax_norm;
-    sh[threadIdx.x] = i < n ? exp((double)(T)(logw[i] - pend) - gmax) : 0.0;
+    const int old = ctl->lwcur ^ 1;                    // (the tail has flipped the live side: the step's weights are in the other)
+    T v = 0;
+    if (i < n_global) {
+        const uint32_t owner = world > 1 ? pf_owner((uint32_t)i, (uint32_t)n_local, world) : 0u;
+        if (world > 1 && owner != (uint32_t)rank) v = ld_sys((const T*)peers->logw[owner][old] + (i - (int64_t)owner * n_local));
+        else v = (old ? logw1 : logw0)[i - (int64_t)owner * n_local];
+    }
+    sh[threadIdx.x] = i < n_global ? exp((double)(T)(v - pend) - gmax) : 0.0;
     __syncthreads();
     for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
-        const double v = threadIdx.x >= off ? sh[threadIdx.x - off] : 0.0;
+        const double u = threadIdx.x >= off ? sh[threadIdx.x - off] : 0.0;
         __syncthreads();
-        sh[threadIdx.x] += v;
+        sh[threadIdx.x] += u;
         __syncthreads();
     }
-    if (i < n) cdf[i] = sh[threadIdx.x];
+    if (i < n_global) cdf[i] = sh[threadIdx.x];
     if (threadIdx.x == SCAN_BLOCK - 1) bsum[blockIdx.x] = sh[threadIdx.x];
 }
 
 // Block offsets (pf_scan2_kernel's serial order, redone by every workgroup out of LDS), ancestors (pf_ancestor_kernel)
-// and the lazy apply (pf_lazy_apply_kernel) of the step that resamples, in one conditional launch.
+// and the lazy apply (pf_lazy_apply_kernel) of the step that resamples, in one conditional launch.  n: this rank's
+// particles, global ids [first, first + n); table entries and ancestors are GLOBAL ids (= local slots on one rank).
 constexpr int AUTO_NB_MAX = 2048;            // scan blocks (of 1024 particles) the fused offsets support
-template <typename T>
+template <typename T, bool SH>
 __global__ __launch_bounds__(256) void pf_auto_resample_kernel(T* pose0, T* pose1, int32_t* tab0, int32_t* tab1,
-                                                                T* __restrict__ logw, int64_t n, const PfCtl* __restrict__ ctl,
+                                                                T* logw0, T* logw1, int64_t n, int64_t first, int64_t n_global,
+                                                                const PfCtl* __restrict__ ctl,
                                                                 long long seq, const double* __restrict__ cdf,
                                                                 const double* __restrict__ bsum, int nb,
-                                                                int32_t* __restrict__ anc_out, T lw_uniform) {
-    if (ctl->resample_seq != seq) return;
+                                                                int32_t* __restrict__ anc_out, T lw_uniform,
+                                                                const PfPeers* __restrict__ peers, int rank, int world) {
+    if (ctl->resample_seq != seq || ctl->error != 0) return;
     __shared__ double s_off[AUTO_NB_MAX + 1];
     __shared__ int s_tl[PF_TAB_MAX];                       // the live tables to compose (once per workgroup, not once per use)
     for (int i = threadIdx.x; i < nb; i += 256) s_off[i] = bsum[i];
@@ -1726,7 +1904,7 @@ __global__ __launch_bounds__(256) void pf_auto_resample_kernel(T* pose0, T* pose
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const double total = s_off[nb];
-    const double target = ((double)p + ctl->u0) / (double)n * total;
+    const double target = ((double)(first + p) + ctl->u0) / (double)n_global * total;
     // first j with cdf[j] + offset(block of j) >= target, in two levels: the block out of LDS (the last element of block b
     // has exactly the value s_off[b + 1] = s_off[b] + bsum[b]), then ten steps inside it -- the same index as the plain
     // binary search of pf_ancestor_kernel over all n
@@ -1736,39 +1914,51 @@ __global__ __launch_bounds__(256) void pf_auto_resample_kernel(T* pose0, T* pose
         if (s_off[bm + 1] >= target) bh = bm; else bl = bm + 1;
     }
     int64_t lo = (int64_t)bl * SCAN_BLOCK, hi = lo + SCAN_BLOCK - 1;
-    if (hi > n - 1) hi = n - 1;
+    if (hi > n_global - 1) hi = n_global - 1;
     const double boff = s_off[bl];
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
         if (cdf[mid] + boff >= target) hi = mid; else lo = mid + 1;
     }
-    const int32_t a = (int32_t)lo;
+    const int32_t a = (int32_t)lo;                         // the ancestor's GLOBAL id
     anc_out[p] = a;
     // the tail has already flipped the buffers: the live ones are the destination
-    const int pnew = ctl->pcur, tnew = ctl->tside;
-    const T* __restrict__ pose_old = pnew ? pose0 : pose1;
+    const int pnew = ctl->pcur, tnew = ctl->tside, lnew = ctl->lwcur;
+    const uint32_t owner = SH ? pf_owner((uint32_t)a, (uint32_t)n, world) : 0u;
+    const bool remote = SH && owner != (uint32_t)rank;
+    const int64_t q = (int64_t)a - (int64_t)owner * n;     // the ancestor's slot on its owner
+    const T* pose_old = remote ? (const T*)peers->pose[owner][pnew ^ 1] : (pnew ? pose0 : pose1);
     T* __restrict__ pose_new = pnew ? pose1 : pose0;
-    const int32_t* __restrict__ tin = tnew ? tab0 : tab1;
+    const int32_t* tin = remote ? (const int32_t*)peers->tab[owner][tnew ^ 1] : (tnew ? tab0 : tab1);
     int32_t* __restrict__ tout = tnew ? tab1 : tab0;
     const int fresh = ctl->tl_fresh, count = ctl->tl_count;
     // Gathers in batches: ALL loads of a batch are issued before its first store.  (Written as load -> store per table,
     // with the table's index fetched from the control block each time, the compiler kept every pair in order behind a
     // full wait -- possible aliasing -- and the 31 live tables of the benchmark cost 31 serial round trips: 21 us.)
+    // A remote ancestor's pose and entries are read with system-scope loads (its owner's kernels have completed: gate).
+    auto ldp = [&](const T* ptr) {
+        if constexpr (SH) return remote ? ld_sys(ptr) : *ptr;
+        else return *ptr;
+    };
+    auto ldt = [&](const int32_t* ptr) {
+        if constexpr (SH) return remote ? ld_sys(ptr) : *ptr;
+        else return *ptr;
+    };
     T pv[3];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) pv[r] = pose_old[(size_t)r * n + a];
+    for (int r = 0; r < 3; ++r) pv[r] = ldp(pose_old + (size_t)r * n + q);
     constexpr int TB = 8;
     int32_t tv[TB];
 #pragma unroll
-    for (int u = 0; u < TB; ++u) tv[u] = u < count ? tin[(size_t)s_tl[u] * n + a] : 0;
+    for (int u = 0; u < TB; ++u) tv[u] = u < count ? ldt(tin + (size_t)s_tl[u] * n + q) : 0;
 #pragma unroll
     for (int r = 0; r < 3; ++r) pose_new[(size_t)r * n + p] = pv[r];
     if (fresh >= 0) tout[(size_t)fresh * n + p] = a;
-    logw[p] = lw_uniform;
+    (lnew ? logw1 : logw0)[p] = lw_uniform;
     for (int i0 = 0; i0 < count; i0 += TB) {
         int32_t tn[TB];
 #pragma unroll
-        for (int u = 0; u < TB; ++u) tn[u] = i0 + TB + u < count ? tin[(size_t)s_tl[i0 + TB + u] * n + a] : 0;    // the next batch
+        for (int u = 0; u < TB; ++u) tn[u] = i0 + TB + u < count ? ldt(tin + (size_t)s_tl[i0 + TB + u] * n + q) : 0;    // the next batch
 #pragma unroll
         for (int u = 0; u < TB; ++u)
             if (i0 + u < count) tout[(size_t)s_tl[i0 + u] * n + p] = tv[u];
@@ -1807,6 +1997,7 @@ inline int grid_for(int64_t n) { return (int)((n + 255) / 256); }
         }                              \
     } while (0)
 
+static void pf_detach_peers_impl(slam_pf* h);
 static int pf_auto_flush(slam_pf* h);      // wait for the steps slam_pf_step_auto has queued (resolving a halted one)
 static int pf_auto_leave(slam_pf* h);      // auto mode -> legacy mode: wait for the queue, bring the bookkeeping back to the host
 #define PF_LEGACY_ENTRY(h)                    \
@@ -1823,8 +2014,9 @@ extern "C" int slam_pf_destroy(slam_pf_t h) {
         if (h->pose[b]) (void)hipFree(h->pose[b]);
         if (h->lm[b]) (void)hipFree(h->lm[b]);
     }
-    void* devs[] = {h->logw, h->d_part, h->d_out, h->d_cdf, h->d_bsum, h->d_src, h->d_anc, h->d_tab[0], h->d_tab[1], h->d_lmeta,
-                    h->d_ctl, h->d_lmstate};
+    pf_detach_peers_impl(h);
+    void* devs[] = {h->logw2[0], h->logw2[1], h->d_part, h->d_out, h->d_cdf, h->d_bsum, h->d_src, h->d_anc, h->d_tab[0], h->d_tab[1],
+                    h->d_lmeta, h->d_ctl, h->d_lmstate, h->inbox};
     if (h->xchg_host) (void)hipHostUnregister(h->xchg_host);
     if (h->h_mir) (void)hipHostFree(h->h_mir);
     for (void* p : devs)
@@ -1848,7 +2040,17 @@ static int pf_create_impl(slam_pf* h) {
         if ((rc = pf_alloc(&h->pose[b], h->esz * 3 * n, h->stream))) return rc;
         if ((rc = pf_alloc(&h->lm[b], h->esz * 5 * n * (size_t)h->nl, h->stream))) return rc;
     }
-    if ((rc = pf_alloc(&h->logw, h->esz * n, h->stream))) return rc;
+    for (int b = 0; b < 2; ++b)
+        if ((rc = pf_alloc(&h->logw2[b], h->esz * n, h->stream))) return rc;
+    h->lwcur = 0;
+    h->logw = h->logw2[0];
+    // the inbox the peers of a sharded filter write into: fine-grained device memory (polled while a peer GPU writes it)
+    if (hipExtMallocWithFlags((void**)&h->inbox, sizeof(PfInbox), hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        h->inbox = nullptr;
+        HIP_TRY(hipMalloc((void**)&h->inbox, sizeof(PfInbox)));
+    }
+    HIP_TRY(hipMemsetAsync(h->inbox, 0, sizeof(PfInbox), h->stream));
     h->ocap = PF_OCAP;
     h->red_blocks = grid_for(h->n);                  // one partial record per 256 particles
     if ((rc = pf_alloc(&h->d_part, sizeof(double) * 8 * h->red_blocks, h->stream))) return rc;
@@ -1915,7 +2117,10 @@ extern "C" int slam_pf_create(slam_pf_t* out, int dtype, int64_t n_local, int64_
     h->prior.assign(max_landmarks, -1);
     h->d_tab[0] = h->d_tab[1] = nullptr; h->d_lmeta = nullptr; h->tside = 0; h->lazy_dirty = 0;
     h->lazy_off = getenv("SLAMHIP_PF_EAGER") && atoi(getenv("SLAMHIP_PF_EAGER")) ? 1 : 0;
-    h->pose[0] = h->pose[1] = h->lm[0] = h->lm[1] = h->logw = nullptr;
+    h->pose[0] = h->pose[1] = h->lm[0] = h->lm[1] = h->logw = h->logw2[0] = h->logw2[1] = nullptr;
+    h->lwcur = 0; h->d_peers = nullptr; h->inbox = nullptr; h->bar_count = 0; h->halts = 0;
+    memset(&h->peers, 0, sizeof(h->peers));
+    memset(h->peer_open, 0, sizeof(h->peer_open));
     h->h_ids = nullptr; h->h_obs = nullptr; h->ocap = 0;
     h->stage_ev[0] = h->stage_ev[1] = nullptr; h->stage_used[0] = h->stage_used[1] = 0; h->stage_slot = 0;
     h->d_part = h->d_out = h->h_out = h->d_cdf = h->d_bsum = nullptr; h->d_src = nullptr; h->d_anc = nullptr;
@@ -1940,11 +2145,28 @@ static void pf_release_table(slam_pf* h, int l) {
 
 // Bring every landmark to (buffer h->cur, identity table): what the non-lazy kernels expect.  Two passes at most:
 // a landmark that sits in h->cur behind a table cannot be gathered in place, it goes to the other buffer first.
+static bool pf_sharded(const slam_pf* h) { return h->d_peers != nullptr && h->xchg_world > 1; }
+
+static int pf_peer_barrier(slam_pf* h) {
+    h->bar_count += 1;
+    hipLaunchKernelGGL(pf_peer_barrier_kernel, dim3(1), dim3(64), 0, h->stream, h->d_ctl, (unsigned long long)h->bar_count,
+                       (const PfPeers*)h->d_peers, h->inbox, h->xchg_rank, h->xchg_world);
+    HIP_TRY(hipGetLastError());
+    return SLAM_OK;
+}
+
+// (Sharded filter with peers: a COLLECTIVE call -- the ancestor tables hold global particle ids and a remote ancestor's
+//  record is read from its owner, so every rank must be here, with barriers among the ranks' streams around the passes:
+//  pass 0 reads what the peers' earlier kernels wrote, pass 1 overwrites what the peers' pass 0 reads.)
 static int pf_materialise(slam_pf* h) {
     if (!h->lazy_dirty) return SLAM_OK;
     const int B = h->cur;
+    const bool sh = pf_sharded(h);
+    const PfShardCtx sc{h->d_peers, (uint32_t)h->first, (uint32_t)h->n, h->xchg_rank, h->xchg_world};
     std::vector<int32_t> work(h->nl);
+    if (sh) { const int rcb = pf_peer_barrier(h); if (rcb) return rcb; }
     for (int pass = 0; pass < 2; ++pass) {
+        if (sh && pass == 1) { const int rcb = pf_peer_barrier(h); if (rcb) return rcb; }
         bool any = false;
         for (int l = 0; l < h->nl; ++l) {
             const bool go = pass == 0 ? (h->lbuf[l] == B && h->ltab[l] >= 0) : (h->lbuf[l] != B);
@@ -1958,11 +2180,18 @@ static int pf_materialise(slam_pf* h) {
         HIP_TRY(hipMemcpyAsync(h->d_lmeta, work.data(), sizeof(int32_t) * h->nl, hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));             // `work` is pageable host memory
         const dim3 grid(grid_for(h->n), (h->nl + MAT_LMS - 1) / MAT_LMS);
-        PF_DISPATCH(h,
-                    hipLaunchKernelGGL(pf_materialise_kernel<T>, grid, dim3(256), 0, h->stream, (T*)h->lm[0], (T*)h->lm[1],
-                                       (const int32_t*)h->d_tab[h->tside], h->n, h->nl, (const int32_t*)h->d_lmeta),
-                    hipLaunchKernelGGL(pf_materialise_kernel<T>, grid, dim3(256), 0, h->stream, (T*)h->lm[0], (T*)h->lm[1],
-                                       (const int32_t*)h->d_tab[h->tside], h->n, h->nl, (const int32_t*)h->d_lmeta));
+        if (sh)
+            PF_DISPATCH(h,
+                        hipLaunchKernelGGL((pf_materialise_kernel<T, true>), grid, dim3(256), 0, h->stream, (T*)h->lm[0], (T*)h->lm[1],
+                                           (const int32_t*)h->d_tab[h->tside], h->n, h->nl, (const int32_t*)h->d_lmeta, sc),
+                        hipLaunchKernelGGL((pf_materialise_kernel<T, true>), grid, dim3(256), 0, h->stream, (T*)h->lm[0], (T*)h->lm[1],
+                                           (const int32_t*)h->d_tab[h->tside], h->n, h->nl, (const int32_t*)h->d_lmeta, sc));
+        else
+            PF_DISPATCH(h,
+                        hipLaunchKernelGGL((pf_materialise_kernel<T, false>), grid, dim3(256), 0, h->stream, (T*)h->lm[0], (T*)h->lm[1],
+                                           (const int32_t*)h->d_tab[h->tside], h->n, h->nl, (const int32_t*)h->d_lmeta, sc),
+                        hipLaunchKernelGGL((pf_materialise_kernel<T, false>), grid, dim3(256), 0, h->stream, (T*)h->lm[0], (T*)h->lm[1],
+                                           (const int32_t*)h->d_tab[h->tside], h->n, h->nl, (const int32_t*)h->d_lmeta, sc));
         HIP_TRY(hipGetLastError());
         for (int l = 0; l < h->nl; ++l)
             if (work[l] >= 0) {
@@ -1970,6 +2199,7 @@ static int pf_materialise(slam_pf* h) {
                 h->lbuf[l] = (int8_t)(pass == 0 ? (B ^ 1) : B);
             }
     }
+    if (sh) { const int rcb = pf_peer_barrier(h); if (rcb) return rcb; }
     h->lazy_dirty = 0;
     return SLAM_OK;
 }
@@ -2061,6 +2291,7 @@ extern "C" int slam_pf_init_landmarks(slam_pf_t h, const double* lm_xy, int nl, 
 }
 
 extern "C" int slam_pf_predict(slam_pf_t h, double V, double G, double wheelbase, const double Q[4], double dt) {
+    SLAM_RANGE();
     ARG_CHECK(h != nullptr && Q != nullptr, "null argument");
     HIP_TRY(hipSetDevice(h->device));
     PF_LEGACY_ENTRY(h);
@@ -2154,11 +2385,13 @@ static int pf_check_obs(slam_pf* h, const double* z, const int32_t* ids, int m, 
 }
 
 extern "C" int slam_pf_update_known(slam_pf_t h, const double* z, const int32_t* ids, int m, const double R[4]) {
+    SLAM_RANGE();
     ARG_CHECK(h != nullptr, "null handle");
     int rc = pf_check_obs(h, z, ids, m, R);
     if (rc || m == 0) return rc;
     HIP_TRY(hipSetDevice(h->device));
     PF_LEGACY_ENTRY(h);
+    if (pf_sharded(h)) { const int rcm = pf_materialise(h); if (rcm) return rcm; }   // (collective: the legacy sweep reads no remote records)
     const double* dz;
     const int32_t* di;
     if ((rc = pf_stage(h, z, ids, m, &dz, &di))) return rc;
@@ -2207,6 +2440,7 @@ static int pf_fold_and_read(slam_pf* h, int relative_to_max, double out[7]) {
  * slam_pf_update_known (bit for bit), same statistics as slam_pf_weight_stats.  Synchronises (the caller needs Neff). */
 extern "C" int slam_pf_step(slam_pf_t h, double V, double G, double wheelbase, const double Q[4], double dt, const double* z,
                             const int32_t* ids, int m, const double R[4], double out[3]) {
+    SLAM_RANGE();
     ARG_CHECK(h != nullptr && Q != nullptr && out != nullptr, "null argument");
     double Rz[4] = {0, 0, 0, 0};
     int rc = pf_check_obs(h, z, ids, m, m ? R : Rz);
@@ -2214,6 +2448,7 @@ extern "C" int slam_pf_step(slam_pf_t h, double V, double G, double wheelbase, c
     if (m) for (int i = 0; i < 4; ++i) Rz[i] = R[i];
     HIP_TRY(hipSetDevice(h->device));
     PF_LEGACY_ENTRY(h);
+    if (pf_sharded(h)) { const int rcm = pf_materialise(h); if (rcm) return rcm; }   // (collective: the legacy sweep reads no remote records)
     const double* dz = h->h_obs_dev;
     const int32_t* di = h->h_ids_dev;
     if (m && (rc = pf_stage(h, z, ids, m, &dz, &di))) return rc;
@@ -2242,6 +2477,7 @@ extern "C" int slam_pf_step(slam_pf_t h, double V, double G, double wheelbase, c
  * shapes the control noise).  With m == 0 it is slam_pf_step bit for bit. */
 extern "C" int slam_pf_step_proposal(slam_pf_t h, double V, double G, double wheelbase, const double Q[4], double dt,
                                      const double* z, const int32_t* ids, int m, const double R[4], double out[3]) {
+    SLAM_RANGE();
     ARG_CHECK(h != nullptr && Q != nullptr && out != nullptr, "null argument");
     double Rz[4] = {0, 0, 0, 0};
     int rc = pf_check_obs(h, z, ids, m, m ? R : Rz);
@@ -2253,6 +2489,7 @@ extern "C" int slam_pf_step_proposal(slam_pf_t h, double V, double G, double whe
     const double lq11 = sqrt(Q[3] - lq10 * lq10);
     HIP_TRY(hipSetDevice(h->device));
     PF_LEGACY_ENTRY(h);
+    if (pf_sharded(h)) { const int rcm = pf_materialise(h); if (rcm) return rcm; }   // (collective: the legacy sweep reads no remote records)
     const double* dz = h->h_obs_dev;
     const int32_t* di = h->h_ids_dev;
     if (m && (rc = pf_stage(h, z, ids, m, &dz, &di))) return rc;
@@ -2299,6 +2536,7 @@ extern "C" int slam_pf_clear_landmarks(slam_pf_t h) {
  * matched, -1 new, -2 dropped.  Enqueued. */
 extern "C" int slam_pf_update_unknown(slam_pf_t h, const double* z, int m, const double R[4], double gate1, double gate2,
                                       int32_t* d_assoc) {
+    SLAM_RANGE();
     ARG_CHECK(h != nullptr, "null handle");
     ARG_CHECK(m >= 0 && m <= UNK_MAX, "slam_pf_update_unknown takes at most 16 observations per call");
     if (m == 0) return SLAM_OK;
@@ -2429,6 +2667,7 @@ extern "C" int slam_pf_ancestors_all(slam_pf_t h, const void* d_logw_all, double
  * bit, as slam_pf_copy_logw + slam_pf_ancestors + slam_pf_resample_apply.  gmax: the maximum of the (normalised)
  * log-weights.  Enqueued. */
 extern "C" int slam_pf_resample_local(slam_pf_t h, double gmax, double u0) {
+    SLAM_RANGE();
     ARG_CHECK(h != nullptr, "null handle");
     ARG_CHECK(h->n == h->n_global, "slam_pf_resample_local needs the whole filter on this shard");
     ARG_CHECK(u0 >= 0.0 && u0 < 1.0, "u0 must be in [0, 1)");
@@ -2462,6 +2701,7 @@ extern "C" int slam_pf_record_rows(slam_pf_t h, int* rows) {
 }
 
 extern "C" int slam_pf_pack(slam_pf_t h, const int32_t* d_local_idx, int cnt, void* d_records) {
+    SLAM_RANGE();
     ARG_CHECK(h != nullptr, "null handle");
     ARG_CHECK(cnt >= 0, "cnt < 0");
     if (cnt == 0) return SLAM_OK;
@@ -2482,6 +2722,7 @@ extern "C" int slam_pf_pack(slam_pf_t h, const int32_t* d_local_idx, int cnt, vo
 
 extern "C" int slam_pf_resample_apply(slam_pf_t h, const int32_t* d_anc, const int32_t* d_remote_ids, int nremote,
                                       const void* d_remote_records) {
+    SLAM_RANGE();
     ARG_CHECK(h != nullptr && d_anc != nullptr, "null argument");
     ARG_CHECK(nremote >= 0, "nremote < 0");
     ARG_CHECK(nremote == 0 || (d_remote_ids != nullptr && d_remote_records != nullptr), "remote buffers missing");
@@ -2529,6 +2770,7 @@ extern "C" int slam_pf_resample_apply(slam_pf_t h, const int32_t* d_anc, const i
 }
 
 extern "C" int slam_pf_download(slam_pf_t h, void* pose, void* logw, void* lm) {
+    SLAM_RANGE();
     ARG_CHECK(h != nullptr, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     PF_LEGACY_ENTRY(h);
@@ -2543,6 +2785,7 @@ extern "C" int slam_pf_download(slam_pf_t h, void* pose, void* logw, void* lm) {
 }
 
 extern "C" int slam_pf_sync(slam_pf_t h) {
+    SLAM_RANGE();
     ARG_CHECK(h != nullptr, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     if (h->auto_on) {                          // (steps queued by slam_pf_step_auto: a halted one is resolved on the way)
@@ -2562,8 +2805,19 @@ extern "C" int slam_pf_stream(slam_pf_t h, void** stream) {
 // ---- auto mode: host side -------------------------------------------------------------------------------------------
 static int pf_auto_nb(const slam_pf* h) { return (int)((h->n_global + SCAN_BLOCK - 1) / SCAN_BLOCK); }
 
+// may a step resample on the device?  The whole filter here, or a sharded one whose peers are attached.
 static bool pf_auto_lazy_ok(const slam_pf* h) {
-    return h->n == h->n_global && !h->lazy_off && h->xchg_world <= 1 && pf_auto_nb(h) <= AUTO_NB_MAX;
+    if (h->lazy_off || pf_auto_nb(h) > AUTO_NB_MAX) return false;
+    return h->xchg_world <= 1 ? h->n == h->n_global : pf_sharded(h);
+}
+
+static const char* pf_error_text(long long code) {
+    switch (code) {
+        case PF_ERR_HANDOVER: return "auto mode: a workgroup's statistics line never reached the collecting workgroup (2 s)";
+        case PF_ERR_EXCHANGE: return "the scalar exchange between the ranks of the sharded filter timed out (a rank is gone)";
+        case PF_ERR_PEER: return "a hand-shake between the ranks of the sharded filter timed out (a rank is gone)";
+        default: return "auto mode: the device reported an unknown error";
+    }
 }
 
 // legacy mode -> auto mode: the host's bookkeeping becomes the device's
@@ -2578,6 +2832,7 @@ static int pf_auto_enter(slam_pf* h) {
     c.nresamples = (int32_t)h->nresamples;
     c.pcur = h->pcur;
     c.tside = h->tside;
+    c.lwcur = h->lwcur;
     c.seq = h->auto_seq;
     for (int t = 0; t < PF_TAB_MAX; ++t) c.tref[t] = h->tref[t];
     for (int l = 0; l < h->nl; ++l) c.identity += h->ltab[l] < 0;
@@ -2612,6 +2867,8 @@ static int pf_auto_import(slam_pf* h, bool halted) {
     for (int t = 0; t < PF_TAB_MAX; ++t) h->tref[t] = c.tref[t];
     h->pcur = c.pcur;
     h->tside = c.tside;
+    h->lwcur = c.lwcur;
+    h->logw = h->logw2[h->lwcur];
     h->nresamples = c.nresamples;
     // a halted step has stored its weights but not yet normalised them: its shift is the pending one
     const double shift = halted ? c.shift_scan : c.shift_next;
@@ -2620,7 +2877,7 @@ static int pf_auto_import(slam_pf* h, bool halted) {
     h->halt_gmax = c.gmax_norm;
     h->auto_on = 0;
     if (c.error) {
-        slam_set_error("the scalar exchange between the ranks of the sharded filter timed out (a rank is gone)");
+        slam_set_error("%s", pf_error_text(c.error));
         return SLAM_E_HIP;
     }
     return SLAM_OK;
@@ -2630,7 +2887,7 @@ static int pf_auto_enqueue(slam_pf* h, const PfStepRec& r) {
     PfAutoArgs a;
     memset(&a, 0, sizeof(a));
     for (int i = 0; i < r.m; ++i) { a.z[2 * i] = r.z[2 * i]; a.z[2 * i + 1] = r.z[2 * i + 1]; a.ids[i] = r.ids[i]; }
-    a.pose0 = h->pose[0]; a.pose1 = h->pose[1]; a.lm0 = h->lm[0]; a.lm1 = h->lm[1]; a.logw = h->logw;
+    a.pose0 = h->pose[0]; a.pose1 = h->pose[1]; a.lm0 = h->lm[0]; a.lm1 = h->lm[1]; a.logw0 = h->logw2[0]; a.logw1 = h->logw2[1];
     a.tab0 = h->d_tab[0]; a.tab1 = h->d_tab[1];
     a.n = h->n; a.first = h->first; a.n_global = h->n_global; a.seq = r.seq;
     a.seed = h->seed; a.step = r.rng_step;
@@ -2648,30 +2905,50 @@ static int pf_auto_enqueue(slam_pf* h, const PfStepRec& r) {
     a.R00 = r.R[0]; a.R10 = r.R[1]; a.R01 = r.R[2]; a.R11 = r.R[3];
     a.neff_frac = r.neff_frac;
     a.part = h->d_part; a.ctl = h->d_ctl; a.lmstate = h->d_lmstate; a.mir = h->h_mir_dev; a.xchg = h->d_xchg;
+    const bool sh = pf_sharded(h);
+    a.peers = sh ? h->d_peers : nullptr;
+    a.inbox = h->inbox;
     const dim3 grid(grid_for(h->n));
-    if (h->dtype == SLAM_F32) {
-        if (r.proposal) hipLaunchKernelGGL((pf_auto_step_kernel<float, true>), grid, dim3(256), 0, h->stream, a);
-        else hipLaunchKernelGGL((pf_auto_step_kernel<float, false>), grid, dim3(256), 0, h->stream, a);
-    } else {
-        if (r.proposal) hipLaunchKernelGGL((pf_auto_step_kernel<double, true>), grid, dim3(256), 0, h->stream, a);
-        else hipLaunchKernelGGL((pf_auto_step_kernel<double, false>), grid, dim3(256), 0, h->stream, a);
-    }
+#define PF_STEP_LAUNCH(TT)                                                                                                   \
+    do {                                                                                                                     \
+        if (sh) {                                                                                                            \
+            if (r.proposal) hipLaunchKernelGGL((pf_auto_step_kernel<TT, true, true>), grid, dim3(256), 0, h->stream, a);     \
+            else hipLaunchKernelGGL((pf_auto_step_kernel<TT, false, true>), grid, dim3(256), 0, h->stream, a);               \
+        } else {                                                                                                             \
+            if (r.proposal) hipLaunchKernelGGL((pf_auto_step_kernel<TT, true, false>), grid, dim3(256), 0, h->stream, a);    \
+            else hipLaunchKernelGGL((pf_auto_step_kernel<TT, false, false>), grid, dim3(256), 0, h->stream, a);              \
+        }                                                                                                                    \
+    } while (0)
+    if (h->dtype == SLAM_F32) PF_STEP_LAUNCH(float);
+    else PF_STEP_LAUNCH(double);
+#undef PF_STEP_LAUNCH
     HIP_TRY(hipGetLastError());
     if (a.lazy_ok && r.force != 0) {                        // (force == 0: this step never resamples, nothing to gate)
         const int nb = pf_auto_nb(h);
         const double lw = -log((double)h->n_global);
+        const PfPeers* pp = sh ? h->d_peers : nullptr;
+        const int rank = h->xchg_rank, world = sh ? h->xchg_world : 1;
+        if (sh) hipLaunchKernelGGL(pf_peer_gate_kernel, dim3(1), dim3(64), 0, h->stream, h->d_ctl, r.seq, pp, h->inbox, rank, world);
         PF_DISPATCH(h,
-                    hipLaunchKernelGGL(pf_auto_scan1_kernel<T>, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, (const T*)h->logw, h->n_global,
-                                       (const PfCtl*)h->d_ctl, r.seq, h->d_cdf, h->d_bsum),
-                    hipLaunchKernelGGL(pf_auto_scan1_kernel<T>, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, (const T*)h->logw, h->n_global,
-                                       (const PfCtl*)h->d_ctl, r.seq, h->d_cdf, h->d_bsum));
-        PF_DISPATCH(h,
-                    hipLaunchKernelGGL(pf_auto_resample_kernel<T>, grid, dim3(256), 0, h->stream, (T*)h->pose[0], (T*)h->pose[1],
-                                       h->d_tab[0], h->d_tab[1], (T*)h->logw, h->n, (const PfCtl*)h->d_ctl, r.seq,
-                                       (const double*)h->d_cdf, (const double*)h->d_bsum, nb, h->d_anc, (T)lw),
-                    hipLaunchKernelGGL(pf_auto_resample_kernel<T>, grid, dim3(256), 0, h->stream, (T*)h->pose[0], (T*)h->pose[1],
-                                       h->d_tab[0], h->d_tab[1], (T*)h->logw, h->n, (const PfCtl*)h->d_ctl, r.seq,
-                                       (const double*)h->d_cdf, (const double*)h->d_bsum, nb, h->d_anc, (T)lw));
+                    hipLaunchKernelGGL(pf_auto_scan1_kernel<T>, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, (const T*)h->logw2[0],
+                                       (const T*)h->logw2[1], h->n, h->n_global, (const PfCtl*)h->d_ctl, r.seq, h->d_cdf, h->d_bsum, pp,
+                                       rank, world),
+                    hipLaunchKernelGGL(pf_auto_scan1_kernel<T>, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, (const T*)h->logw2[0],
+                                       (const T*)h->logw2[1], h->n, h->n_global, (const PfCtl*)h->d_ctl, r.seq, h->d_cdf, h->d_bsum, pp,
+                                       rank, world));
+#define PF_RESAMPLE_LAUNCH(SHV)                                                                                              \
+        PF_DISPATCH(h,                                                                                                       \
+                    hipLaunchKernelGGL((pf_auto_resample_kernel<T, SHV>), grid, dim3(256), 0, h->stream, (T*)h->pose[0], (T*)h->pose[1], \
+                                       h->d_tab[0], h->d_tab[1], (T*)h->logw2[0], (T*)h->logw2[1], h->n, h->first, h->n_global,     \
+                                       (const PfCtl*)h->d_ctl, r.seq, (const double*)h->d_cdf, (const double*)h->d_bsum, nb,      \
+                                       h->d_anc, (T)lw, pp, rank, world),                                                     \
+                    hipLaunchKernelGGL((pf_auto_resample_kernel<T, SHV>), grid, dim3(256), 0, h->stream, (T*)h->pose[0], (T*)h->pose[1], \
+                                       h->d_tab[0], h->d_tab[1], (T*)h->logw2[0], (T*)h->logw2[1], h->n, h->first, h->n_global,     \
+                                       (const PfCtl*)h->d_ctl, r.seq, (const double*)h->d_cdf, (const double*)h->d_bsum, nb,      \
+                                       h->d_anc, (T)lw, pp, rank, world))
+        if (sh) PF_RESAMPLE_LAUNCH(true);
+        else PF_RESAMPLE_LAUNCH(false);
+#undef PF_RESAMPLE_LAUNCH
         HIP_TRY(hipGetLastError());
     }
     return SLAM_OK;
@@ -2725,6 +3002,7 @@ static int pf_auto_handle_halt(slam_pf* h) {
     h->last_resampled_seq = s;
     if (h->n != h->n_global) {
         h->halted = 1;
+        h->halts += 1;
         return SLAM_PF_HALTED;
     }
     const double u0 = resample_offset((uint32_t)h->nresamples, h->seed);
@@ -2757,7 +3035,7 @@ static int pf_auto_flush(slam_pf* h) {
         h->last_out[2] = (double)h->nresamples;
         h->last_out[3] = (double)h->auto_seq;
         if (h->h_mir->error) {
-            slam_set_error("the scalar exchange between the ranks of the sharded filter timed out (a rank is gone)");
+            slam_set_error("%s", pf_error_text(h->h_mir->error));
             return SLAM_E_HIP;
         }
     }
@@ -2782,6 +3060,7 @@ static int pf_auto_leave(slam_pf* h) {
  * migrating records with the legacy entry points, calls slam_pf_resume and repeats the call. */
 extern "C" int slam_pf_step_auto(slam_pf_t h, double V, double G, double wheelbase, const double Q[4], double dt, const double* z,
                                  const int32_t* ids, int m, const double R[4], double neff_frac, int force, int proposal) {
+    SLAM_RANGE();
     ARG_CHECK(h != nullptr && Q != nullptr, "null argument");
     ARG_CHECK(m >= 0 && m <= PF_AUTO_MAXOBS, "slam_pf_step_auto takes at most 64 observations per call");
     ARG_CHECK(m == 0 || (z != nullptr && ids != nullptr && R != nullptr), "null argument");
@@ -2817,6 +3096,7 @@ extern "C" int slam_pf_step_auto(slam_pf_t h, double V, double G, double wheelba
 /* Wait for everything slam_pf_step_auto has queued.  out (may be NULL) = {Neff of the last step, 1 if it resampled,
  * resamplings so far, steps so far}.  SLAM_PF_HALTED as for slam_pf_step_auto. */
 extern "C" int slam_pf_flush(slam_pf_t h, double out[4]) {
+    SLAM_RANGE();
     ARG_CHECK(h != nullptr, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     if (h->halted) return SLAM_PF_HALTED;
@@ -2830,6 +3110,7 @@ extern "C" int slam_pf_flush(slam_pf_t h, double out[4]) {
 /* After SLAM_PF_HALTED and the caller's resampling (slam_pf_copy_logw ... slam_pf_resample_apply): the skipped steps are
  * enqueued again.  `resamplings`: the caller's count after its resampling (the offset of the next one derives from it). */
 extern "C" int slam_pf_resume(slam_pf_t h, int64_t resamplings) {
+    SLAM_RANGE();
     ARG_CHECK(h != nullptr, "null handle");
     ARG_CHECK(h->halted, "nothing is halted");
     HIP_TRY(hipSetDevice(h->device));
@@ -2886,9 +3167,132 @@ extern "C" int slam_pf_attach_exchange(slam_pf_t h, int rank, int world, void* p
     return SLAM_OK;
 }
 
+/* ---- sharding behind the C ABI: peers -----------------------------------------------------------------------------
+ * One process per GPU.  Every rank exports a blob (slam_pf_export_peer: IPC handles of its state buffers and of its
+ * inbox page, or -- same process, e.g. one host thread per GPU -- the raw device pointers), the caller moves the blobs
+ * between the ranks by whatever it has (MPI, files, torch.distributed ...), and every rank attaches all of them in
+ * rank order.  From then on slam_pf_step_auto resamples the sharded filter on the device (no SLAM_PF_HALTED). */
+struct PfPeerBlob {
+    uint64_t magic;
+    int64_t pid;
+    int32_t device, dtype, nl, reserved;
+    int64_t n;
+    void* raw[9];                     // pose0, pose1, lm0, lm1, logw0, logw1, tab0, tab1, inbox
+    hipIpcMemHandle_t ipc[9];
+};
+static_assert(sizeof(PfPeerBlob) <= SLAM_PF_PEER_BLOB_BYTES, "peer blob");
+constexpr uint64_t PF_BLOB_MAGIC = 0x534c414d50465033ull;      // "SLAMPFP3"
+
+extern "C" int slam_pf_export_peer(slam_pf_t h, void* blob) {
+    ARG_CHECK(h != nullptr && blob != nullptr, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    PfPeerBlob b;
+    memset(&b, 0, sizeof(b));
+    b.magic = PF_BLOB_MAGIC;
+    b.pid = (int64_t)getpid();
+    b.device = h->device; b.dtype = h->dtype; b.nl = h->nl; b.n = h->n;
+    void* ptrs[9] = {h->pose[0], h->pose[1], h->lm[0], h->lm[1], h->logw2[0], h->logw2[1], h->d_tab[0], h->d_tab[1], h->inbox};
+    for (int i = 0; i < 9; ++i) {
+        b.raw[i] = ptrs[i];
+        HIP_TRY(hipIpcGetMemHandle(&b.ipc[i], ptrs[i]));
+    }
+    memset(blob, 0, SLAM_PF_PEER_BLOB_BYTES);
+    memcpy(blob, &b, sizeof(b));
+    return SLAM_OK;
+}
+
+static void pf_detach_peers_impl(slam_pf* h) {
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (int r = 0; r < PF_MAX_WORLD; ++r)
+        for (int i = 0; i < 9; ++i)
+            if (h->peer_open[r][i]) {
+                (void)hipIpcCloseMemHandle(h->peer_open[r][i]);
+                h->peer_open[r][i] = nullptr;
+            }
+    if (h->d_peers) { (void)hipFree(h->d_peers); h->d_peers = nullptr; }
+    memset(&h->peers, 0, sizeof(h->peers));
+}
+
+extern "C" int slam_pf_detach_peers(slam_pf_t h) {
+    SLAM_RANGE();
+    ARG_CHECK(h != nullptr, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    PF_LEGACY_ENTRY(h);
+    { const int rcm = pf_materialise(h); if (rcm) return rcm; }      // (collective: no remote references may stay behind)
+    pf_detach_peers_impl(h);
+    if (!h->xchg_host) { h->xchg_rank = 0; h->xchg_world = 1; }
+    return SLAM_OK;
+}
+
+extern "C" int slam_pf_attach_peers(slam_pf_t h, int rank, int world, const void* blobs) {
+    SLAM_RANGE();
+    ARG_CHECK(h != nullptr && blobs != nullptr, "null argument");
+    ARG_CHECK(world >= 1 && world <= PF_MAX_WORLD && rank >= 0 && rank < world, "rank / world out of range (at most 8 ranks)");
+    ARG_CHECK(h->n * world == h->n_global && h->first == (int64_t)rank * h->n, "ranks must own equal, contiguous slices in rank order");
+    HIP_TRY(hipSetDevice(h->device));
+    PF_LEGACY_ENTRY(h);
+    ARG_CHECK(!pf_sharded(h), "peers are already attached (slam_pf_detach_peers first)");
+    pf_detach_peers_impl(h);
+    const int64_t me = (int64_t)getpid();
+    PfPeers t;
+    memset(&t, 0, sizeof(t));
+    for (int r = 0; r < world; ++r) {
+        PfPeerBlob b;
+        memcpy(&b, (const char*)blobs + (size_t)r * SLAM_PF_PEER_BLOB_BYTES, sizeof(b));
+        ARG_CHECK(b.magic == PF_BLOB_MAGIC, "a peer blob is not one of slam_pf_export_peer's");
+        ARG_CHECK(b.n == h->n && b.nl == h->nl && b.dtype == h->dtype, "the peers' shards differ in size or type");
+        void* ptr[9];
+        if (r == rank) {
+            ARG_CHECK(b.pid == me && b.raw[0] == h->pose[0], "blob [rank] is not this handle's own export");
+            for (int i = 0; i < 9; ++i) ptr[i] = b.raw[i];
+        } else if (b.pid == me) {                           // a shard of this very process: plain pointers
+            if (b.device != h->device) {
+                const hipError_t e = hipDeviceEnablePeerAccess(b.device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(e);
+                (void)hipGetLastError();
+            }
+            for (int i = 0; i < 9; ++i) ptr[i] = b.raw[i];
+        } else {
+            for (int i = 0; i < 9; ++i) {
+                const hipError_t e = hipIpcOpenMemHandle(&ptr[i], b.ipc[i], hipIpcMemLazyEnablePeerAccess);
+                if (e != hipSuccess) {
+                    slam_set_error("hipIpcOpenMemHandle of rank %d's buffer %d failed: %s", r, i, hipGetErrorString(e));
+                    pf_detach_peers_impl(h);
+                    return SLAM_E_HIP;
+                }
+                h->peer_open[r][i] = ptr[i];
+            }
+        }
+        t.pose[r][0] = ptr[0]; t.pose[r][1] = ptr[1]; t.lm[r][0] = ptr[2]; t.lm[r][1] = ptr[3];
+        t.logw[r][0] = ptr[4]; t.logw[r][1] = ptr[5]; t.tab[r][0] = (int32_t*)ptr[6]; t.tab[r][1] = (int32_t*)ptr[7];
+        t.inbox[r] = (PfInbox*)ptr[8];
+    }
+    h->peers = t;
+    HIP_TRY(hipMalloc((void**)&h->d_peers, sizeof(PfPeers)));
+    HIP_TRY(hipMemcpy(h->d_peers, &t, sizeof(t), hipMemcpyHostToDevice));
+    h->xchg_rank = rank;
+    h->xchg_world = world;
+    return SLAM_OK;
+}
+
+/* out = {ranks of the filter, 1 if peers are attached (device-side resampling of the sharded filter), SLAM_PF_HALTED
+ * returns so far, resamplings so far}. */
+extern "C" int slam_pf_comm_info(slam_pf_t h, int64_t out[4]) {
+    ARG_CHECK(h != nullptr && out != nullptr, "null argument");
+    out[0] = h->xchg_world;
+    out[1] = pf_sharded(h) ? 1 : 0;
+    out[2] = h->halts;
+    int64_t cnt = 0;
+    const int rc = slam_pf_resample_count(h, &cnt);
+    if (rc) return rc;
+    out[3] = cnt;
+    return SLAM_OK;
+}
+
 /* normalise, and resample if Neff < neff_frac * n (filter wholly on this shard).  *resampled (may be NULL)
  * tells whether it did.  The synchronous form of what slam_pf_step_auto decides on the device. */
 extern "C" int slam_pf_resample(slam_pf_t h, double neff_frac, int* resampled) {
+    SLAM_RANGE();
     ARG_CHECK(h != nullptr, "null handle");
     ARG_CHECK(h->n == h->n_global, "slam_pf_resample needs the whole filter on this shard");
     double s[7];

@@ -27,10 +27,10 @@ import os
 
 import numpy as np
 
-from ._lib import SLAM_F32, SLAM_F64, SLAM_PF_HALTED, check, lib
+from ._lib import SLAM_F32, SLAM_F64, SLAM_PF_HALTED, SLAM_PF_PEER_BLOB_BYTES, check, lib
 from .ekf import _obs, _small, _ptr
 
-__all__ = ["PFShard", "PFSlamState", "FastSLAM", "philox_uniform", "small", "shared_page"]
+__all__ = ["PFShard", "PFSlamState", "FastSLAM", "philox_uniform", "small", "shared_page", "attach_local_peers"]
 
 _M0, _M1, _W0, _W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
 STREAM_RESAMPLE = 2
@@ -257,6 +257,29 @@ class PFShard:
         assert page.dtype == np.float64 and page.flags.c_contiguous and page.size >= 2 * world * 8
         self._xchg_page = page                       # keeps the mapping alive
         check(lib.slam_pf_attach_exchange(self._h, int(rank), int(world), C.c_void_p(page.ctypes.data), page.nbytes))
+
+    # -- sharding behind the C ABI: peers (slam_pf_export_peer / slam_pf_attach_peers) ------------------------
+    def export_peer(self):
+        """This shard's peer blob (bytes): IPC handles of its buffers and inbox; every rank attaches all ranks' blobs."""
+        buf = C.create_string_buffer(SLAM_PF_PEER_BLOB_BYTES)
+        check(lib.slam_pf_export_peer(self._h, buf))
+        return bytes(buf.raw)
+
+    def attach_peers(self, rank, world, blobs):
+        """``blobs``: the ``world`` peer blobs in rank order.  From here on step_auto resamples the sharded filter on
+        the device (no SLAM_PF_HALTED); calls that need plain maps (download with landmarks, pack, legacy sweeps) are
+        collective."""
+        assert len(blobs) == world and all(len(b) == SLAM_PF_PEER_BLOB_BYTES for b in blobs)
+        check(lib.slam_pf_attach_peers(self._h, int(rank), int(world), C.c_char_p(b"".join(blobs))))
+
+    def detach_peers(self):
+        check(lib.slam_pf_detach_peers(self._h))
+
+    def comm_info(self):
+        """{world, peers attached?, SLAM_PF_HALTED returns so far, resamplings so far}."""
+        out = (C.c_int64 * 4)()
+        check(lib.slam_pf_comm_info(self._h, out))
+        return dict(world=int(out[0]), peers=bool(out[1]), halts=int(out[2]), resamples=int(out[3]))
 
     def resample_if_needed(self, neff_frac=0.75):
         """slam_pf_resample: normalise and resample if Neff < neff_frac * n (filter wholly on this shard)."""
@@ -640,6 +663,11 @@ class FastSLAM:
         return np.array([s[0], s[1], math.atan2(s[2], s[3])])       # weights are normalised: sums are means
 
 
+def socket_host():
+    import socket
+    return socket.gethostname()
+
+
 def shared_page(dist, rank, world, doubles):
     """A zero-filled float64 page in /dev/shm that every rank of ONE node maps (the ranks' scalar page of a sharded
     filter: slam_pf_attach_exchange).  The file is unlinked once every rank has mapped it."""
@@ -647,7 +675,9 @@ def shared_page(dist, rank, world, doubles):
     name = [f"/dev/shm/slamhip-x-{uuid.uuid4().hex}" if rank == 0 else None]
     dist.broadcast_object_list(name, src=0)
     if rank == 0:
-        np.zeros(doubles, dtype=np.float64).tofile(name[0])
+        fd = os.open(name[0], os.O_CREAT | os.O_EXCL | os.O_WRONLY, 0o600)
+        with os.fdopen(fd, "wb") as f:
+            f.write(np.zeros(doubles, dtype=np.float64).tobytes())
     dist.barrier()
     mem = np.memmap(name[0], dtype=np.float64, mode="r+", shape=(doubles,))
     dist.barrier()
@@ -674,8 +704,20 @@ class PFSlamState(FastSLAM):
             per = n // world
             shard = PFShard(per, max_landmarks, seed, dtype=dtype, first=rank * per, n_global=n, device=device)
             comm = TorchComm(torch.device("cuda", int(device)))
-            if world > 1:                                # the per-step scalars of step_async travel GPU to GPU through this
-                shard.attach_exchange(rank, world, shared_page(dist, rank, world, 2 * world * 8))
+            self.peers = False
+            if world > 1:
+                # the ranks' GPUs address each other's buffers (IPC handles, moved here by an object all-gather): the
+                # per-step scalars travel GPU to GPU and a resampling step stays on the device.  SLAMHIP_PF_PEERS=0, more
+                # than 8 ranks or ranks on several nodes: the legacy flow -- scalars through a shared pinned page, a
+                # resampling step halts and the host resamples through the collectives
+                blobs = [None] * world
+                dist.all_gather_object(blobs, (socket_host(), shard.export_peer()))
+                one_node = len({h for h, _ in blobs}) == 1
+                if one_node and world <= 8 and os.environ.get("SLAMHIP_PF_PEERS", "1") != "0":
+                    shard.attach_peers(rank, world, [b for _, b in blobs])
+                    self.peers = True
+                elif one_node:
+                    shard.attach_exchange(rank, world, shared_page(dist, rank, world, 2 * world * 8))
         else:
             shard = PFShard(n, max_landmarks, seed, dtype=dtype, device=device)
             comm = None
@@ -683,4 +725,20 @@ class PFSlamState(FastSLAM):
         self.n = n
 
     def close(self):
+        """Collective for a sharded filter with peers: remote records are brought home, the peers are detached, then a
+        barrier -- nobody frees buffers a peer may still read."""
+        if getattr(self, "peers", False):
+            import torch.distributed as dist
+            self.shard.detach_peers()
+            self.shard.sync()
+            dist.barrier()
+            self.peers = False
         self.shard.close()
+
+
+def attach_local_peers(shards):
+    """Several shards of ONE process (one host thread driving several GPUs, or -- the tests -- several shards on one
+    card) become the ranks of one sharded filter: every shard attaches every shard's blob (raw pointers, no IPC)."""
+    blobs = [sh.export_peer() for sh in shards]
+    for r, sh in enumerate(shards):
+        sh.attach_peers(r, len(shards), blobs)

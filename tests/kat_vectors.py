@@ -1,4 +1,4 @@
-"""Hand-derived known answers KAT-8 .. KAT-10 (closed forms worked on paper from the reference's formulas,
+"""Hand-derived known answers KAT-8 .. KAT-11 (closed forms worked on paper from the reference's formulas,
 never by running the oracle).  Shared by the CPU tests of the oracle (tests/test_oracle_kat.py) and the GPU tests
 through the C ABI (tests/test_gpu_ekf.py).
 
@@ -31,6 +31,18 @@ KAT-10 ``add_features`` (src/ekf.jl:84-122) with a NON-ZERO vehicle covariance a
         P_ff = Gv Pvv Gv' + Gz R Gz' = [[a - 4e + 4g + 4 r2, d - 2f], [d - 2f, b + r1]]
         P_fm = Gv Pvm       = [[h1 - 2 j1, h2 - 2 j2], [i1, i2]]
     and the old 5 x 5 block is unchanged.
+
+KAT-11 ``update`` with a ROTATED heading, an OFF-AXIS landmark and a COUPLED covariance (KAT-8/9 have the landmark on
+    the x axis, phi = 0 and a diagonal P: nothing there exercises the bearing's -phi term, the sign pattern of the
+    off-axis Jacobian or a P with cross terms).  A 3-4-5 triangle keeps the Jacobian rational:
+        x = [1, 2, pi/6, 4, 6]:  dx = 3, dy = 4, d = 5, d^2 = 25
+        zhat = (5, atan2(4, 3) - pi/6)                                        (src/common.jl:148-152)
+        H = [[-3/5, -4/5, 0, 3/5, 4/5], [4/25, -3/25, -1, -4/25, 3/25]]       (:161-162)
+    z = zhat + (0.3, -0.015) so v = (0.3, -0.015) exactly as data; P = the coupled 5 x 5 matrix of KAT-10 (positive
+    definite).  The expected posterior is NOT formed the reference's way (P H' inv(chol(S)), W1 W1') but through the
+    INFORMATION form of the same linear-Gaussian update, whose only inverses are a 2 x 2 diagonal one (R) and 5 x 5
+    ones:        Lambda+ = P^-1 + H' R^-1 H,     P+ = (Lambda+)^-1,     x+ = x + P+ H' R^-1 v
+    (Woodbury: (P^-1 + H' R^-1 H)^-1 = P - P H' (H P H' + R)^-1 H P, and P+ H' R^-1 = P H' S^-1 = K.)
 """
 import math
 
@@ -100,3 +112,19 @@ def kat10():
     Pp[3:5, 5:] = Pfm.T
     Pp[5:, 5:] = Pff
     return x, P, zn, xp, Pp
+
+
+# ---- KAT-11 -------------------------------------------------------------------------------------------------
+def kat11():
+    """(x, P, z (2 x 1), idf, x_plus, P_plus): rotated heading, off-axis landmark, coupled P; information form"""
+    _, P, _, _, _ = kat10()
+    x = np.array([1.0, 2.0, math.pi / 6, 4.0, 6.0])
+    H = np.array([[-3 / 5, -4 / 5, 0.0, 3 / 5, 4 / 5],
+                  [4 / 25, -3 / 25, -1.0, -4 / 25, 3 / 25]])
+    v = np.array([0.3, -0.015])
+    z = np.array([5.0 + v[0], math.atan2(4.0, 3.0) - math.pi / 6 + v[1]]).reshape(2, 1)
+    Ri = np.diag([1.0 / R[0, 0], 1.0 / R[1, 1]])
+    Pp = np.linalg.inv(np.linalg.inv(P) + H.T @ Ri @ H)
+    Pp = 0.5 * (Pp + Pp.T)
+    xp = x + Pp @ H.T @ Ri @ v
+    return x, P, z, np.array([[1]]), xp, Pp

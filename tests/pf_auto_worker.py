@@ -1,5 +1,7 @@
 """Worker of tests/test_gpu_pf.py::test_auto_mode_two_ranks_on_one_card: one rank of the GPU FastSLAM driver, either
-the synchronous single-rank filter ("sync") or the sharded auto mode over gloo with all ranks on card 0 ("auto")."""
+the synchronous single-rank filter ("sync") or the sharded auto mode with all ranks on card 0 ("auto": peers attached
+through IPC handles, resampling on the device; with SLAMHIP_PF_PEERS=0 the halting flow over gloo).  argv[3]: the
+resampling regime ("mixed" or "every_step")."""
 import math
 import os
 import sys
@@ -16,6 +18,7 @@ from __graft_entry__ import load_package  # noqa: E402
 
 def main():
     out_path, mode = sys.argv[1], sys.argv[2]
+    regime = sys.argv[3] if len(sys.argv) > 3 else "mixed"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     if mode == "nccl1":
         # a ONE-rank RCCL group: the collectives of the sharded flow (all-gather of the log-weights, all-to-all of the
@@ -49,7 +52,10 @@ def main():
         ids = (np.arange(3) + 3 * t) % NL + 1
         dx, dy = lm[ids - 1, 0] - pose[0], lm[ids - 1, 1] - pose[1]
         z = np.vstack([np.hypot(dx, dy), np.arctan2(dy, dx) - pose[2]]) + rng.normal(0, [[0.1], [math.pi / 180]], (2, 3))
-        force = True if t % 4 == 1 else None
+        if regime == "every_step":                      # (what BASELINE config 4 does at full size: every step resamples)
+            force = None if t == 6 else True
+        else:
+            force = True if t % 4 == 1 else None
         if mode == "auto":
             pf.step_async(V, G, 4.0, Q, 0.1, z, ids, R, force_resample=force)
             if t % 5 == 4 or t == 13:
@@ -58,8 +64,10 @@ def main():
             neff, _ = pf.step(V, G, 4.0, Q, 0.1, z, ids, R, force_resample=force)
             if t % 5 == 4 or t == 13:
                 neffs.append(neff)
-    p, lw, l = pf.shard.download()
-    np.savez(out_path + f".rank{rank}", pose=p, lm=l, logw=lw, resamples=pf.resamples, neff=np.array(neffs))
+    p, lw, l = pf.shard.download()                      # (collective when peers are attached)
+    info = pf.shard.comm_info()
+    np.savez(out_path + f".rank{rank}", pose=p, lm=l, logw=lw, resamples=pf.resamples, neff=np.array(neffs),
+             halts=info["halts"], peers=int(info["peers"]))
     pf.close()
     if world > 1 or mode == "nccl1":
         dist.barrier()

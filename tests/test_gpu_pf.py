@@ -289,6 +289,70 @@ def test_full_size_config4_properties(pkg):
     pf.close()
 
 
+def test_full_size_config4_auto_mode_against_the_synchronous_driver_and_the_oracle(pkg):
+    """The entry point bench.py TIMES at C4 -- FastSLAM.step_async (slam_pf_step_auto: tagged-line hand-over of 1024
+    workgroups, decision and lazy resampling on the device, ~31 live ancestor tables) -- at the benchmarked shape
+    262144 x 512 x 16 observations, fp32, against the host-driven FastSLAM.step on a second filter: poses and every
+    sampled landmark record bit-identical, log-weights within 4 ulp, the same resampling steps and count.  The steps
+    before the first resampling are also checked against the fp64 oracle on global ids [0, 4096) (the random numbers
+    are keyed by global id, particles are independent until a resampling)."""
+    import torch
+    n, nl, seed, m = 262144, 512, 20240602, 16
+    rng = np.random.default_rng(seed)
+    lm = rng.uniform(-200, 200, (nl, 2))
+    f = {}
+    for name in ("auto", "sync"):
+        f[name] = pkg.PFSlamState(n, nl, seed=seed, dtype="f32", distributed=False)
+        f[name].shard.set_pose([0.0, 0.0, 0.3])
+        f[name].shard.init_landmarks(lm, 0.01, 0.1)
+    no = 4096
+    orc = F.OraclePF(no, nl, seed, first_id=0, n_global=n)
+    orc.set_pose([0.0, 0.0, 0.3])
+    orc.init_landmarks(lm, 0.01, 0.1)
+    sample = torch.tensor(np.r_[0:8, 1000:1008, no - 8:no, 131072 - 4:131072 + 4, n - 8:n], dtype=torch.int32, device="cuda")
+    osample = np.r_[0:8, 1000:1008, no - 8:no]
+    pose = np.array([0.0, 0.0, 0.3])
+    # never / never / never, then the Neff rule, forced, and one forced "no" in between
+    schedule = [False, False, False, None, None, True, None, False, None, True, None, None, True, None]
+    hist = []
+    for t, force in enumerate(schedule):
+        pose = np.array([pose[0] + 0.2 * math.cos(pose[2]), pose[1] + 0.2 * math.sin(pose[2]), pose[2]])
+        ids = (np.arange(m) + m * t) % nl + 1
+        z = observe(lm, pose, ids, rng)
+        f["auto"].step_async(8.0, 0.0, 4.0, Q, 0.025, z, ids, R, force_resample=force)
+        hist.append(f["sync"].step(8.0, 0.0, 4.0, Q, 0.025, z, ids, R, force_resample=force))
+        if t < 3:
+            orc.predict(8.0, 0.0, 4.0, Q, 0.025)
+            orc.update_known(z, ids, R)
+        if t == 2:                                  # no resampling so far: the oracle's particles are the filter's
+            f["auto"].flush()
+            p, lw, _ = f["auto"].shard.download(landmarks=False)
+            assert close(p[:, :no], orc.pose, 2e-5, scale=1.0), "poses against the oracle"
+            d_gpu = lw[:no].astype(np.float64) - float(lw[0])
+            d_orc = orc.logw - orc.logw[0]
+            assert close(d_gpu, d_orc, 2e-4, scale=max(1.0, float(np.abs(d_orc).max()))), "log-weights against the oracle"
+            rec = f["auto"].shard.pack(sample[:len(osample)]).cpu().numpy().astype(np.float64)      # [3 + 5 nl, samples]
+            got, want = rec[3:].reshape(nl, 5, -1), orc.lm[:, :, osample]
+            assert close(got[:, 0:2], want[:, 0:2], 2e-6, scale=200.0), "landmark means against the oracle"
+            assert close(got[:, 2:5], want[:, 2:5], 2e-3, scale=float(np.abs(want[:, 2:5]).max())), "landmark covariances"
+        if t in (2, 6, 9, len(schedule) - 1):
+            neff, did = f["auto"].flush()
+            assert did == hist[-1][1], f"step {t}"
+            assert neff == pytest.approx(hist[-1][0], rel=1e-6), f"step {t}"
+            assert f["auto"].resamples == f["sync"].resamples, f"step {t}"
+            pa, wa, _ = f["auto"].shard.download(landmarks=False)
+            pb, wb, _ = f["sync"].shard.download(landmarks=False)
+            assert np.array_equal(pa, pb), f"step {t}: poses differ"
+            assert np.allclose(wa, wb, rtol=0, atol=4 * np.finfo(np.float32).eps * max(1.0, float(np.abs(wb).max()))), f"step {t}"
+            if t in (6, len(schedule) - 1):          # (pack materialises the lazily resampled maps: also a legacy call mid-queue)
+                assert torch.equal(f["auto"].shard.pack(sample), f["sync"].shard.pack(sample)), f"step {t}: landmark records differ"
+    dids = [d for _, d in hist]
+    assert f["sync"].resamples == sum(dids) >= 6 and not dids[7] and all(dids[i] for i in (5, 9, 12))
+    assert f["auto"].shard.resample_count() == f["sync"].resamples
+    for g in f.values():
+        g.close()
+
+
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_unknown_correspondences_against_oracle(pkg, dtype):
     """per-particle gated nearest-neighbour association over each particle's own landmark slots,
@@ -707,32 +771,140 @@ def test_whole_filter_calls(pkg):
     b.close()
 
 
-@pytest.mark.parametrize("nranks", [2, 4])
-def test_auto_mode_two_ranks_on_one_card(pkg, tmp_path, nranks):
-    """The sharded auto mode rehearsed with two (and four) processes on ONE card (gloo for the resampling collectives): the ranks'
-    GPUs exchange their per-step scalars through the shared pinned page (device writes, device polls -- here both
-    'GPUs' are the same card), a resampling step halts, the hosts resample through the collectives, resume, and the
-    skipped steps are replayed.  The two shards together must equal the one-rank synchronous filter."""
+class _Rank:
+    """The world of one in-process rank (FastSLAM only checks the slice layout against it)."""
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+
+@pytest.mark.parametrize("proposal", [False, True])
+@pytest.mark.parametrize("dtype,world", [("f32", 2), ("f64", 3)])
+def test_sharded_filter_resamples_on_the_device(pkg, dtype, world, proposal):
+    """A filter sharded over `world` ranks with PEERS attached (slam_pf_attach_peers; here the ranks are shards of this
+    process on one card, one host thread each -- the same kernels and the same peer table as IPC-mapped ranks): the
+    per-step scalars travel through the ranks' inboxes and EVERY resampling happens on the device -- cdf over the
+    gathered weights, global ancestors, remote poses / table entries read from their owners, remote landmark records
+    read lazily by the sweep.  Regime: a resampling on (almost) every step, forced and Neff-triggered, with repeats
+    and first sightings.  The shards together must be the one-rank synchronous filter bit for bit, with ZERO
+    SLAM_PF_HALTED returns."""
+    import threading
+    per, nl, seed = 1365, 14, 77
+    n = per * world
+    lm = scene(nl, 19)
+    ref_shard = pkg.PFShard(n, nl, seed, dtype=dtype)
+    ref_shard.set_pose([0.5, 1.5, -0.2])
+    ref_shard.init_landmarks(lm[:9], 0.01, 0.1)
+    ref = pkg.FastSLAM(ref_shard, None, neff_frac=0.75)
+    shards = [pkg.PFShard(per, nl, seed, dtype=dtype, first=r * per, n_global=n) for r in range(world)]
+    for sh in shards:
+        sh.set_pose([0.5, 1.5, -0.2])
+        sh.init_landmarks(lm[:9], 0.01, 0.1)
+    pkg.attach_local_peers(shards)
+    ranks = [pkg.FastSLAM(sh, _Rank(r, world), neff_frac=0.75) for r, sh in enumerate(shards)]
+    rng = np.random.default_rng(6)
+    pose = np.array([0.5, 1.5, -0.2])
+    steps = []
+    for t in range(36):
+        pose = np.array([pose[0] + 0.6 * math.cos(pose[2]), pose[1] + 0.6 * math.sin(pose[2]), pose[2]])
+        ids = np.zeros(0, dtype=np.int32) if t == 17 else np.array([1 + t % 9, 1 + (t + 4) % 9, 1 + t % 9, 10 + t % 5, 10 + t % 5, 3])
+        z = observe(lm, pose, ids, rng) if len(ids) else np.zeros((2, 0))
+        force = False if t % 9 == 5 else (None if t % 3 == 2 else True)
+        steps.append((0.01 * (t % 5), z, ids, force))
+    hist = [ref.step(6.0, g, 4.0, Q, 0.1, z, ids, R, force_resample=force, proposal=proposal) for g, z, ids, force in steps]
+    want = ref_shard.download()
+    got, errs = [None] * world, []
+
+    def drive(r):
+        try:
+            f = ranks[r]
+            for t, (g, z, ids, force) in enumerate(steps):
+                f.step_async(6.0, g, 4.0, Q, 0.1, z, ids, R, force_resample=force, proposal=proposal)
+                if t in (7, 20):
+                    neff, did = f.flush()
+                    assert did == hist[t][1] and neff == pytest.approx(hist[t][0], rel=1e-12 if dtype == "f64" else 1e-6), f"step {t}"
+            neff, did = f.flush()
+            assert did == hist[-1][1] and neff == pytest.approx(hist[-1][0], rel=1e-12 if dtype == "f64" else 1e-6)
+            assert f.resamples == ref.resamples
+            got[r] = f.shard.download()              # collective: remote records come home first
+        except BaseException as e:                    # noqa: BLE001 -- reported by the main thread
+            errs.append((r, e))
+
+    th = [threading.Thread(target=drive, args=(r,)) for r in range(world)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=300)
+    assert not errs, errs
+    assert all(g is not None for g in got)
+    assert ref.resamples >= 20
+    info = [sh.comm_info() for sh in shards]
+    assert all(i["halts"] == 0 and i["peers"] and i["world"] == world and i["resamples"] == ref.resamples for i in info), info
+    assert np.array_equal(np.hstack([g[0] for g in got]), want[0]), "poses differ"
+    assert np.array_equal(np.concatenate([g[2] for g in got], axis=2), want[2]), "landmarks differ"
+    wa = np.concatenate([g[1] for g in got])
+    assert np.allclose(wa, want[1], rtol=0, atol=4 * np.finfo(wa.dtype).eps * max(1.0, float(np.abs(want[1]).max())))
+    th = [threading.Thread(target=sh.detach_peers) for sh in shards]          # collective, too
+    for x in th:
+        x.start()
+    for x in th:
+        x.join(timeout=60)
+    for sh in shards + [ref_shard]:
+        sh.close()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _run_workers(tmp_path, tag, world, mode, regime, extra_env=None):
+    """`world` processes of tests/pf_auto_worker.py, all on card 0; returns the concatenated filter."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = str(tmp_path / "auto2")
-    outs = {}
-    for world, mode, port in ((1, "sync", 29711 + 10 * nranks), (nranks, "auto", 29712 + 10 * nranks)):
-        procs = []
-        for r in range(world):
-            env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-            procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "pf_auto_worker.py"), f"{out}{mode}", mode],
-                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-        logs = [p.communicate(timeout=500)[0] for p in procs]
-        assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
-        parts = [np.load(f"{out}{mode}.rank{k}.npz") for k in range(world)]
-        outs[mode] = dict(pose=np.hstack([p["pose"] for p in parts]), lm=np.concatenate([p["lm"] for p in parts], axis=2),
-                          logw=np.concatenate([p["logw"] for p in parts]), resamples=int(parts[0]["resamples"]),
-                          neff=parts[0]["neff"])
-    a, s = outs["auto"], outs["sync"]
+    out = str(tmp_path / tag)
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "pf_auto_worker.py"), out, mode, regime],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=500)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
+    parts = [np.load(f"{out}.rank{k}.npz") for k in range(world)]
+    return dict(pose=np.hstack([p["pose"] for p in parts]), lm=np.concatenate([p["lm"] for p in parts], axis=2),
+                logw=np.concatenate([p["logw"] for p in parts]), resamples=int(parts[0]["resamples"]),
+                neff=parts[0]["neff"], halts=[int(p["halts"]) for p in parts], peers=[int(p["peers"]) for p in parts])
+
+
+@pytest.mark.parametrize("regime", ["mixed", "every_step"])
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_auto_mode_two_ranks_on_one_card(pkg, tmp_path, nranks, regime):
+    """The sharded auto mode rehearsed with two (and four) PROCESSES on ONE card: PFSlamState under torch.distributed
+    (gloo, for the set-up's object all-gather of the peer blobs only) attaches the ranks as peers through IPC handles
+    (slam_pf_attach_peers), the ranks' GPUs -- here the same card -- exchange their per-step scalars through each other's
+    inboxes and resample ON THE DEVICE: no step may halt (the count of SLAM_PF_HALTED returns must be ZERO), in the
+    `every_step` regime every step resamples.  The shards together must equal the one-rank synchronous filter."""
+    s = _run_workers(tmp_path, "sync", 1, "sync", regime)
+    a = _run_workers(tmp_path, "auto", nranks, "auto", regime)
+    assert a["peers"] == [1] * nranks and a["halts"] == [0] * nranks, (a["peers"], a["halts"])
+    assert a["resamples"] == s["resamples"] >= (13 if regime == "every_step" else 3)
+    assert np.array_equal(a["pose"], s["pose"]) and np.array_equal(a["lm"], s["lm"])
+    assert np.allclose(a["logw"], s["logw"], rtol=0, atol=1e-12)
+    assert np.allclose(a["neff"], s["neff"], rtol=1e-10)
+
+
+def test_auto_mode_two_ranks_without_peers_halts_and_resumes(pkg, tmp_path):
+    """The fallback (SLAMHIP_PF_PEERS=0; also what several nodes get): per-step scalars through the shared pinned page, a
+    resampling step HALTS, the hosts resample through the collectives (gloo here), resume, and the skipped steps are
+    replayed.  Same filter; the halts are counted."""
+    s = _run_workers(tmp_path, "sync", 1, "sync", "mixed")
+    a = _run_workers(tmp_path, "halt", 2, "auto", "mixed", extra_env={"SLAMHIP_PF_PEERS": "0"})
+    assert a["peers"] == [0, 0] and all(h >= 3 for h in a["halts"]), (a["peers"], a["halts"])
     assert a["resamples"] == s["resamples"] >= 3
     assert np.array_equal(a["pose"], s["pose"]) and np.array_equal(a["lm"], s["lm"])
     assert np.allclose(a["logw"], s["logw"], rtol=0, atol=1e-12)
@@ -750,11 +922,11 @@ def test_rccl_collectives_of_the_sharded_flow_on_a_one_rank_group(pkg, tmp_path)
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
-    for mode, port in (("sync", 29721), ("nccl1", 29722)):
+    for mode in ("sync", "nccl1"):
         out = str(tmp_path / f"r_{mode}")
-        env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+        env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
-        r = subprocess.run([sys.executable, os.path.join(root, "tests", "pf_auto_worker.py"), out, mode], env=env,
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "pf_auto_worker.py"), out, mode, "mixed"], env=env,
                            capture_output=True, text=True, timeout=500)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
         outs[mode] = np.load(out + ".rank0.npz")

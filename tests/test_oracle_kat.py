@@ -233,6 +233,28 @@ def test_kat8_kat9_update_closed_forms(kat):
         assert xp[3] == pytest.approx(10.0 + 0.5 / 1.51, rel=1e-15)
 
 
+def test_kat11_update_rotated_heading_off_axis_landmark_coupled_covariance():
+    # src/ekf.jl:46-77 with src/common.jl:139-165 at phi = pi/6, (dx, dy) = (3, 4) and a P with cross terms, against
+    # the information form of the same update (tests/kat_vectors.py): the Jacobian is the hand-written one
+    x, P, z, idf, xp, Pp = KV.kat11()
+    zhat, H = O.predict_observation(x, 1)
+    assert np.allclose(zhat, [5.0, math.atan2(4.0, 3.0) - math.pi / 6], rtol=0, atol=1e-15)
+    assert np.allclose(H, [[-0.6, -0.8, 0.0, 0.6, 0.8], [0.16, -0.12, -1.0, -0.16, 0.12]], rtol=0, atol=1e-15)
+    assert np.all(np.linalg.eigvalsh(P) > 0)
+    for fn in (O.update, O.update_sparse, O.update_joseph_sparse):
+        xn, Pn = fn(x.copy(), P.copy(), z, KV.R, idf if fn is O.update else idf.reshape(-1))
+        assert np.allclose(xn, xp, rtol=1e-11, atol=1e-13), fn.__name__
+        assert np.allclose(Pn, Pp, rtol=1e-9, atol=1e-13), fn.__name__
+    # the posterior is tighter than the prior in the measured directions, and really coupled
+    assert np.all(np.diag(Pp) < np.diag(P)) and abs(Pp[2, 4]) > 1e-4 and abs(Pp[0, 4]) > 1e-4
+    # the gate sees the same innovation: nis = v' S^-1 v with S = H P H' + R
+    v = np.array([0.3, -0.015])
+    S = H @ P @ H.T + KV.R
+    nis, nd = O.compute_association(x, P, z[:, 0], KV.R, 1)
+    assert nis == pytest.approx(float(v @ np.linalg.solve(S, v)), rel=1e-12)
+    assert nd == pytest.approx(nis + math.log(np.linalg.det(S)), rel=1e-12)
+
+
 def test_kat10_add_features_with_vehicle_covariance_and_existing_landmark():
     # src/ekf.jl:84-122 incl. the cross block with the existing map (rnm, :115-118)
     x, P, zn, xp, Pp = KV.kat10()
