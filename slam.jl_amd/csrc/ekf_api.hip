@@ -216,7 +216,7 @@ extern "C" int slam_ekf_destroy(slam_ekf_t h) {
     free_update_workspace(h);
     dev_free(h->x); dev_free(h->P); dev_free(h->tiles);
     dev_free(h->obsbuf); dev_free(h->idfbuf); dev_free(h->d_assoc); dev_free(h->gate_part); dev_free(h->znbuf);
-    dev_free(h->d_small); dev_free(h->d_status); dev_free(h->d_count); dev_free(h->d_pmax);
+    dev_free(h->d_small); dev_free(h->d_status); dev_free(h->d_count); dev_free(h->d_pmax); dev_free(h->dd_claim);
     if (h->h_flag) (void)hipHostFree(h->h_flag);
     if (h->h_obs) (void)hipHostFree(h->h_obs);
     if (h->h_idf) (void)hipHostFree(h->h_idf);
@@ -248,6 +248,7 @@ static int create_impl(slam_ekf* h) {
     if ((rc = dev_alloc_zero(&h->d_small, sizeof(double) * 64, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->d_count, sizeof(int32_t) * 4, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->d_pmax, sizeof(double), h->stream))) return rc;
+    if ((rc = dev_alloc_zero(&h->dd_claim, 8 * 64, h->stream))) return rc;
     HIP_TRY(hipHostMalloc((void**)&h->h_flag, sizeof(int32_t) * 16, hipHostMallocDefault));
     h->h_flag[0] = 0;
     HIP_TRY(hipHostGetDevicePointer((void**)&h->h_flag_dev, h->h_flag, 0));
@@ -292,7 +293,7 @@ extern "C" int slam_ekf_create(slam_ekf_t* out, int dtype, int max_landmarks, in
     h->h_obs = nullptr; h->h_idf = nullptr; h->h_assoc = nullptr; h->d_assoc = nullptr;
     h->gate_part = nullptr; h->gate_blocks_cap = 0;
     h->d_small = h->h_small = nullptr;
-    h->d_pmax = nullptr; h->pmax_valid = 0;
+    h->d_pmax = nullptr; h->pmax_valid = 0; h->dd_claim = nullptr;
     h->znbuf = nullptr; h->d_count = nullptr; h->h_flag = nullptr; h->h_flag_dev = nullptr; h->obs_seq = 0;
     h->d_status = h->h_status = nullptr;
     h->async_updates = 0; h->deferred = 0; h->pending_status = 0; h->debug_stamps = 0;

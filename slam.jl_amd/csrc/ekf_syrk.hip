@@ -562,13 +562,30 @@ __device__ __forceinline__ void mfma_chunk_p(const DdCtx& c, const char* sm, int
 
 // WRAP (timing experiment, experiments build only): the image's 8 chunks are walked twice -- the LDS fills, fragment
 // reads and MFMAs of a panel of 256 columns, i.e. of TWO steps' down-dates applied in one pass over P (wrong numbers).
-template <bool DBG, int NCH, int POFF, bool WRAP = false>
-__device__ __forceinline__ void dd_stream_p(DdCtx& c, const int2* __restrict__ list, int L, int nper, int& slot, char* sm) {
+// DYN (round 3): a PERSISTENT grid that CLAIMS its tiles.  `ctr` (one counter per XCD list, zeroed before the launch)
+// hands out the list positions nper, nper + 1, ... in order: the band-major walk stays what it was, and a workgroup
+// that was given slow tiles simply claims fewer.  One workgroup per tile from the hardware dispatcher (round 2) balances
+// as well, but every tile then pays a workgroup launch, an exposed first panel chunk and the drain of its 64 KB of
+// stores before the CU slot is free again; a persistent workgroup requests the next tile's first chunks during this
+// tile's last ones and lets its stores drain behind the next tile's MFMAs (dd_stream's point), which a STATIC split
+// could not turn into time because it ends with its slowest workgroup.  The claim costs nothing: lane 0 of wave 0
+// issues the returning atomic right after chunk 0's barrier, BEFORE the request of chunk 2 (vector-memory results
+// return in order: anything issued behind the P tile would wait for the P tile; this sits in front of a panel chunk
+// that is waited for anyway), stores the position to an LDS word before chunk 1's barrier, and every wave reads it
+// after that barrier -- wave-uniform, so the list entry comes through the SCALAR cache, outside the in-order queue.
+constexpr int CLAIM_OFF = 2 * 2 * IMG_CHUNK;        // the LDS word behind the two image buffers
+
+template <bool DBG, int NCH, int POFF, bool WRAP = false, bool DYN = false>
+__device__ __forceinline__ void dd_stream_p(DdCtx& c, const int2* __restrict__ list, int L, int nper, int& slot, char* sm,
+                                            unsigned* __restrict__ ctr = nullptr) {
     auto fetch = [&](int sl) { return sl < L ? list[sl] : make_int2(-1, -1); };
     auto request_chunk_p = [&](const DdCtx& cc, int2 t, int chunk, u32x4b (&gg)[3]) { ::request_chunk_p(cc, t, WRAP ? (chunk & 7) : chunk, gg); };
     constexpr int PCH = NCH - POFF > 0 ? NCH - POFF : 0;
+    static_assert(!DYN || NCH >= 4, "the claimed position is read after chunk 1 and used at chunk NCH - 2");
     int2 tile = fetch(slot);
-    int2 next = fetch(slot + nper);
+    int2 next = DYN ? make_int2(-1, -1) : fetch(slot + nper);
+    int next_slot = slot + nper;
+    unsigned claimed = 0;
     f32x16 acc[2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -582,15 +599,23 @@ __device__ __forceinline__ void dd_stream_p(DdCtx& c, const int2* __restrict__ l
     request_chunk_p(c, tile, 1, g);
     int base = 0;
     for (;;) {
-        const bool next_off = next.x >= 0 && next.x != next.y;
+        bool next_off = next.x >= 0 && next.x != next.y;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             const int pb = (base + ch) & 1;
             if (ch == PCH && !(DBG && (c.dbg & 4))) load_p_mfma(c, tile.x * TILE, tile.y * TILE, pold);
             mfma_chunk_p<DBG>(c, sm, pb, acc, WRAP && ch >= 8);
+            if (DYN && ch == 1 && threadIdx.x == 0) *reinterpret_cast<volatile unsigned*>(sm + CLAIM_OFF) = claimed;
             if (ch < NCH - 1) {
                 fill_lds_p(sm, pb ^ 1, g);
                 __syncthreads();
+                if (DYN && ch == 0 && threadIdx.x == 0)
+                    claimed = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (DYN && ch == 1) {
+                    next_slot = nper + __builtin_amdgcn_readfirstlane((int)*reinterpret_cast<volatile unsigned*>(sm + CLAIM_OFF));
+                    next = fetch(next_slot);
+                    next_off = next.x >= 0 && next.x != next.y;
+                }
                 if (ch + 2 < NCH) request_chunk_p(c, tile, ch + 2, g);
                 else if (next_off) request_chunk_p(c, next, 0, g);
             } else {
@@ -600,10 +625,10 @@ __device__ __forceinline__ void dd_stream_p(DdCtx& c, const int2* __restrict__ l
                 if (!(DBG && (c.dbg & 1))) store_p_mfma(c, tile.x * TILE, tile.y * TILE, pold, acc);
             }
         }
-        slot += nper;
+        slot = DYN ? next_slot : slot + nper;
         if (!next_off) return;
         tile = next;
-        next = fetch(slot + nper);
+        if (!DYN) next = fetch(slot + nper);
         base = (base + NCH) & 1;
     }
 }
@@ -670,7 +695,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
                                                                  const int32_t* __restrict__ status, int dbg,
                                                                  unsigned long long* __restrict__ prof,
                                                                  const int32_t* __restrict__ dcount, int joseph,
-                                                                 const char* __restrict__ img, int img_nch) {
+                                                                 const char* __restrict__ img, int img_nch,
+                                                                 unsigned* __restrict__ claim) {      // non-null: the grid claims its tiles (dd_stream_p<DYN>)
     if (status[0] != 0) return;
     if (dcount) {                     // observe(): the host's kp is an upper bound
         const int k = 2 * dcount[0];
@@ -699,7 +725,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int rk = blockIdx.x >> 3;
     const int nper = gridDim.x >> 3;
     // persistent launches only (fewer workgroups than tiles): the second half of the grid starts ~3.4 us late (speed only)
-    if (nper < L && rk >= (nper >> 1) && !(c.xflags & 1)) __builtin_amdgcn_s_sleep(127);
+    if (nper < L && rk >= (nper >> 1) && !(c.xflags & 1) && !claim) __builtin_amdgcn_s_sleep(127);
     const int2* list = tiles + (size_t)xcd * L;
     float* sD = &smem[0][0][0][0] + wave * (2 * 32 * SP);                   // per-wave scratches alias the panel buffers
     float* sV = sD + 32 * SP;
@@ -709,6 +735,33 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
     int2 tile = slot < L ? list[slot] : make_int2(-1, -1);
     if (tile.x < 0) return;
     f32x4 gx[2], gy[2];
+    if (BF && claim && img && kp >= 5 * KB && kp <= 8 * KB && !joseph) {
+        // the product's launch at 80 <= k <= 128: a persistent grid that CLAIMS its tiles (dd_stream_p<DYN>)
+        char* sm = reinterpret_cast<char*>(&smem[0][0][0][0]);
+        unsigned* ctr = claim + 16 * xcd;                     // one counter per XCD list, 64 bytes apart
+        if (tile.x != tile.y) {
+            switch (kp / KB) {
+                case 8: dd_stream_p<DBG, 8, 7, false, true>(c, list, L, nper, slot, sm, ctr); break;
+                case 7: dd_stream_p<DBG, 7, 6, false, true>(c, list, L, nper, slot, sm, ctr); break;
+                case 6: dd_stream_p<DBG, 6, 5, false, true>(c, list, L, nper, slot, sm, ctr); break;
+                default: dd_stream_p<DBG, 5, 4, false, true>(c, list, L, nper, slot, sm, ctr); break;
+            }
+        }
+        // what is left for this workgroup: the list's diagonal tiles (fp32 pipeline, 1.3 % of the tiles), claimed one at a time
+        while (slot < L) {
+            tile = list[slot];
+            if (tile.x < 0) break;
+            __syncthreads();                                   // every wave is done with the image buffers and the claim word
+            request_chunk(c, tile, 0, gx, gy);
+            if (tile.x != tile.y) dd_tile<false, DBG>(c, tile, make_int2(-1, -1), smem, sD, sV, gx, gy);
+            else dd_tile<true, DBG>(c, tile, make_int2(-1, -1), smem, sD, sV, gx, gy);
+            if (tid == 0)
+                *reinterpret_cast<volatile unsigned*>(sm + CLAIM_OFF) = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            slot = nper + __builtin_amdgcn_readfirstlane((int)*reinterpret_cast<volatile unsigned*>(sm + CLAIM_OFF));
+        }
+        return;
+    }
     if (BF && tile.x != tile.y && kp >= 5 * KB && kp <= 8 * KB && !joseph) {
         // off-diagonal tiles on the bf16 matrix cores (kp = 80, 96, 112 or 128); the diagonal ones follow below
         char* sm = reinterpret_cast<char*>(&smem[0][0][0][0]);
@@ -955,7 +1008,8 @@ int ensure_tile_order(slam_ekf* h, int T) {
 
 int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int pitch, const int32_t* dcount, int joseph, int k16,
                     const void* img) {
-#define IMGARGS (const char*)img, h->kcap / 16
+#define IMGARGS (const char*)img, h->kcap / 16, (unsigned*)nullptr
+#define IMGARGS_CLAIM (const char*)img, h->kcap / 16, h->dd_claim
     const int n = 3 + 2 * h->N;
     const int edge = h->dtype == SLAM_F32 ? TILE : DT;
     const int rc = ensure_tile_order(h, (n + edge - 1) / edge);
@@ -1007,9 +1061,21 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
                 const bool bandB = slam_exp_env("SLAMHIP_ORDER", 2) != 0;
                 const int2* lst = bandB ? (const int2*)h->tiles + h->tilesB_off : (const int2*)h->tiles;
                 const int L = bandB ? h->tilesB_len : h->tiles_len;
-                int wgs = slam_exp_env("SLAMHIP_WGS", L);
+                // Round 3: a persistent grid (two workgroups per CU) that CLAIMS its tiles from per-XCD counters in list
+                // order (dd_stream_p<DYN>): the dispatcher's load balance without a workgroup launch, an exposed first
+                // panel chunk and a store drain per tile.  SLAMHIP_WGS (experiments build): n > 0 = the static persistent
+                // grid with n workgroups per list, 0 = one workgroup per tile from the dispatcher (round 2's launch).
+                const int wgs_env = slam_exp_env("SLAMHIP_WGS", -1);
+                const bool dyn = wgs_env < 0 && img != nullptr;
+                int wgs = dyn ? per_xcd : (wgs_env > 0 ? wgs_env : L);
                 if (wgs > L) wgs = L;
                 if (wgs < 1) wgs = 1;
+                if (dyn) {
+                    HIP_TRY(hipMemsetAsync(h->dd_claim, 0, 8 * 64, h->stream));
+                    hipLaunchKernelGGL((downdate_f32_mfma<false, 4, 3, true>), dim3(8 * wgs), dim3(NTHREADS), 0, h->stream,
+                                       (float*)h->P, h->ld, n, (const float*)X, (const float*)Y, pitch, kp_total, lst, L,
+                                       h->d_status, h->xflags << 8, (unsigned long long*)nullptr, dcount, joseph, IMGARGS_CLAIM);
+                } else
                 hipLaunchKernelGGL((downdate_f32_mfma<false, 4, 3, true>), dim3(8 * wgs), dim3(NTHREADS), 0, h->stream,
                                    (float*)h->P, h->ld, n, (const float*)X, (const float*)Y, pitch, kp_total, lst, L,
                                    h->d_status, h->xflags << 8, (unsigned long long*)nullptr, dcount, joseph, IMGARGS);
@@ -1035,4 +1101,5 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
     HIP_TRY(hipGetLastError());
     return SLAM_OK;
 #undef IMGARGS
+#undef IMGARGS_CLAIM
 }
