@@ -209,6 +209,20 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         res[regime] = {"particle_steps_per_s": NP * steps / el, "ms_per_step": el / steps * 1e3, "resamples": pf.resamples - n0}
+    info = pf.shard.comm_info()            # what the exchange between the ranks saw: peers attached?  steps that halted for the host?
+    halts = info["halts"]
+    if world > 1:
+        th = torch.tensor([float(halts)], dtype=torch.float64, device=RED_DEVICE)
+        dist.all_reduce(th, op=dist.ReduceOp.MAX)
+        halts = int(th.item())
+    comm = {"world": world, "halts": halts, "peers_attached": bool(info["peers"]),
+            "backend": ("single GPU: no exchange" if world == 1 else
+                        "device-side: per-step scalars written into the peers' inboxes and the resampling's reads of the peers' "
+                        "weights / poses / ancestor tables / records go over IPC-mapped buffers (xGMI between GPUs), no collective "
+                        "launch, no host" if info["peers"] else
+                        "halting flow: scalars through a pinned host page, a resampling step halts and the hosts resample through "
+                        f"torch.distributed ({dist.get_backend()})"),
+            "control_plane": None if world == 1 else f"torch.distributed ({dist.get_backend()}): set-up (object all-gather of the peer blobs) and timing only"}
     pf.close()
     weak = None
     if world > 1:
@@ -241,11 +255,15 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
             "unit": "particle-steps/s", "n_gpus": world, "scaling": "strong",
             "config": {"workload": f"FastSLAM-1.0 known correspondences, {NP} particles x {NL} landmarks, {M} obs/step, fp32, "
                                    f"predict + {M} 2x2 EKF updates + weights + Neff all-reduce (+ resample when Neff < 0.75 Np)"},
-            "regimes": res, "weak_scaling": weak,
+            "regimes": res, "weak_scaling": weak, "comm": comm,
             "resampling": ("decided and done on the device, lazily (poses permuted, ancestor tables composed, maps moved on "
                            "their next update)" if world == 1 else
+                           "decided and done on the device on every rank: cdf over all ranks' weights (read from the peers' "
+                           "buffers), global ancestors, remote poses / table entries read from their owners, maps stay put (an "
+                           "ancestor-table entry is a global particle id; a remote record is read when its landmark is next updated)"
+                           if comm["peers_attached"] else
                            "decided on the device (scalars exchanged GPU to GPU through a pinned page); a resampling step halts "
-                           "the queue, the hosts all-gather the log-weights and exchange records (RCCL), then resume"),
+                           "the queue, the hosts all-gather the log-weights and exchange records, then resume"),
             "roofline": {"bound": "hbm", "achieved": NP * bytes_per / t_step / 1e9, "peak": HBM_PEAK_GBPS * world,
                          "unit": "GB/s", "frac": NP * bytes_per / t_step / 1e9 / (HBM_PEAK_GBPS * world), "traffic": None,
                          "algorithmic_bytes_per_particle_step": bytes_per, "regime": "no_resample: per step ONE sweep kernel "

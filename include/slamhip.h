@@ -331,6 +331,9 @@ int slam_pf_attach_exchange(slam_pf_t h, int rank, int world, void* page, size_t
 int slam_pf_export_peer(slam_pf_t h, void* blob);
 int slam_pf_attach_peers(slam_pf_t h, int rank, int world, const void* blobs);
 int slam_pf_detach_peers(slam_pf_t h);
+/* Collective: a barrier among the attached ranks through their inboxes; SLAM_OK when every peer's word arrived within
+ * timeout_ms.  The caller's check, right after attaching, that the GPUs see each other's writes. */
+int slam_pf_peer_selftest(slam_pf_t h, int timeout_ms);
 int slam_pf_comm_info(slam_pf_t h, int64_t out[4]);
 /* Diagnostics: 100 MHz wall-clock stamps of the last auto step: kernel start, every workgroup's statistics collected,
  * statistics folded, decision taken, bookkeeping done, published; [6] the collecting workgroup finished its own share,

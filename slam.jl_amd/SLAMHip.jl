@@ -16,7 +16,7 @@ export SlamState, EKFSlamState, set_state!, predict, update, add_features, assoc
        compute_association, predict_observation, mpi_to_pi,
        ekf_predict!, ekf_update!, augment!, observe!, cov_block, cov_diag, feature_ellipses, vehicle_ellipse,
        PFSlamState, set_pose!, init_landmarks!, pf_predict!, update_known!, step!, step_async!, flush!,
-       resample!, mean_pose, weights, particles, peer_blob, attach_peers!, detach_peers!, comm_info
+       resample!, mean_pose, weights, particles, peer_blob, attach_peers!, peer_selftest, detach_peers!, comm_info
 
 const libslamhip = get(ENV, "SLAMHIP_LIB", joinpath(@__DIR__, "libslamhip.so"))
 
@@ -306,6 +306,11 @@ function attach_peers!(s::PFSlamState, blobs::AbstractVector)
     all = reduce(vcat, [Vector{UInt8}(b) for b in blobs])
     check(ccall((:slam_pf_attach_peers, libslamhip), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}), s.handle, s.rank, s.world, all))
     s
+end
+
+"Collective: true when every attached peer's inbox write arrived within `timeout_ms` (call right after `attach_peers!`)."
+function peer_selftest(s::PFSlamState, timeout_ms::Integer = 3000)
+    ccall((:slam_pf_peer_selftest, libslamhip), Cint, (Ptr{Cvoid}, Cint), s.handle, timeout_ms) == 0
 end
 
 "Collective: remote records come home, the peers are detached (call on every rank before any rank lets its state go)."

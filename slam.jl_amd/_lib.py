@@ -134,6 +134,7 @@ SIGNATURES = {
     "slam_pf_export_peer": (C.c_int, [_h, C.c_void_p]),
     "slam_pf_attach_peers": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p]),
     "slam_pf_detach_peers": (C.c_int, [_h]),
+    "slam_pf_peer_selftest": (C.c_int, [_h, C.c_int]),
     "slam_pf_comm_info": (C.c_int, [_h, C.POINTER(C.c_int64)]),
     "slam_pf_debug_stamps": (C.c_int, [_h, C.POINTER(C.c_uint64)]),
     "slam_pf_resample": (C.c_int, [_h, C.c_double, C.POINTER(C.c_int)]),

@@ -1828,15 +1828,15 @@ __global__ __launch_bounds__(64) void pf_peer_gate_kernel(PfCtl* ctl, long long 
 }
 
 // A barrier among the ranks on their streams (materialise): every rank counts its calls, tells every peer, waits for all.
-__global__ __launch_bounds__(64) void pf_peer_barrier_kernel(PfCtl* ctl, unsigned long long count, const PfPeers* __restrict__ peers,
-                                                             PfInbox* inbox, int rank, int world) {
+__global__ __launch_bounds__(64) void pf_peer_barrier_kernel(int32_t* err, unsigned long long count, const PfPeers* __restrict__ peers,
+                                                             PfInbox* inbox, int rank, int world, unsigned long long timeout_ticks) {
     const int r = threadIdx.x;
     if (r < world) {
         __hip_atomic_store(&peers->inbox[r]->bar[rank][0], count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const unsigned long long t0 = wall_clock64();
         while (__hip_atomic_load(&inbox->bar[r][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < count) {
             __builtin_amdgcn_s_sleep(20);
-            if (wall_clock64() - t0 > 2000000000ull) { ctl->error = PF_ERR_PEER; break; }
+            if (wall_clock64() - t0 > timeout_ticks) { *err = PF_ERR_PEER; break; }
         }
     }
 }
@@ -2149,8 +2149,8 @@ static bool pf_sharded(const slam_pf* h) { return h->d_peers != nullptr && h->xc
 
 static int pf_peer_barrier(slam_pf* h) {
     h->bar_count += 1;
-    hipLaunchKernelGGL(pf_peer_barrier_kernel, dim3(1), dim3(64), 0, h->stream, h->d_ctl, (unsigned long long)h->bar_count,
-                       (const PfPeers*)h->d_peers, h->inbox, h->xchg_rank, h->xchg_world);
+    hipLaunchKernelGGL(pf_peer_barrier_kernel, dim3(1), dim3(64), 0, h->stream, &h->d_ctl->error, (unsigned long long)h->bar_count,
+                       (const PfPeers*)h->d_peers, h->inbox, h->xchg_rank, h->xchg_world, 2000000000ull);       // 20 s
     HIP_TRY(hipGetLastError());
     return SLAM_OK;
 }
@@ -3272,6 +3272,40 @@ extern "C" int slam_pf_attach_peers(slam_pf_t h, int rank, int world, const void
     HIP_TRY(hipMemcpy(h->d_peers, &t, sizeof(t), hipMemcpyHostToDevice));
     h->xchg_rank = rank;
     h->xchg_world = world;
+    return SLAM_OK;
+}
+
+/* A barrier among the attached ranks through their inboxes (every rank writes a word into every peer's inbox and polls its
+ * own): collective, synchronises.  SLAM_OK when every peer's word arrived within timeout_ms -- the caller's check that the
+ * GPUs really see each other's writes before it relies on the device-side exchange (it can fall back to the halting
+ * flow otherwise). */
+extern "C" int slam_pf_peer_selftest(slam_pf_t h, int timeout_ms) {
+    ARG_CHECK(h != nullptr, "null handle");
+    ARG_CHECK(pf_sharded(h), "no peers attached");
+    ARG_CHECK(timeout_ms > 0, "timeout must be positive");
+    HIP_TRY(hipSetDevice(h->device));
+    PF_LEGACY_ENTRY(h);
+    int32_t* d_err = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_err, sizeof(int32_t)));
+    hipError_t e = hipMemsetAsync(d_err, 0, sizeof(int32_t), h->stream);
+    h->bar_count += 1;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pf_peer_barrier_kernel, dim3(1), dim3(64), 0, h->stream, d_err, (unsigned long long)h->bar_count,
+                           (const PfPeers*)h->d_peers, h->inbox, h->xchg_rank, h->xchg_world, (unsigned long long)timeout_ms * 100000ull);
+        e = hipGetLastError();
+    }
+    int32_t err = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&err, d_err, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_err);
+    if (e != hipSuccess) {
+        slam_set_error("HIP error in slam_pf_peer_selftest: %s", hipGetErrorString(e));
+        return SLAM_E_HIP;
+    }
+    if (err) {
+        slam_set_error("peer self-test: a peer's word did not arrive within %d ms", timeout_ms);
+        return SLAM_E_HIP;
+    }
     return SLAM_OK;
 }
 

@@ -275,6 +275,10 @@ class PFShard:
     def detach_peers(self):
         check(lib.slam_pf_detach_peers(self._h))
 
+    def peer_selftest(self, timeout_ms=3000):
+        """Collective: True when every attached peer's inbox write arrived here within the time-out."""
+        return lib.slam_pf_peer_selftest(self._h, int(timeout_ms)) == 0
+
     def comm_info(self):
         """{world, peers attached?, SLAM_PF_HALTED returns so far, resamplings so far}."""
         out = (C.c_int64 * 4)()
@@ -714,9 +718,23 @@ class PFSlamState(FastSLAM):
                 dist.all_gather_object(blobs, (socket_host(), shard.export_peer()))
                 one_node = len({h for h, _ in blobs}) == 1
                 if one_node and world <= 8 and os.environ.get("SLAMHIP_PF_PEERS", "1") != "0":
-                    shard.attach_peers(rank, world, [b for _, b in blobs])
-                    self.peers = True
-                elif one_node:
+                    # attach, then prove that the GPUs see each other's inbox writes; any rank failing either step sends
+                    # every rank to the fallback (the decision must be the same everywhere)
+                    try:
+                        shard.attach_peers(rank, world, [b for _, b in blobs])
+                        ok = shard.peer_selftest()
+                    except Exception:  # noqa: BLE001 -- e.g. hipIpcOpenMemHandle refused
+                        ok = False
+                    oks = [None] * world
+                    dist.all_gather_object(oks, bool(ok))
+                    if all(oks):
+                        self.peers = True
+                    else:
+                        try:
+                            shard.detach_peers()
+                        except Exception:  # noqa: BLE001
+                            pass
+                if one_node and not self.peers:
                     shard.attach_exchange(rank, world, shared_page(dist, rank, world, 2 * world * 8))
         else:
             shard = PFShard(n, max_landmarks, seed, dtype=dtype, device=device)

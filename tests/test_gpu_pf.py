@@ -817,6 +817,7 @@ def test_sharded_filter_resamples_on_the_device(pkg, dtype, world, proposal):
     def drive(r):
         try:
             f = ranks[r]
+            assert f.shard.peer_selftest(10000)      # (collective) every peer's inbox write arrives
             for t, (g, z, ids, force) in enumerate(steps):
                 f.step_async(6.0, g, 4.0, Q, 0.1, z, ids, R, force_resample=force, proposal=proposal)
                 if t in (7, 20):
