@@ -160,6 +160,14 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
         z = np.vstack([np.hypot(dx, dy), np.arctan2(dy, dx) - pose[2]]) + rng.normal(0, [[0.1], [math.pi / 180]], (2, M))
         obs.append((z, ids))
     res = {}
+    trace = os.environ.get("SLAM_BENCH_TRACE") == "1" and rank == 0       # progress lines on stderr (diagnosing a slow rehearsal)
+    t_trace = time.perf_counter()
+
+    def say(msg):
+        if trace:
+            print(f"[fastslam +{time.perf_counter() - t_trace:7.2f} s] {msg}", file=sys.stderr, flush=True)
+    n_align = 300 if os.environ.get("SLAM_BENCH_REHEARSE") != "1" else 20    # (a one-card rehearsal only checks the plumbing)
+    say(f"filter created, world {world}, peers {pf.shard.comm_info()}")
     fence()                                # the ranks start their (device-side) scalar exchange together
     # observations converted once, outside the timed regions: a timed step is one library call
     prep = [pkg.PFShard.prepare_obs(z, ids) for z, ids in obs]
@@ -187,11 +195,13 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
         while world == 1 and time.perf_counter() - t_pw < 0.1:
             run(j % len(obs), force, prop, use_async)
             j += 1
-        for j in range(300 if world > 1 else 0):
+        say(f"regime {regime}: warm-up")
+        for j in range(n_align if world > 1 else 0):
             run(j % len(obs), force, prop, use_async)
         for _ in range(warmup):
             run(next(it), force, prop, use_async)
         r0 = pf.flush() if use_async else None
+        say(f"regime {regime}: timed region")
         pf.shard.sync()
         fence()
         n0 = pf.resamples
@@ -209,6 +219,8 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         res[regime] = {"particle_steps_per_s": NP * steps / el, "ms_per_step": el / steps * 1e3, "resamples": pf.resamples - n0}
+        say(f"regime {regime}: {el / steps * 1e3:.3f} ms per step")
+    say("regimes done; comm_info")
     info = pf.shard.comm_info()            # what the exchange between the ranks saw: peers attached?  steps that halted for the host?
     halts = info["halts"]
     if world > 1:
@@ -223,7 +235,9 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
                         "halting flow: scalars through a pinned host page, a resampling step halts and the hosts resample through "
                         f"torch.distributed ({dist.get_backend()})"),
             "control_plane": None if world == 1 else f"torch.distributed ({dist.get_backend()}): set-up (object all-gather of the peer blobs) and timing only"}
+    say(f"closing the filter ({comm['halts']} halts)")
     pf.close()
+    say("filter closed")
     weak = None
     if world > 1:
         # the same filter with the per-GPU particle count held at 262144 (weak scaling): the strong-scaling figure
@@ -231,7 +245,8 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
         pfw = pkg.PFSlamState(NP * world, NL, seed=20240602, dtype="f32", device=local_rank, distributed=True)
         pfw.shard.set_pose([0.0, 0.0, 0.3])
         pfw.shard.init_landmarks(lm, 0.01, 0.1)
-        for j in range(300):
+        say("weak-scaling filter created")
+        for j in range(n_align):
             pfw.step_async(8.0, 0.0, 4.0, Qs, 0.025, *obs[j % len(obs)], Rs, force_resample=False, prepared=prep[j % len(obs)])
         pfw.flush()
         pfw.shard.sync()

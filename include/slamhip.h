@@ -326,6 +326,9 @@ int slam_pf_attach_exchange(slam_pf_t h, int rank, int world, void* page, size_t
  * sweeps slam_pf_update_known / slam_pf_step / slam_pf_step_proposal, slam_pf_update_unknown, slam_pf_detach_peers) are
  * COLLECTIVE while peers are attached: every rank must call them in the same order (they first bring remote records
  * home, with barriers among the ranks' streams).  Detach (collectively) before any rank destroys its handle.
+ * Limit: a peer of ANOTHER process must keep its landmark buffer (5 * n_local * max_landmarks values) below 2 GiB --
+ * hipIpcOpenMemHandle of a larger allocation hangs on ROCm 7.2 (tools/ipc_gen_test.py); slam_pf_attach_peers returns
+ * SLAM_E_CAPACITY instead and the caller keeps the halting flow (slam.jl_amd/pf.py does that by itself).
  * slam_pf_comm_info: out = {ranks, 1 if peers are attached, SLAM_PF_HALTED returns so far, resamplings so far}. */
 #define SLAM_PF_PEER_BLOB_BYTES 1024
 int slam_pf_export_peer(slam_pf_t h, void* blob);

@@ -574,6 +574,9 @@ __device__ __forceinline__ void mfma_chunk_p(const DdCtx& c, const char* sm, int
 // that is waited for anyway), stores the position to an LDS word before chunk 1's barrier, and every wave reads it
 // after that barrier -- wave-uniform, so the list entry comes through the SCALAR cache, outside the in-order queue.
 constexpr int CLAIM_OFF = 2 * 2 * IMG_CHUNK;        // the LDS word behind the two image buffers
+#ifndef DD_PCH0
+#define DD_PCH0 0
+#endif
 
 template <bool DBG, int NCH, int POFF, bool WRAP = false, bool DYN = false>
 __device__ __forceinline__ void dd_stream_p(DdCtx& c, const int2* __restrict__ list, int L, int nper, int& slot, char* sm,
@@ -741,10 +744,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
         unsigned* ctr = claim + 16 * xcd;                     // one counter per XCD list, 64 bytes apart
         if (tile.x != tile.y) {
             switch (kp / KB) {
-                case 8: dd_stream_p<DBG, 8, 7, false, true>(c, list, L, nper, slot, sm, ctr); break;
-                case 7: dd_stream_p<DBG, 7, 6, false, true>(c, list, L, nper, slot, sm, ctr); break;
-                case 6: dd_stream_p<DBG, 6, 5, false, true>(c, list, L, nper, slot, sm, ctr); break;
-                default: dd_stream_p<DBG, 5, 4, false, true>(c, list, L, nper, slot, sm, ctr); break;
+                // (DD_PCH0 = 1, build-time A/B: the P tile requested at the tile's FIRST chunk instead of its second)
+                case 8: dd_stream_p<DBG, 8, 7 + DD_PCH0, false, true>(c, list, L, nper, slot, sm, ctr); break;
+                case 7: dd_stream_p<DBG, 7, 6 + DD_PCH0, false, true>(c, list, L, nper, slot, sm, ctr); break;
+                case 6: dd_stream_p<DBG, 6, 5 + DD_PCH0, false, true>(c, list, L, nper, slot, sm, ctr); break;
+                default: dd_stream_p<DBG, 5, 4 + DD_PCH0, false, true>(c, list, L, nper, slot, sm, ctr); break;
             }
         }
         // what is left for this workgroup: the list's diagonal tiles (fp32 pipeline, 1.3 % of the tiles), claimed one at a time
@@ -1070,8 +1074,7 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
                 int wgs = dyn ? per_xcd : (wgs_env > 0 ? wgs_env : L);
                 if (wgs > L) wgs = L;
                 if (wgs < 1) wgs = 1;
-                if (dyn) {
-                    HIP_TRY(hipMemsetAsync(h->dd_claim, 0, 8 * 64, h->stream));
+                if (dyn) {                 // (the counters were zeroed by the W1 kernel that wrote the image: ekf_update.hip)
                     hipLaunchKernelGGL((downdate_f32_mfma<false, 4, 3, true>), dim3(8 * wgs), dim3(NTHREADS), 0, h->stream,
                                        (float*)h->P, h->ld, n, (const float*)X, (const float*)Y, pitch, kp_total, lst, L,
                                        h->d_status, h->xflags << 8, (unsigned long long*)nullptr, dcount, joseph, IMGARGS_CLAIM);

@@ -885,7 +885,10 @@ __global__ __launch_bounds__(W1_THREADS) void w1_mfma_kernel(const double* __res
                                                              const double* __restrict__ g,
                                                              const int32_t* __restrict__ status,
                                                              const int32_t* __restrict__ dcount, char* __restrict__ img,
-                                                             int img_nch) {
+                                                             int img_nch, unsigned* __restrict__ dd_claim) {
+    // the tile counters of the down-date that follows (its persistent grid claims tiles from them): zeroed here, one
+    // launch ahead, instead of by a memset node of its own in front of the dominant kernel
+    if (dd_claim && blockIdx.x == 0 && threadIdx.x < 128) dd_claim[threadIdx.x] = 0u;
     if (status[0] != 0) return;
     if (dcount) {
         int m = 0, k = 0;
@@ -973,7 +976,8 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form, const int32_t*
             // W1 = PHt*C and x += PHt*g on the fp64 matrix cores
             hipLaunchKernelGGL(w1_mfma_kernel<T>, dim3(h->npad / 128), dim3(W1_THREADS), (size_t)kp * kp * sizeof(double),
                                h->stream, (const double*)h->PHt, pitchA, (const double*)h->Cmat, pitchA, kp, W1, pitchW, x, n,
-                               (const double*)h->gvec, h->d_status, dcount, use_img ? (char*)h->Wimg : (char*)nullptr, h->kcap / 16);
+                               (const double*)h->gvec, h->d_status, dcount, use_img ? (char*)h->Wimg : (char*)nullptr, h->kcap / 16,
+                               use_img ? h->dd_claim : (unsigned*)nullptr);
             kp_total = round_up(k, 16);
         } else if (!joseph) {
             // W1 = PHt*C

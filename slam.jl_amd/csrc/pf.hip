@@ -3209,6 +3209,7 @@ static void pf_detach_peers_impl(slam_pf* h) {
                 (void)hipIpcCloseMemHandle(h->peer_open[r][i]);
                 h->peer_open[r][i] = nullptr;
             }
+    (void)hipDeviceSynchronize();       // the unmaps have taken effect before anybody frees (and re-exports) the memory behind them
     if (h->d_peers) { (void)hipFree(h->d_peers); h->d_peers = nullptr; }
     memset(&h->peers, 0, sizeof(h->peers));
 }
@@ -3253,6 +3254,16 @@ extern "C" int slam_pf_attach_peers(slam_pf_t h, int rank, int world, const void
             }
             for (int i = 0; i < 9; ++i) ptr[i] = b.raw[i];
         } else {
+            // hipIpcOpenMemHandle of an allocation above 2 GiB never returns on this runtime (ROCm 7.2, dmabuf IPC; measured
+            // with tools/ipc_gen_test.py: 1.91 GiB opens in milliseconds, 2.50 GiB hangs both processes): refuse BEFORE
+            // opening anything, the caller falls back to the halting flow.  The largest buffer is the landmark array.
+            const double lm_bytes = (double)b.n * 5.0 * (double)b.nl * (double)h->esz;
+            if (lm_bytes > 2047.0 * 1048576.0) {
+                slam_set_error("rank %d's landmark buffer is %.2f GiB: above the 2 GiB an IPC mapping can carry on this runtime "
+                               "(use more ranks, or the halting flow)", r, lm_bytes / 1073741824.0);
+                pf_detach_peers_impl(h);
+                return SLAM_E_CAPACITY;
+            }
             for (int i = 0; i < 9; ++i) {
                 const hipError_t e = hipIpcOpenMemHandle(&ptr[i], b.ipc[i], hipIpcMemLazyEnablePeerAccess);
                 if (e != hipSuccess) {

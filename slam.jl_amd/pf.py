@@ -24,6 +24,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import sys
 
 import numpy as np
 
@@ -703,6 +704,11 @@ class PFSlamState(FastSLAM):
         if use_dist:
             import torch
             rank, world = dist.get_rank(), dist.get_world_size()
+            trace = os.environ.get("SLAMHIP_TRACE_CLOSE") == "1"
+
+            def say(msg):
+                if trace:
+                    print(f"[create rank {rank}] {msg}", file=sys.stderr, flush=True)
             if n % world:
                 raise ValueError("n must be divisible by the number of ranks")
             per = n // world
@@ -715,16 +721,33 @@ class PFSlamState(FastSLAM):
                 # than 8 ranks or ranks on several nodes: the legacy flow -- scalars through a shared pinned page, a
                 # resampling step halts and the host resamples through the collectives
                 blobs = [None] * world
-                dist.all_gather_object(blobs, (socket_host(), shard.export_peer()))
+                say("shard created; exporting")
+                mine = shard.export_peer()
+                say("exported; all-gather of the blobs")
+                dist.all_gather_object(blobs, (socket_host(), mine))
+                say("blobs gathered")
                 one_node = len({h for h, _ in blobs}) == 1
                 if one_node and world <= 8 and os.environ.get("SLAMHIP_PF_PEERS", "1") != "0":
                     # attach, then prove that the GPUs see each other's inbox writes; any rank failing either step sends
                     # every rank to the fallback (the decision must be the same everywhere)
+                    # one rank at a time (a precaution: with dmabuf IPC the importer asks the EXPORTER's process for the
+                    # buffer, so two processes inside an open of each other's memory depend on each other's runtime).
+                    # A landmark buffer above 2 GiB makes attach_peers refuse (hipIpcOpenMemHandle hangs above that size
+                    # on ROCm 7.2: tools/ipc_gen_test.py) and every rank takes the fallback below
+                    ok = True
+                    for turn in range(world):
+                        if turn == rank:
+                            try:
+                                shard.attach_peers(rank, world, [b for _, b in blobs])
+                            except Exception:  # noqa: BLE001 -- e.g. hipIpcOpenMemHandle refused
+                                ok = False
+                        dist.barrier()
+                    say(f"attached ({ok}); self-test")
                     try:
-                        shard.attach_peers(rank, world, [b for _, b in blobs])
-                        ok = shard.peer_selftest()
-                    except Exception:  # noqa: BLE001 -- e.g. hipIpcOpenMemHandle refused
+                        ok = ok and shard.peer_selftest()
+                    except Exception:  # noqa: BLE001
                         ok = False
+                    say(f"self-test {ok}")
                     oks = [None] * world
                     dist.all_gather_object(oks, bool(ok))
                     if all(oks):
@@ -747,9 +770,16 @@ class PFSlamState(FastSLAM):
         barrier -- nobody frees buffers a peer may still read."""
         if getattr(self, "peers", False):
             import torch.distributed as dist
+            trace = os.environ.get("SLAMHIP_TRACE_CLOSE") == "1"
+            if trace:
+                print(f"[close rank {dist.get_rank()}] detach", file=sys.stderr, flush=True)
             self.shard.detach_peers()
             self.shard.sync()
+            if trace:
+                print(f"[close rank {dist.get_rank()}] barrier", file=sys.stderr, flush=True)
             dist.barrier()
+            if trace:
+                print(f"[close rank {dist.get_rank()}] destroy", file=sys.stderr, flush=True)
             self.peers = False
         self.shard.close()
 

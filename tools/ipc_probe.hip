@@ -154,6 +154,7 @@ static int run(int rank, int rfd, int wfd) {
         printf("[rank %d] %-12s payload after hand-shake: %u wrong words of %d x 3\n", rank, kinds[kind], bad_total, N);
         CK(hipIpcCloseMemHandle(pflag));
         CK(hipIpcCloseMemHandle(ppay));
+        CK(hipDeviceSynchronize());
         char c = 1;
         if (write(wfd, &c, 1) != 1 || read(rfd, &c, 1) != 1) return 1;      // both have closed before anyone frees
         CK(hipFree(flag));
