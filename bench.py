@@ -152,13 +152,14 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
     pf.shard.set_pose([0.0, 0.0, 0.3])
     pf.shard.init_landmarks(lm, 0.01, 0.1)
     pose = np.array([0.0, 0.0, 0.3])
-    obs = []
+    obs, poses = [], [pose.copy()]
     for t in range(5 * (steps + warmup) + 8):
         pose = np.array([pose[0] + 0.2 * math.cos(pose[2]), pose[1] + 0.2 * math.sin(pose[2]), pose[2]])
         ids = (np.arange(M) + M * t) % NL + 1
         dx, dy = lm[ids - 1, 0] - pose[0], lm[ids - 1, 1] - pose[1]
         z = np.vstack([np.hypot(dx, dy), np.arctan2(dy, dx) - pose[2]]) + rng.normal(0, [[0.1], [math.pi / 180]], (2, M))
         obs.append((z, ids))
+        poses.append(pose.copy())                # poses[t]: where the vehicle is BEFORE step t
     res = {}
     trace = os.environ.get("SLAM_BENCH_TRACE") == "1" and rank == 0       # progress lines on stderr (diagnosing a slow rehearsal)
     t_trace = time.perf_counter()
@@ -172,15 +173,21 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
     # observations converted once, outside the timed regions: a timed step is one library call
     prep = [pkg.PFShard.prepare_obs(z, ids) for z, ids in obs]
     Qs, Rs = pkg.small(Q), pkg.small(R)
-    it = iter(range(len(obs)))
     import gc
 
-    def run(k, force, prop, use_async):
+    def run(k, force, prop, use_async, V=8.0):
         z, ids = obs[k]
         if use_async:                      # slam_pf_step_auto: enqueued; statistics, Neff, decision, resampling on the device
-            pf.step_async(8.0, 0.0, 4.0, Qs, 0.025, z, ids, Rs, force_resample=force, proposal=prop, prepared=prep[k])
+            pf.step_async(V, 0.0, 4.0, Qs, 0.025, z, ids, Rs, force_resample=force, proposal=prop, prepared=prep[k])
         else:                              # the host decides after every step (slam_pf_step + read-back)
-            pf.step(8.0, 0.0, 4.0, Q, 0.025, z, ids, R, force_resample=force, proposal=prop)
+            pf.step(V, 0.0, 4.0, Q, 0.025, z, ids, R, force_resample=force, proposal=prop)
+
+    def fresh(k):
+        """Every regime starts from a CLEAN filter at the vehicle's pose before step k: every particle there, the map at
+        truth + jitter, uniform weights (a regime that never resamples must not inherit -- or hand on -- a degenerate
+        particle set; with 200+ steps per regime the fifth regime used to start from non-finite weights)."""
+        pf.shard.set_pose(poses[k])
+        pf.shard.init_landmarks(lm, 0.01, 0.1)
 
     # (the fourth regime is the FastSLAM-2.0 step of SURVEY 8f N4: the pose drawn from the observation-aware proposal;
     #  the fifth is the first one with the host back in the loop, for comparison)
@@ -190,14 +197,20 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
         gc.collect()                       # parked until the end of the timed region (see main)
         gc.disable()
         # untimed device warm-up in the regime's own mode (a GPU out of idle needs ~40 ms of load to reach its
-        # sustained clocks): a fixed count keeps the ranks' exchanges aligned
-        t_pw, j = time.perf_counter(), 0
+        # sustained clocks): the vehicle stands still at the regime's first observation (V = 0: same kernels, and the
+        # particles stay where the observations are); a fixed count keeps the ranks' exchanges aligned
+        k0 = (steps + warmup) * len(res)
+        fresh(k0)
+        t_pw = time.perf_counter()
         while world == 1 and time.perf_counter() - t_pw < 0.1:
-            run(j % len(obs), force, prop, use_async)
-            j += 1
+            run(k0, force, prop, use_async, V=0.0)
         say(f"regime {regime}: warm-up")
         for j in range(n_align if world > 1 else 0):
-            run(j % len(obs), force, prop, use_async)
+            run(k0, force, prop, use_async, V=0.0)
+        if use_async:
+            pf.flush()
+        fresh(k0)
+        it = iter(range(k0, len(obs)))
         for _ in range(warmup):
             run(next(it), force, prop, use_async)
         r0 = pf.flush() if use_async else None
@@ -247,8 +260,10 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
         pfw.shard.init_landmarks(lm, 0.01, 0.1)
         say("weak-scaling filter created")
         for j in range(n_align):
-            pfw.step_async(8.0, 0.0, 4.0, Qs, 0.025, *obs[j % len(obs)], Rs, force_resample=False, prepared=prep[j % len(obs)])
+            pfw.step_async(0.0, 0.0, 4.0, Qs, 0.025, *obs[0], Rs, force_resample=False, prepared=prep[0])
         pfw.flush()
+        pfw.shard.set_pose(poses[0])
+        pfw.shard.init_landmarks(lm, 0.01, 0.1)
         pfw.shard.sync()
         fence()
         t0 = time.perf_counter()

@@ -408,6 +408,24 @@ __device__ __forceinline__ void block_sum6(double (&v)[6], double (*sh6)[6]) {
     }
 }
 
+// the first two of them only (same order of additions for those two: the same sums bit for bit)
+__device__ __forceinline__ void block_sum2(double (&v)[6], double (*sh6)[6]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v[i] += __shfl_xor(v[i], off);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) { sh6[wave][0] = v[0]; sh6[wave][1] = v[1]; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        double r = sh6[0][i];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r += sh6[w][i];
+        v[i] = r;
+    }
+}
+
 // ---- hand-over of the per-workgroup statistics inside ONE launch (auto mode) --------------------------------------
 // A workgroup's seven partials and a TAG fill one 64-byte line of `part`: tag = key(step) xor the (rotated) bit patterns
 // of the seven values, all eight stored write-through at agent scope and NOT waited for.  The launch's last workgroup
@@ -428,7 +446,10 @@ __device__ __forceinline__ unsigned long long part_hash(const double (&v)[7]) {
     return x;
 }
 
-template <typename T, bool SC1 = false>
+// POSE = false (the filter-step kernels, round 3): the weighted pose sums are left out (zeros in the record) -- nothing reads
+// them from a step (the mean pose is asked for through pf_stats_kernel), and they cost a double-precision sincos per
+// particle and four of the six block sums in a sweep that is bound by instruction issue as much as by memory.
+template <typename T, bool SC1 = false, bool POSE = true>
 __device__ __forceinline__ void block_weight_stats(T lw, T x, T y, T phi, bool valid, int relative, double* __restrict__ part,
                                                    long long seq = 0) {
     __shared__ double sh[16];
@@ -440,11 +461,16 @@ __device__ __forceinline__ void block_weight_stats(T lw, T x, T y, T phi, bool v
     double sn = (double)phi, cs = 1.0;
 #else
     const double e = valid ? exp((double)lw - shift) : 0.0;
-    double sn, cs;
-    sincos((double)phi, &sn, &cs);
+    double sn = 0.0, cs = 0.0;
+    if constexpr (POSE) sincos((double)phi, &sn, &cs);
 #endif
-    double v[6] = {e, e * e, e * (double)x, e * (double)y, e * sn, e * cs};
-    block_sum6(v, sh6);
+    double v[6] = {e, e * e, 0.0, 0.0, 0.0, 0.0};
+    if constexpr (POSE) {
+        v[2] = e * (double)x; v[3] = e * (double)y; v[4] = e * sn; v[5] = e * cs;
+        block_sum6(v, sh6);
+    } else {
+        block_sum2(v, sh6);
+    }
     if (threadIdx.x == 0) {
         double* o = part + (size_t)blockIdx.x * 8;
         const double w[7] = {m, v[0], v[1], v[2], v[3], v[4], v[5]};
@@ -810,7 +836,7 @@ __global__ __launch_bounds__(256) void pf_step_kernel(T* __restrict__ pose, T* l
     // (folding the partials in the last workgroup to finish behind an agent-scope release/acquire was tried: that is an L2
     //  write-back + invalidate on this multi-XCD part and doubled the kernel's time; here a 1-workgroup fold kernel
     //  follows, the auto mode's kernel uses write-through partials instead: pf_auto_step_kernel)
-    if (STATS) block_weight_stats<T>(lw, x, y, phi, valid, 1, part);
+    if (STATS) block_weight_stats<T, false, false>(lw, x, y, phi, valid, 1, part);
 }
 
 // One particle's FastSLAM-2.0 step (see pf_proposal_kernel).  Shared by the legacy kernel and the auto mode's kernel.
@@ -966,7 +992,7 @@ __global__ __launch_bounds__(256) void pf_proposal_kernel(T* __restrict__ pose, 
     T xn, yn, pn, lw;
     proposal_core<T>(pose, lm0, lm1, tabs, logw, n, first, step, seed, V, G, wheelbase, lq00, lq10, lq11, dt, s_obs, s_ids, s_meta, m,
                      R00, R10, R01, R11, pend, p, valid, xn, yn, pn, lw);
-    block_weight_stats<T>(lw, xn, yn, pn, valid, 1, part);
+    block_weight_stats<T, false, false>(lw, xn, yn, pn, valid, 1, part);
 }
 
 // ---- N4: unknown correspondences --------------------------------------------------------------------
@@ -1445,14 +1471,13 @@ static_assert(sizeof(PfAutoArgs) <= 4096, "kernel argument segment");
 // The planning of pf_stage on the device: observation i of landmark l = ids[i] - 1 gets its code (landmark, first
 // sighting / repeat of a first sighting) and its meta word (where the record is read and written) from the landmark's
 // state word; a repeat inside the call sees the state its first occurrence leaves behind.
-template <typename IdPtr>
-__device__ __forceinline__ void plan_obs(IdPtr ids, const int32_t* __restrict__ lmstate, int m, int32_t* s_l,
+// (l, st: thread i < m holds observation i's landmark and its state word, loaded by the caller ahead of time)
+__device__ __forceinline__ void plan_obs(int l_mine, int32_t st_mine, int m, int32_t* s_l,
                                          int32_t* s_st, int32_t* s_ids, int32_t* s_meta, int32_t* s_first) {
     const int tid = threadIdx.x;
     if (tid < m) {
-        const int l = ids[tid] - 1;
-        s_l[tid] = l;
-        s_st[tid] = lmstate[l];
+        s_l[tid] = l_mine;
+        s_st[tid] = st_mine;
     }
     __syncthreads();
     if (tid < m) {
@@ -1479,20 +1504,21 @@ __device__ __forceinline__ void plan_obs(IdPtr ids, const int32_t* __restrict__ 
     __syncthreads();
 }
 
-// six sums at once: one LDS exchange and one barrier pair for all of them (256 threads); the result reaches every thread
+// the first NS of six sums at once: one LDS exchange and one barrier pair for all of them (256 threads); the result reaches every thread
+template <int NS = 6>
 __device__ __forceinline__ void block_reduce6(double (&v)[6], double (*sh6)[6]) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < NS; ++i)
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) v[i] += __shfl_xor(v[i], off);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     __syncthreads();
     if (lane == 0)
 #pragma unroll
-        for (int i = 0; i < 6; ++i) sh6[wave][i] = v[i];
+        for (int i = 0; i < NS; ++i) sh6[wave][i] = v[i];
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 6; ++i) v[i] = sh6[0][i] + sh6[1][i] + sh6[2][i] + sh6[3][i];
+    for (int i = 0; i < NS; ++i) v[i] = sh6[0][i] + sh6[1][i] + sh6[2][i] + sh6[3][i];
 }
 
 // One lane writes a step's outcome to the host's mirror (pinned memory).
@@ -1580,14 +1606,13 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
         m = block_reduce(m, sh, true);
         const double Mn = fmax(M, m);
         const double fo = M == -__builtin_inf() ? 0.0 : exp(M - Mn);              // rescale what earlier passes summed
-        acc[0] *= fo; acc[1] *= fo * fo; acc[2] *= fo; acc[3] *= fo; acc[4] *= fo; acc[5] *= fo;
+        acc[0] *= fo; acc[1] *= fo * fo;
         M = Mn;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const double f = qv(u, 0) == -__builtin_inf() ? 0.0 : exp(qv(u, 0) - M);
             acc[0] += qv(u, 1) * f;
-            acc[1] += qv(u, 2) * f * f;
-            acc[2] += qv(u, 3) * f; acc[3] += qv(u, 4) * f; acc[4] += qv(u, 5) * f; acc[5] += qv(u, 6) * f;
+            acc[1] += qv(u, 2) * f * f;               // (the pose sums of a step's lines are zeros: block_weight_stats<POSE = false>)
         }
     }
     // ---- this step's state transitions (what pf_stage does on the host): one thread per observation; the state word
@@ -1604,7 +1629,7 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
         }
         a.lmstate[s_l[tid]] = LS_SEEN | ((tab ? (rb ^ 1) : rb) ? LS_BUF : 0);
     }
-    block_reduce6(acc, s_r6);
+    block_reduce6<2>(acc, s_r6);
     if (tid == 0) {
         ctl->stamps[2] = wall_clock64();
         double gM = M, gs1 = acc[0], gs2 = acc[1];
@@ -1698,8 +1723,7 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
         const int outcome = s_i[1];
         if (!s_i[3]) {                     // (a failed hand-over / exchange: the numbers are partial and are not recorded)
             ctl->stats[0] = s_g[0]; ctl->stats[1] = s_g[1]; ctl->stats[2] = s_g[2];
-            // (weighted pose sums relative to the LOCAL maximum: shard-local, summed over the ranks by the caller)
-            ctl->stats[3] = acc[2]; ctl->stats[4] = acc[3]; ctl->stats[5] = acc[4]; ctl->stats[6] = acc[5];
+            ctl->stats[3] = ctl->stats[4] = ctl->stats[5] = ctl->stats[6] = 0.0;      // (not formed by a step: slam_pf_mean_pose_sums)
             ctl->stats[7] = s_g[4];
             ctl->shift_scan = s_g[3];
             ctl->gmax_norm = s_g[5];
@@ -1742,6 +1766,16 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void pf_auto_step_kern
 #if defined(SLAMHIP_EXPERIMENTS) && defined(PF_EXP_STAMPS)
     if (blockIdx.x == 0 && threadIdx.x == 0) g_xs[7] = wall_clock64();
 #endif
+    // the observed landmarks' state words are requested FIRST (their addresses need the kernel arguments only): the plan,
+    // and with it the first record requests, then waits for one round trip (control block and state words together), not two
+    typedef const __attribute__((address_space(4))) PfAutoArgs* KargPtr0;
+    const KargPtr0 ka0 = (KargPtr0)__builtin_amdgcn_kernarg_segment_ptr();
+    int l_pre = 0;
+    int32_t st_pre = 0;
+    if ((int)threadIdx.x < a.m) {
+        l_pre = ka0->ids[threadIdx.x] - 1;
+        st_pre = a.lmstate[l_pre];
+    }
     // the control words this step needs, in one go (one cache line, one round trip)
     const long long halted = ctl->halt_seq;
     const int pcur = ctl->pcur, tside = ctl->tside, lwcur = ctl->lwcur;
@@ -1775,7 +1809,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void pf_auto_step_kern
         lw = logw[p];
         normals2<T>((uint64_t)(a.first + p), a.step, STREAM_PREDICT, a.seed, e1, e2);
     }
-    plan_obs(&ka->ids[0], a.lmstate, m, s_l, s_st, s_ids, s_meta, s_first);
+    plan_obs(l_pre, st_pre, m, s_l, s_st, s_ids, s_meta, s_first);
     PF_XS(2);
     if (PROPOSAL)
         proposal_core<T, SH>(pose, (T*)a.lm0, (T*)a.lm1, tabs, logw, n, a.first, a.step, a.seed, (T)a.V, (T)a.G, (T)a.wheelbase, (T)a.a0,
@@ -1787,7 +1821,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void pf_auto_step_kern
                                      (T)a.R11, pend, p, valid, x, y, phi, lw, e1, e2, sc);
     PF_XS(4);
     PF_WG(1);
-    block_weight_stats<T, true>(lw, x, y, phi, valid, 1, a.part, a.seq);          // a tagged line, not waited for
+    block_weight_stats<T, true, false>(lw, x, y, phi, valid, 1, a.part, a.seq);   // a tagged line, not waited for
     PF_XS(5);
     PF_WG(2);
     // the workgroup with the highest index collects the lines.  The wait cannot deadlock because NO other workgroup waits
