@@ -84,7 +84,9 @@ int slam_ekf_destroy(slam_ekf_t h);
 int slam_ekf_set_state(slam_ekf_t h, const void* x, const void* P, int n, int ldP);
 /* Same, from DEVICE buffers on the handle's device (stream-ordered D2D copy). */
 int slam_ekf_set_state_device(slam_ekf_t h, const void* d_x, const void* d_P, int n, int ldP);
-/* Download; either pointer may be NULL.  Reads of state.x / state.cov. */
+/* Download; either pointer may be NULL.  Reads of state.x / state.cov.
+ * Peak device memory of set_state (host source) / get_state: the state itself plus a staging buffer of at most
+ * max(256 MiB, 128 columns) -- the matrix is repacked band by band, never through a second n x n copy. */
 int slam_ekf_get_state(slam_ekf_t h, void* x, void* P, int n, int ldP);
 /* state.cov[r0+1 : r0+nr, c0+1 : c0+nc] (0-based r0, c0 here) into a column-major host buffer of the handle's
  * dtype with leading dimension ld_out >= nr, and diag(state.cov) (n values): the way to look at parts of a

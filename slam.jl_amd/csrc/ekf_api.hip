@@ -320,6 +320,15 @@ extern "C" int slam_ekf_create(slam_ekf_t* out, int dtype, int max_landmarks, in
 }
 
 // ---- state I/O -------------------------------------------------------------------
+// columns per band of the staged state transfers: a multiple of the tile edge, n x W elements <= 256 MiB
+static int state_band_columns(const slam_ekf* h, int n) {
+    const size_t budget = (size_t)256 << 20;
+    size_t w = budget / (h->esz * (size_t)n) / SLAM_TILE * SLAM_TILE;
+    if (w < SLAM_TILE) w = SLAM_TILE;
+    if (w > (size_t)h->npad) w = (size_t)h->npad;
+    return (int)w;
+}
+
 static int set_state_impl(slam_ekf* h, const void* x, const void* P, int n, int ldP, hipMemcpyKind kind) {
     ARG_CHECK(h != nullptr, "null handle");
     ARG_CHECK(x != nullptr && P != nullptr, "x / P is null");
@@ -336,28 +345,32 @@ static int set_state_impl(slam_ekf* h, const void* x, const void* P, int n, int 
         if (rc) return rc;
     }
     HIP_TRY(hipMemcpyAsync(h->x, x, h->esz * (size_t)n, kind, h->stream));
-    // the caller's matrix is column-major (Julia order); the state is tile-major: a device-side repack.  A host source
-    // is staged through a temporary column-major device buffer.
-    void* d_tmp = nullptr;
-    const void* d_src = P;
-    int lds = ldP;
+    // the caller's matrix is column-major (Julia order); the state is tile-major: a device-side repack.  A host source is
+    // staged band by band through a BOUNDED column-major device buffer (<= 256 MiB: the 80 GB matrix of N = 50k fp64 must
+    // not need another 80 GB of scratch), a device source is packed where it lies.
+    int rc = SLAM_OK;
+    hipError_t es = hipSuccess;
     if (kind == hipMemcpyHostToDevice) {
-        HIP_TRY(hipMalloc(&d_tmp, h->esz * (size_t)n * n));
-        const hipError_t e = hipMemcpy2DAsync(d_tmp, h->esz * (size_t)n, P, h->esz * (size_t)ldP, h->esz * (size_t)n, (size_t)n, kind, h->stream);
-        if (e != hipSuccess) {
-            (void)hipFree(d_tmp);
-            slam_set_error("upload of the covariance failed: %s", hipGetErrorString(e));
-            return SLAM_E_HIP;
+        const int W = state_band_columns(h, n);
+        void* d_tmp = nullptr;
+        HIP_TRY(hipMalloc(&d_tmp, h->esz * (size_t)n * W));
+        for (int c = 0; c < h->npad && rc == SLAM_OK && es == hipSuccess; c += W) {
+            const int w = c + W <= h->npad ? W : h->npad - c;
+            const int wn = n - c < 0 ? 0 : (n - c < w ? n - c : w);           // real columns of this band (the rest is padding)
+            if (wn > 0)
+                es = hipMemcpy2DAsync(d_tmp, h->esz * (size_t)n, (const char*)P + h->esz * (size_t)c * ldP, h->esz * (size_t)ldP,
+                                      h->esz * (size_t)n, (size_t)wn, kind, h->stream);
+            if (es == hipSuccess) rc = launch_pack(h, d_tmp, n, n, c, w);
+            if (es == hipSuccess && rc == SLAM_OK) es = hipStreamSynchronize(h->stream);   // the staging buffer is reused
         }
-        d_src = d_tmp;
-        lds = n;
+        (void)hipFree(d_tmp);
+    } else {
+        rc = launch_pack(h, P, ldP, n, 0, h->npad);
+        es = hipStreamSynchronize(h->stream);
     }
-    int rc = launch_pack(h, d_src, lds, n);
-    const hipError_t es = hipStreamSynchronize(h->stream);
-    if (d_tmp) (void)hipFree(d_tmp);
     if (rc) return rc;
     if (es != hipSuccess) {
-        slam_set_error("hipStreamSynchronize failed in set_state: %s", hipGetErrorString(es));
+        slam_set_error("upload of the state failed: %s", hipGetErrorString(es));
         return SLAM_E_HIP;
     }
     h->N = N;
@@ -382,26 +395,28 @@ extern "C" int slam_ekf_get_state(slam_ekf_t h, void* x, void* P, int n, int ldP
     ARG_CHECK(P == nullptr || ldP >= n, "ldP < n");
     HIP_TRY(hipSetDevice(h->device));
     if (x) HIP_TRY(hipMemcpyAsync(x, h->x, h->esz * (size_t)n, hipMemcpyDeviceToHost, h->stream));
-    void* d_tmp = nullptr;
     int rc = SLAM_OK;
+    hipError_t es = hipSuccess;
     if (P) {
-        // the full symmetric matrix in the caller's column-major order: unpacked on the device from the stored triangle
-        HIP_TRY(hipMalloc(&d_tmp, h->esz * (size_t)n * n));
-        rc = launch_unpack(h, d_tmp, n, n);
-        if (rc == SLAM_OK) {
-            const hipError_t e = hipMemcpy2DAsync(P, h->esz * (size_t)ldP, d_tmp, h->esz * (size_t)n, h->esz * (size_t)n, (size_t)n,
-                                                  hipMemcpyDeviceToHost, h->stream);
-            if (e != hipSuccess) {
-                slam_set_error("download of the covariance failed: %s", hipGetErrorString(e));
-                rc = SLAM_E_HIP;
-            }
+        // the full symmetric matrix in the caller's column-major order: unpacked on the device from the stored triangle,
+        // band by band through a bounded staging buffer (<= 256 MiB)
+        const int W = state_band_columns(h, n);
+        void* d_tmp = nullptr;
+        HIP_TRY(hipMalloc(&d_tmp, h->esz * (size_t)n * W));
+        for (int c = 0; c < n && rc == SLAM_OK && es == hipSuccess; c += W) {
+            const int w = c + W <= n ? W : n - c;
+            rc = launch_unpack(h, d_tmp, n, n, c, w);
+            if (rc == SLAM_OK)
+                es = hipMemcpy2DAsync((char*)P + h->esz * (size_t)c * ldP, h->esz * (size_t)ldP, d_tmp, h->esz * (size_t)n,
+                                      h->esz * (size_t)n, (size_t)w, hipMemcpyDeviceToHost, h->stream);
+            if (rc == SLAM_OK && es == hipSuccess) es = hipStreamSynchronize(h->stream);   // the staging buffer is reused
         }
+        (void)hipFree(d_tmp);
     }
-    const hipError_t es = hipStreamSynchronize(h->stream);
-    if (d_tmp) (void)hipFree(d_tmp);
+    if (es == hipSuccess) es = hipStreamSynchronize(h->stream);
     if (rc) return rc;
     if (es != hipSuccess) {
-        slam_set_error("hipStreamSynchronize failed in get_state: %s", hipGetErrorString(es));
+        slam_set_error("download of the state failed: %s", hipGetErrorString(es));
         return SLAM_E_HIP;
     }
     return SLAM_OK;

@@ -101,27 +101,32 @@ __global__ __launch_bounds__(256) void augment_kernel(T* __restrict__ x, T* __re
 // Column-major <-> tile-major.  pack: every element of every stored tile (rows / columns >= n: the zero padding) from a
 // column-major n x n source; a workgroup owns 32 x 32 elements of one tile (consecutive threads walk rows: coalesced on
 // both sides).  unpack: the full symmetric n x n matrix, each element from whichever tile stores it.
+// Both work on a BAND of columns [cf, cf + 32 gridDim.y): src / dst hold that band only (column cf first), so the state of
+// a large map is packed / unpacked through a bounded staging buffer (slam_ekf_set_state / get_state).
 template <typename T>
-__global__ __launch_bounds__(256) void pack_kernel(T* __restrict__ P, int ld, int tlog, const T* __restrict__ src, int lds, int n) {
-    const int r0 = 32 * blockIdx.x, c0 = 32 * blockIdx.y;
+__global__ __launch_bounds__(256) void pack_kernel(T* __restrict__ P, int ld, int tlog, const T* __restrict__ src, int lds, int n,
+                                                    int cf) {
+    const int r0 = 32 * blockIdx.x, c0 = cf + 32 * blockIdx.y;
     if ((r0 >> tlog) < (c0 >> tlog)) return;                           // (32 divides the tile edge)
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int j = ty; j < 32; j += 8) {
         const int r = r0 + tx, c = c0 + j;
-        P[p_off(ld, tlog, r, c)] = (r < n && c < n) ? src[(size_t)c * lds + r] : (T)0;
+        P[p_off(ld, tlog, r, c)] = (r < n && c < n) ? src[(size_t)(c - cf) * lds + r] : (T)0;
     }
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void unpack_kernel(const T* __restrict__ P, int ld, int tlog, T* __restrict__ dst, int ldd, int n) {
+__global__ __launch_bounds__(256) void unpack_kernel(const T* __restrict__ P, int ld, int tlog, T* __restrict__ dst_band, int ldd,
+                                                      int n, int cf) {
     __shared__ T sh[32][33];
-    const int r0 = 32 * blockIdx.x, c0 = 32 * blockIdx.y;
+    T* __restrict__ dst = dst_band;
+    const int r0 = 32 * blockIdx.x, c0 = cf + 32 * blockIdx.y;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const bool lower = (r0 >> tlog) >= (c0 >> tlog);
     if (lower) {
         for (int j = ty; j < 32; j += 8) {
             const int r = r0 + tx, c = c0 + j;
-            if (r < n && c < n) dst[(size_t)c * ldd + r] = P[p_off(ld, tlog, r, c)];
+            if (r < n && c < n) dst[(size_t)(c - cf) * ldd + r] = P[p_off(ld, tlog, r, c)];
         }
         return;
     }
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256) void unpack_kernel(const T* __restrict__ P, in
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
         const int r = r0 + tx, c = c0 + j;
-        if (r < n && c < n) dst[(size_t)c * ldd + r] = sh[tx][j];      // P[r, c] = P[c, r]
+        if (r < n && c < n) dst[(size_t)(c - cf) * ldd + r] = sh[tx][j];      // P[r, c] = P[c, r]
     }
 }
 
@@ -206,22 +211,25 @@ int launch_ellipses(slam_ekf* h, double* d_out) {
     return SLAM_OK;
 }
 
-int launch_pack(slam_ekf* h, const void* d_src, int lds, int n) {
-    const int nb = h->npad / 32;
+// columns [cf, cf + ncols) of the tile-major state (cf, ncols multiples of 32; up to npad: the zero padding is written too)
+// from d_src, which holds that band column-major with leading dimension lds
+int launch_pack(slam_ekf* h, const void* d_src, int lds, int n, int cf, int ncols) {
+    const dim3 grid(h->npad / 32, (ncols + 31) / 32);
     if (h->dtype == SLAM_F32)
-        hipLaunchKernelGGL(pack_kernel<float>, dim3(nb, nb), dim3(256), 0, h->stream, (float*)h->P, h->ld, 7, (const float*)d_src, lds, n);
+        hipLaunchKernelGGL(pack_kernel<float>, grid, dim3(256), 0, h->stream, (float*)h->P, h->ld, 7, (const float*)d_src, lds, n, cf);
     else
-        hipLaunchKernelGGL(pack_kernel<double>, dim3(nb, nb), dim3(256), 0, h->stream, (double*)h->P, h->ld, 6, (const double*)d_src, lds, n);
+        hipLaunchKernelGGL(pack_kernel<double>, grid, dim3(256), 0, h->stream, (double*)h->P, h->ld, 6, (const double*)d_src, lds, n, cf);
     HIP_TRY(hipGetLastError());
     return SLAM_OK;
 }
 
-int launch_unpack(slam_ekf* h, void* d_dst, int ldd, int n) {
-    const int nb = (n + 31) / 32;
+// columns [cf, cf + ncols) of the full symmetric matrix into d_dst (that band, column-major, leading dimension ldd)
+int launch_unpack(slam_ekf* h, void* d_dst, int ldd, int n, int cf, int ncols) {
+    const dim3 grid((n + 31) / 32, (ncols + 31) / 32);
     if (h->dtype == SLAM_F32)
-        hipLaunchKernelGGL(unpack_kernel<float>, dim3(nb, nb), dim3(256), 0, h->stream, (const float*)h->P, h->ld, 7, (float*)d_dst, ldd, n);
+        hipLaunchKernelGGL(unpack_kernel<float>, grid, dim3(256), 0, h->stream, (const float*)h->P, h->ld, 7, (float*)d_dst, ldd, n, cf);
     else
-        hipLaunchKernelGGL(unpack_kernel<double>, dim3(nb, nb), dim3(256), 0, h->stream, (const double*)h->P, h->ld, 6, (double*)d_dst, ldd, n);
+        hipLaunchKernelGGL(unpack_kernel<double>, grid, dim3(256), 0, h->stream, (const double*)h->P, h->ld, 6, (double*)d_dst, ldd, n, cf);
     HIP_TRY(hipGetLastError());
     return SLAM_OK;
 }
