@@ -500,6 +500,22 @@ def test_observe_with_many_observations(pkg, dtype):
     st.close()
 
 
+def test_state_upload_and_download_in_bands(pkg):
+    """slam_ekf_set_state / get_state repack the covariance band by band through a staging buffer of at most 256 MiB: a
+    state whose dense matrix (538 MB in fp64) needs three bands, with a ragged last one, must come back bit for bit -- the full symmetric matrix from the stored triangle -- and read the same piecewise."""
+    rng = np.random.default_rng(12)
+    N = 4100
+    n = 3 + 2 * N
+    x, P = random_state(rng, N, rank=3)
+    st = pkg.EKFSlamState(x, P, dtype="f64", max_landmarks=N + 60)       # (capacity above N: the padding columns are packed too)
+    xg, Pg = st.download()
+    assert np.array_equal(xg, x) and np.array_equal(Pg, P)
+    assert np.array_equal(st.get_block(n - 300, 4000, 300, 200), P[n - 300:, 4000:4200])
+    assert np.array_equal(st.get_block(100, n - 77, 50, 77), P[100:150, n - 77:])
+    assert np.array_equal(st.diag(), np.diag(P))
+    st.close()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_joseph_form(pkg, dtype):
     rng = np.random.default_rng(5)

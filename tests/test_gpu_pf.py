@@ -912,6 +912,23 @@ def test_auto_mode_two_ranks_without_peers_halts_and_resumes(pkg, tmp_path):
     assert np.allclose(a["neff"], s["neff"], rtol=1e-10)
 
 
+def test_sharded_filter_above_the_ipc_limit_falls_back(pkg):
+    """hipIpcOpenMemHandle of an allocation above 2 GiB hangs on this runtime (tools/ipc_gen_test.py found it): a sharded
+    filter whose landmark buffer is 2.5 GiB per rank (BASELINE config 4 PER GPU, the weak-scaling shape) must REFUSE the
+    peer attach (SLAM_E_CAPACITY, before anything is opened), take the halting flow on every rank, and come up and go
+    down cleanly; one just below the limit attaches its peers."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode, want in (("big:524288", "peers False"), ("big:400000", "peers True")):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "ipc_gen_test.py"), mode], capture_output=True, text=True,
+                           timeout=120)
+        out = r.stdout + r.stderr
+        assert "exit codes [0, 0]" in out and "HUNG" not in out, out[-3000:]
+        assert out.count(want) == 2, out[-3000:]
+
+
 def test_rccl_collectives_of_the_sharded_flow_on_a_one_rank_group(pkg, tmp_path):
     """The `nccl` (= RCCL) branch of the sharded driver has no multi-GPU box to run on here; a ONE-rank RCCL process group
     does exist on a one-GPU box: the filter is driven through FastSLAM with the multi-rank resampling flow forced
