@@ -94,6 +94,11 @@ int slam_ekf_get_state(slam_ekf_t h, void* x, void* P, int n, int ldP);
  * sim/browser/wsserver.jl:36).  Elements come from the symmetric view, whichever triangle holds them. */
 int slam_ekf_get_block(slam_ekf_t h, int r0, int c0, int nr, int nc, void* out, int ld_out);
 int slam_ekf_get_diag(slam_ekf_t h, void* out);
+/* The landmarks' 2 x 2 covariance blocks (what compute_association, src/data-association.jl:59, and the ellipses of
+ * sim/browser/wsserver.jl:72-85 need of state.cov), packed: out[0][j] = P[f, f], out[1][j] = P[f+1, f], out[2][j] =
+ * P[f+1, f+1], f = 3 + 2 j; three rows of N values in the handle's dtype.  Read from the side array the gating sweep
+ * streams instead of gathering the matrix's diagonal (kept by every writer of these entries). */
+int slam_ekf_get_landmark_blocks(slam_ekf_t h, void* out);
 int slam_ekf_get_pose(slam_ekf_t h, double pose[3]);       /* state.x[1:3]          */
 int slam_ekf_num_landmarks(slam_ekf_t h, int* N);          /* (length(x)-3)/2       */
 int slam_ekf_dtype(slam_ekf_t h, int* dtype);

@@ -14,7 +14,7 @@ module SLAMHip
 
 export SlamState, EKFSlamState, set_state!, predict, update, add_features, associate,
        compute_association, predict_observation, mpi_to_pi,
-       ekf_predict!, ekf_update!, augment!, observe!, cov_block, cov_diag, feature_ellipses, vehicle_ellipse,
+       ekf_predict!, ekf_update!, augment!, observe!, cov_block, cov_diag, landmark_blocks, feature_ellipses, vehicle_ellipse,
        PFSlamState, set_pose!, init_landmarks!, pf_predict!, update_known!, step!, step_async!, flush!,
        resample!, mean_pose, weights, particles, peer_blob, attach_peers!, peer_selftest, detach_peers!, comm_info
 
@@ -183,6 +183,14 @@ function cov_diag(s::EKFSlamState{T}) where {T}
     out = Vector{T}(undef, length(s))
     check(ccall((:slam_ekf_get_diag, libslamhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), handle(s), out))
     out
+end
+
+"The landmarks' 2 x 2 covariance blocks, 3 x N: [P[f,f]; P[f+1,f]; P[f+1,f+1]] per landmark (slam_ekf_get_landmark_blocks)."
+function landmark_blocks(s::EKFSlamState{T}) where {T}
+    N = div(length(s) - 3, 2)
+    out = Matrix{T}(undef, N, 3)                     # the library writes three rows of N values
+    check(ccall((:slam_ekf_get_landmark_blocks, libslamhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), handle(s), out))
+    permutedims(out)
 end
 
 "feature_ellipses(x, cov) of the browser monitor (sim/browser/wsserver.jl:72-85): 5 x N [cx; cy; rx; ry; phi], on the device."

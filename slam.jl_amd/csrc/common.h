@@ -90,6 +90,7 @@ struct slam_ekf {
     size_t esz;       // element size
     void* x;          // [ncap]
     void* P;          // tile-major, block lower (device_math.h): T(T+1)/2 tiles of E x E, T = npad / E; rows/cols >= n are zero padding
+    void* Pside;      // [3][npad / 2]: the landmarks' 2 x 2 diagonal blocks, packed (device_math.h: side_note)
     hipStream_t stream;
     double* PHtS;          // compact panel [3 + kcap][kcap]: the rows of P*H' the factorisation needs
     hipEvent_t stage_ev;   // marks the last H2D copy out of the pinned staging buffers

@@ -76,3 +76,18 @@ template <typename T>
 __device__ inline void p_store(T* __restrict__ P, int ld, int tile_log2, int r, int c, T v) {
     if ((r >> tile_log2) >= (c >> tile_log2)) P[p_off(ld, tile_log2, r, c)] = v;
 }
+
+// ---- the landmarks' 2 x 2 diagonal blocks, packed (SURVEY 7 "hard parts") -------------------------------------------------
+// side[0][j] = P[f, f], side[1][j] = P[f+1, f], side[2][j] = P[f+1, f+1] with f = 3 + 2 j, three rows of side_n values each
+// in the state's dtype.  In the tile-major matrix these entries sit on the diagonals of the diagonal tiles, 129 elements
+// apart: every landmark of the gating sweep touched two 128-byte lines of its own for 12 useful bytes (6.5x the sweep's
+// algorithmic bytes).  The side array is kept by EVERY writer of those entries -- the state upload (pack_kernel),
+// add_features (augment_kernel) and the diagonal-tile epilogues of the down-dates -- through side_note(), and read by the
+// sweep (ekf_gate.hip) as three coalesced rows.  The matrix itself stays complete: every other reader uses P.
+template <typename T>
+__device__ __forceinline__ void side_note(T* __restrict__ side, int side_n, int r, int c, T v) {
+    if (c < 3) return;
+    const int o = c - 3, j = o >> 1;
+    if (r == c) side[(size_t)((o & 1) ? 2 : 0) * side_n + j] = v;
+    else if (r == c + 1 && !(o & 1)) side[(size_t)side_n + j] = v;
+}

@@ -214,7 +214,7 @@ extern "C" int slam_ekf_destroy(slam_ekf_t h) {
     for (auto& p : h->pairs) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto& p : h->free_pairs) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     free_update_workspace(h);
-    dev_free(h->x); dev_free(h->P); dev_free(h->tiles);
+    dev_free(h->x); dev_free(h->P); dev_free(h->Pside); dev_free(h->tiles);
     dev_free(h->obsbuf); dev_free(h->idfbuf); dev_free(h->d_assoc); dev_free(h->gate_part); dev_free(h->znbuf);
     dev_free(h->d_small); dev_free(h->d_status); dev_free(h->d_count); dev_free(h->d_pmax); dev_free(h->dd_claim);
     if (h->h_flag) (void)hipHostFree(h->h_flag);
@@ -244,6 +244,7 @@ static int create_impl(slam_ekf* h) {
         const int E = h->dtype == SLAM_F32 ? 128 : 64;
         const size_t T = (size_t)h->npad / E;
         if ((rc = dev_alloc_zero(&h->P, h->esz * (T * (T + 1) / 2) * E * E, h->stream))) return rc;
+        if ((rc = dev_alloc_zero(&h->Pside, h->esz * 3 * (size_t)(h->npad / 2), h->stream))) return rc;
     }
     if ((rc = dev_alloc_zero(&h->d_small, sizeof(double) * 64, h->stream))) return rc;
     if ((rc = dev_alloc_zero(&h->d_count, sizeof(int32_t) * 4, h->stream))) return rc;
@@ -281,7 +282,7 @@ extern "C" int slam_ekf_create(slam_ekf_t* out, int dtype, int max_landmarks, in
     h->npad = round_up(h->ncap, SLAM_TILE);
     h->ld = h->npad;                  // P is allocated in whole tiles: npad x npad, padding stays zero
     h->esz = dtype == SLAM_F32 ? 4 : 8;
-    h->x = h->P = nullptr;
+    h->x = h->P = h->Pside = nullptr;
     h->stream = nullptr;
     h->stage_ev = nullptr; h->stage_pending = 0;
     h->PHtS = nullptr;
@@ -459,6 +460,19 @@ extern "C" int slam_ekf_get_diag(slam_ekf_t h, void* out) {
     ARG_CHECK(h != nullptr && out != nullptr, "null argument");
     const int n = 3 + 2 * h->N;
     return get_gathered(h, 0, 0, n, 1, 1, out, n);
+}
+
+/* The landmarks' 2 x 2 covariance blocks, packed: out[0][j] = P[f, f], out[1][j] = P[f+1, f], out[2][j] = P[f+1, f+1]
+ * (f = 3 + 2 j, j = 0 .. N-1; three rows of N values in the handle's dtype) -- straight from the side array the gating
+ * sweep reads (device_math.h: side_note), which every writer of those entries keeps. */
+extern "C" int slam_ekf_get_landmark_blocks(slam_ekf_t h, void* out) {
+    ARG_CHECK(h != nullptr && out != nullptr, "null argument");
+    if (h->N == 0) return SLAM_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpy2DAsync(out, h->esz * (size_t)h->N, h->Pside, h->esz * (size_t)(h->npad / 2), h->esz * (size_t)h->N, 3,
+                             hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SLAM_OK;
 }
 
 extern "C" int slam_ekf_get_pose(slam_ekf_t h, double pose[3]) {
@@ -733,6 +747,24 @@ extern "C" int slam_ekf_observe(slam_ekf_t h, const double* z, int nz, const dou
 }
 
 // ---- stream / timing -----------------------------------------------------------------
+#ifdef SLAMHIP_EXPERIMENTS
+/* Experiments build only (tools/graph_observe.py): the observation step ENQUEUED and nothing else -- gating + compaction,
+ * then the update with the matched count read on the device -- without waiting for the decisions and without
+ * add_features, i.e. valid only for a workload in which no new feature arises.  It exists so that the six launches of a
+ * step can be captured into a hipGraph (a capture cannot contain the host's wait for the decisions). */
+extern "C" int slam_exp_observe_enqueue(slam_ekf_t h, const double* z, int nz, const double R[4], double gate1, double gate2) {
+    ARG_CHECK(h != nullptr && z != nullptr && nz > 0 && h->N > 0, "bad argument");
+    int rc = check_R(R);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    if ((rc = ensure_update_workspace(h, nz))) return rc;
+    if ((rc = ensure_obs_capacity(h, nz))) return rc;
+    h->obs_seq = h->obs_seq == 0x7fffffff ? 1 : h->obs_seq + 1;
+    if ((rc = launch_gate(h, nz, R, gate1, gate2, z, true))) return rc;
+    return launch_update(h, nz, R, SLAM_FORM_CHOLESKY, true);
+}
+#endif
+
 extern "C" int slam_ekf_set_async(slam_ekf_t h, int async_updates) {
     ARG_CHECK(h != nullptr, "null handle");
     h->async_updates = async_updates ? 1 : 0;

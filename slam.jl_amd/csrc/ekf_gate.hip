@@ -88,9 +88,11 @@ __device__ inline void pair_eval(const PairConst& pc, double z0, double z1, doub
     nd = nis + pc.logdet;
 }
 
+// side (may be null: the single-pair entry points read the matrix): the packed 2 x 2 diagonal blocks, three coalesced rows
 template <typename T>
 __device__ inline PairConst landmark_const(const T* __restrict__ x, const T* __restrict__ P, int ld, int tlog, int j0,
-                                           const double pose[3], const double* pvv, const double R[4]) {
+                                           const double pose[3], const double* pvv, const double R[4],
+                                           const T* __restrict__ side = nullptr, int side_n = 0) {
     const int f = 3 + 2 * j0;
     const double lx = (double)x[f], ly = (double)x[f + 1];
     const ObsModel om = obs_model(pose[0], pose[1], pose[2], lx, ly);
@@ -101,10 +103,16 @@ __device__ inline PairConst landmark_const(const T* __restrict__ x, const T* __r
         pfv[1][c] = (double)P[p_off(ld, tlog, f + 1, c)];
     }
     double pff[4];
-    pff[0] = (double)P[p_off(ld, tlog, f, f)];           // P[f][f]
-    pff[2] = (double)P[p_off(ld, tlog, f + 1, f)];       // P[f+1][f]  (lower: always stored)
+    if (side) {
+        pff[0] = (double)side[j0];
+        pff[2] = (double)side[(size_t)side_n + j0];
+        pff[3] = (double)side[(size_t)2 * side_n + j0];
+    } else {
+        pff[0] = (double)P[p_off(ld, tlog, f, f)];           // P[f][f]
+        pff[2] = (double)P[p_off(ld, tlog, f + 1, f)];       // P[f+1][f]  (lower: always stored)
+        pff[3] = (double)P[p_off(ld, tlog, f + 1, f + 1)];   // P[f+1][f+1]
+    }
     pff[1] = pff[2];                                     // P[f][f+1]  = its mirror (it may lie in a tile above the diagonal)
-    pff[3] = (double)P[p_off(ld, tlog, f + 1, f + 1)];   // P[f+1][f+1]
     return pair_const(om, pvv, pfv, pff, R);
 }
 
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(GATE_BLOCK * OBS_WAVES) void gate_kernel(GateObs za
                                                            int ld, int N, double* __restrict__ zdev, int nz, double R0,
                                                            double R1, double R2, double R3, double gate1, double gate2,
                                                            double* __restrict__ part, const double* __restrict__ pmax_ptr,
-                                                           int pregate, int tlog) {
+                                                           int pregate, int tlog, const T* __restrict__ side, int side_n) {
     extern __shared__ double smem[];
     double* zs = smem;                 // [nz][2]
     double* red = smem + 2 * nz;       // [nz][3]
@@ -198,7 +206,7 @@ __global__ __launch_bounds__(GATE_BLOCK * OBS_WAVES) void gate_kernel(GateObs za
         valid = need;
     }
     PairConst pc;
-    if (valid) pc = landmark_const(x, P, ld, tlog, j0, pose, pvv, R);
+    if (valid) pc = landmark_const(x, P, ld, tlog, j0, pose, pvv, R, side, side_n);
     // per-observation result of this wave, default "nothing in either gate"
     for (int i = tid; i < nz; i += NT) {
         red[3 * i] = INF;
@@ -424,11 +432,11 @@ int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gat
             if (h->dtype == SLAM_F32)
                 hipLaunchKernelGGL(gate_kernel<float>, dim3(nblocks), dim3(GATE_BLOCK * OBS_WAVES), shmem, h->stream, zarg,
                                    (const float*)h->x, (const float*)h->P, h->ld, h->N, zc, cz, R[0], R[1], R[2], R[3],
-                                   gate1, gate2, h->gate_part, (const double*)h->d_pmax, pregate, 7);
+                                   gate1, gate2, h->gate_part, (const double*)h->d_pmax, pregate, 7, (const float*)h->Pside, h->npad / 2);
             else
                 hipLaunchKernelGGL(gate_kernel<double>, dim3(nblocks), dim3(GATE_BLOCK * OBS_WAVES), shmem, h->stream, zarg,
                                    (const double*)h->x, (const double*)h->P, h->ld, h->N, zc, cz, R[0], R[1], R[2], R[3],
-                                   gate1, gate2, h->gate_part, (const double*)h->d_pmax, pregate, 6);
+                                   gate1, gate2, h->gate_part, (const double*)h->d_pmax, pregate, 6, (const double*)h->Pside, h->npad / 2);
         }
         HIP_TRY(hipGetLastError());
         {

@@ -22,7 +22,8 @@ namespace {
 template <typename T>
 __global__ __launch_bounds__(256) void augment_kernel(T* __restrict__ x, T* __restrict__ P, int ld, int n0,
                                                        const double* __restrict__ zn, int nn, double R0, double R1,
-                                                       double R2, double R3, unsigned long long* __restrict__ pmax, int tlog) {
+                                                       double R2, double R3, unsigned long long* __restrict__ pmax, int tlog,
+                                                       T* __restrict__ side, int side_n) {
     const double xv = (double)x[0], yv = (double)x[1], phi = (double)x[2];   // ekf.jl:88 (phi fixed for the call)
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < n0) {
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(256) void augment_kernel(T* __restrict__ x, T* __re
                     const double val = (GP[r][0] * Ga[cc][0] + GP[r][1] * Ga[cc][1] + GP[r][2] * Ga[cc][2]) +
                                        (GR[r][0] * Gz[cc][0] + GR[r][1] * Gz[cc][1]);
                     p_store(P, ld, tlog, fa + r, fa + cc, (T)val);      // (the entry above the diagonal exists inside a diagonal tile only)
+                    if (r >= cc) side_note(side, side_n, fa + r, fa + cc, (T)val);
                     // the new landmark's variances enter the pre-gate's bound (ekf_gate.hip): bit pattern of a
                     // non-negative double orders like the integer; anything else disables the pre-gate (+inf)
                     if (r == cc) {
@@ -105,13 +107,15 @@ __global__ __launch_bounds__(256) void augment_kernel(T* __restrict__ x, T* __re
 // a large map is packed / unpacked through a bounded staging buffer (slam_ekf_set_state / get_state).
 template <typename T>
 __global__ __launch_bounds__(256) void pack_kernel(T* __restrict__ P, int ld, int tlog, const T* __restrict__ src, int lds, int n,
-                                                    int cf) {
+                                                    int cf, T* __restrict__ side, int side_n) {
     const int r0 = 32 * blockIdx.x, c0 = cf + 32 * blockIdx.y;
     if ((r0 >> tlog) < (c0 >> tlog)) return;                           // (32 divides the tile edge)
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int j = ty; j < 32; j += 8) {
         const int r = r0 + tx, c = c0 + j;
-        P[p_off(ld, tlog, r, c)] = (r < n && c < n) ? src[(size_t)(c - cf) * lds + r] : (T)0;
+        const T v = (r < n && c < n) ? src[(size_t)(c - cf) * lds + r] : (T)0;
+        P[p_off(ld, tlog, r, c)] = v;
+        side_note(side, side_n, r, c, v);                              // the packed 2 x 2 diagonal blocks follow the upload
     }
 }
 
@@ -216,9 +220,11 @@ int launch_ellipses(slam_ekf* h, double* d_out) {
 int launch_pack(slam_ekf* h, const void* d_src, int lds, int n, int cf, int ncols) {
     const dim3 grid(h->npad / 32, (ncols + 31) / 32);
     if (h->dtype == SLAM_F32)
-        hipLaunchKernelGGL(pack_kernel<float>, grid, dim3(256), 0, h->stream, (float*)h->P, h->ld, 7, (const float*)d_src, lds, n, cf);
+        hipLaunchKernelGGL(pack_kernel<float>, grid, dim3(256), 0, h->stream, (float*)h->P, h->ld, 7, (const float*)d_src, lds, n, cf,
+                           (float*)h->Pside, h->npad / 2);
     else
-        hipLaunchKernelGGL(pack_kernel<double>, grid, dim3(256), 0, h->stream, (double*)h->P, h->ld, 6, (const double*)d_src, lds, n, cf);
+        hipLaunchKernelGGL(pack_kernel<double>, grid, dim3(256), 0, h->stream, (double*)h->P, h->ld, 6, (const double*)d_src, lds, n, cf,
+                           (double*)h->Pside, h->npad / 2);
     HIP_TRY(hipGetLastError());
     return SLAM_OK;
 }
@@ -315,10 +321,12 @@ int launch_augment(slam_ekf* h, int nn, const double R[4], const double* zn_dev)
         KTimer t(h, SLAM_K_AUGMENT);
         if (h->dtype == SLAM_F32)
             hipLaunchKernelGGL(augment_kernel<float>, dim3(blocks), dim3(256), 0, h->stream, (float*)h->x, (float*)h->P,
-                               h->ld, n0, zn_dev, nn, R[0], R[1], R[2], R[3], (unsigned long long*)h->d_pmax, 7);
+                               h->ld, n0, zn_dev, nn, R[0], R[1], R[2], R[3], (unsigned long long*)h->d_pmax, 7, (float*)h->Pside,
+                               h->npad / 2);
         else
             hipLaunchKernelGGL(augment_kernel<double>, dim3(blocks), dim3(256), 0, h->stream, (double*)h->x,
-                               (double*)h->P, h->ld, n0, zn_dev, nn, R[0], R[1], R[2], R[3], (unsigned long long*)h->d_pmax, 6);
+                               (double*)h->P, h->ld, n0, zn_dev, nn, R[0], R[1], R[2], R[3], (unsigned long long*)h->d_pmax, 6,
+                               (double*)h->Pside, h->npad / 2);
     }
     HIP_TRY(hipGetLastError());
     return SLAM_OK;

@@ -79,6 +79,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct DdCtxP {      // where P lives (first members of DdCtx)
     float* P;
     int ld;
+    float* side;     // the packed 2 x 2 diagonal blocks (device_math.h: side_note), kept by the diagonal tiles' epilogue
+    int side_n;
 };
 
 // P is TILE-MAJOR (device_math.h): tile (I, J) is one contiguous 64 KiB column-major block, the tiles of a column band
@@ -141,13 +143,20 @@ __device__ __forceinline__ void store_p_tile(const DdCtx& c, int R0, int C0, con
             if (dbg & 1) continue;                                 // experiment: no stores (P stays as it is)
             if (!diag) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rs, voff, soff, 0);
+                if (R0 == C0 + TILE) {          // the tile below a diagonal tile: P[f+1, f] of the landmark straddling the boundary
+                    const float vs[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) side_note(c.side, c.side_n, rowb + 4 * q + t, colb + col, vs[t]);
+                }
             } else {
                 // (scalar copies: bit-casting val[t] directly made hipcc 7.2 store element 0 four times)
                 const float ve[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                    if (rowb + 4 * q + t >= colb + col)
+                    if (rowb + 4 * q + t >= colb + col) {
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ve[t]), rs, voff + 4 * t, soff, 0);
+                        side_note(c.side, c.side_n, rowb + 4 * q + t, colb + col, ve[t]);
+                    }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) sV[(4 * q + t) * SP + col] = ve[t];
             }
@@ -321,12 +330,17 @@ template <int AUX = 2>
 __device__ __forceinline__ void store_p_mfma(const DdCtx& c, int R0, int C0, const float (&pold)[2][16], f32x16 (&acc)[2]) {
     const auto rs = tile_rsrc(c, R0, C0);
     const int voff = (4 * c.lh * TILE + c.l31) * 4;
+    // the tile BELOW a diagonal tile holds P[f+1, f] of the landmark that straddles the tile boundary (f = 127 mod 128):
+    // that entry of the packed 2 x 2 blocks (device_math.h: side_note) is kept here -- 1 tile in 78, a wave-uniform branch
+    const bool adj = R0 == C0 + TILE;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int soff = ((32 * c.wc + 8 * (r >> 2) + (r & 3)) * TILE + 64 * c.wr + 32 * rb) * 4;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pold[rb][r] - acc[rb][r]), rs, voff, soff, AUX);
+            const float v = pold[rb][r] - acc[rb][r];
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, AUX);
+            if (adj) side_note(c.side, c.side_n, R0 + 64 * c.wr + 32 * rb + c.l31, C0 + 32 * c.wc + 8 * (r >> 2) + (r & 3) + 4 * c.lh, v);
             acc[rb][r] = 0.0f;
         }
 }
@@ -699,7 +713,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
                                                                  unsigned long long* __restrict__ prof,
                                                                  const int32_t* __restrict__ dcount, int joseph,
                                                                  const char* __restrict__ img, int img_nch,
-                                                                 unsigned* __restrict__ claim) {      // non-null: the grid claims its tiles (dd_stream_p<DYN>)
+                                                                 unsigned* __restrict__ claim,        // non-null: the grid claims its tiles (dd_stream_p<DYN>)
+                                                                 float* __restrict__ side, int side_n) {
     if (status[0] != 0) return;
     if (dcount) {                     // observe(): the host's kp is an upper bound
         const int k = 2 * dcount[0];
@@ -711,6 +726,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // provably wave-uniform
     DdCtx c;
+    c.side = side; c.side_n = side_n;
     c.P = P; c.X = X; c.Y = Y; c.ld = ld; c.pitch = pitch; c.kp = kp; c.dbg = dbg & 0xff; c.xflags = dbg >> 8;      // (experiments build: bit 64 = no Y image loads)
     c.img = img; c.img_nch = img_nch;
     c.nchunks = (kp + KC - 1) / KC;                           // kp is a multiple of 16: the last chunk may be half
@@ -845,7 +861,8 @@ __global__ __launch_bounds__(256) void downdate_f64_mfma(double* __restrict__ P,
                                                          const double* __restrict__ Y, int pitch, int kp,
                                                          const int2* __restrict__ tiles, int L,
                                                          const int32_t* __restrict__ status,
-                                                         const int32_t* __restrict__ dcount, int joseph, int k16) {
+                                                         const int32_t* __restrict__ dcount, int joseph, int k16,
+                                                         double* __restrict__ side, int side_n) {
     if (status[0] != 0) return;
     // Joseph form: X = [K | T], Y = [T | K], each half padded to SLAM_KPAD columns of which only the first
     // k16 = round_up(k, 16) are non-zero: the k-loop walks the two live ranges and skips the zero padding.
@@ -922,6 +939,9 @@ __global__ __launch_bounds__(256) void downdate_f64_mfma(double* __restrict__ P,
                 const int cl = 32 * wc + 16 * cb + 4 * r + kk, rl = 32 * wr + 16 * rb + li;
                 const double val = pold[cb][rb][r] - acc[cb][rb][r];
                 if (!diag || rl >= cl) Pt[cl * DT + rl] = val;
+                // the packed 2 x 2 diagonal blocks (device_math.h: side_note): diagonal tiles, and the tile below one for the
+                // landmark that straddles the tile boundary
+                if ((diag && rl >= cl) || tile.x == tile.y + 1) side_note(side, side_n, R0 + rl, C0 + cl, val);
                 // in-tile mirror of a diagonal tile: element (row rl, column cl) of the lower triangle also goes to (row cl,
                 // column rl) -- a strided store straight from the registers (1 tile in 390 at C5; a staging buffer for it
                 // cost 33 KB of LDS in EVERY workgroup and held the kernel at three workgroups per CU)
@@ -1012,8 +1032,8 @@ int ensure_tile_order(slam_ekf* h, int T) {
 
 int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int pitch, const int32_t* dcount, int joseph, int k16,
                     const void* img) {
-#define IMGARGS (const char*)img, h->kcap / 16, (unsigned*)nullptr
-#define IMGARGS_CLAIM (const char*)img, h->kcap / 16, h->dd_claim
+#define IMGARGS (const char*)img, h->kcap / 16, (unsigned*)nullptr, (float*)h->Pside, h->npad / 2
+#define IMGARGS_CLAIM (const char*)img, h->kcap / 16, h->dd_claim, (float*)h->Pside, h->npad / 2
     const int n = 3 + 2 * h->N;
     const int edge = h->dtype == SLAM_F32 ? TILE : DT;
     const int rc = ensure_tile_order(h, (n + edge - 1) / edge);
@@ -1099,7 +1119,7 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
         const int L = bandB ? h->tilesB_len : h->tiles_len;
         hipLaunchKernelGGL(downdate_f64_mfma, dim3(8 * L), dim3(256), 0, h->stream, (double*)h->P, h->ld, n,
                            (const double*)X, (const double*)Y, pitch, kp_total, lst, L,
-                           h->d_status, dcount, joseph, joseph ? k16 : kp_total);
+                           h->d_status, dcount, joseph, joseph ? k16 : kp_total, (double*)h->Pside, h->npad / 2);
     }
     HIP_TRY(hipGetLastError());
     return SLAM_OK;

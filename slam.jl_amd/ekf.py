@@ -205,6 +205,13 @@ class EKFSlamState(SlamState):
         check(lib.slam_ekf_get_diag(self._h, out.ctypes.data))
         return out
 
+    def landmark_blocks(self):
+        """[3, N]: P[f, f], P[f+1, f], P[f+1, f+1] of every landmark (slam_ekf_get_landmark_blocks: the packed side array
+        the gating sweep streams)."""
+        out = np.empty((3, self.N), dtype=self.np_dtype)
+        check(lib.slam_ekf_get_landmark_blocks(self._h, out.ctypes.data))
+        return out
+
     def device_ptrs(self):
         """(x_ptr, P_ptr, ld, stream_ptr) raw device addresses for zero-copy interop."""
         dx, dP, st = C.c_void_p(), C.c_void_p(), C.c_void_p()

@@ -60,9 +60,19 @@ def relerr_cov(Pg, Po, prior_diag=None, block=2048):
     return worst
 
 
+def check_side(st, Pg, what):
+    """The packed 2 x 2 diagonal blocks the gating sweep streams (slam_ekf_get_landmark_blocks) are the matrix's own
+    entries, bit for bit: every writer of those entries (upload, add_features, the diagonal tiles of every down-date)
+    keeps the side array."""
+    blk = st.landmark_blocks()
+    f = 3 + 2 * np.arange(st.N)
+    assert np.array_equal(blk[0], Pg[f, f]) and np.array_equal(blk[1], Pg[f + 1, f]) and np.array_equal(blk[2], Pg[f + 1, f + 1]), what
+
+
 def check_state(st, xo, Po, dtype, what, fx=1.0, fP=1.0, prior=None):
     xg, Pg = st.download()
     assert xg.shape == xo.shape and Pg.shape == Po.shape, what
+    check_side(st, Pg, what)
     ex, eP = relerr(xg, xo), relerr_cov(Pg, Po, None if prior is None else np.diag(prior))
     assert ex <= TOL[dtype]["x"] * fx, f"{what}: x rel err {ex:.3e}"
     assert eP <= TOL[dtype]["P"] * fP, f"{what}: P rel err {eP:.3e}"
@@ -513,6 +523,7 @@ def test_state_upload_and_download_in_bands(pkg):
     assert np.array_equal(st.get_block(n - 300, 4000, 300, 200), P[n - 300:, 4000:4200])
     assert np.array_equal(st.get_block(100, n - 77, 50, 77), P[100:150, n - 77:])
     assert np.array_equal(st.diag(), np.diag(P))
+    check_side(st, Pg, "banded upload")
     st.close()
 
 
@@ -574,6 +585,7 @@ def test_config1_replay(pkg, config1, dtype):
     xg, Pg = st.download()
     worst_x = max(worst_x, relerr(xg, c["final_x"]))
     worst_P = max(worst_P, relerr_cov(Pg, c["final_P"]))
+    check_side(st, Pg, "config 1, end of the replay")
     print(f"config1 {dtype}: worst rel err x {worst_x:.3e} P {worst_P:.3e}; association agreement {agree}/{total}")
     assert worst_x <= tol_x and worst_P <= tol_P
     assert agree >= 0.99 * total
@@ -664,6 +676,7 @@ def test_full_size_10k_landmarks_fp32(pkg):
     print(f"N=10k fp32 update: rel err x {ex:.3e}  P {eP:.3e}  matched {int(sel.sum())}/{m}")
     assert ex <= 5e-6 and eP <= 5e-6
     assert np.array_equal(Pg, Pg.T)
+    check_side(st, Pg, "full size, 10k landmarks")
     assert float(np.trace(Pg.astype(np.float64))) < tr0
     st.close()
 
@@ -809,6 +822,9 @@ def test_full_size_50k_landmarks_fp64_joseph(pkg):
     s = np.maximum(prior_diag, post_diag)                      # relerr_cov's scale: max(prior, posterior) variance
     assert np.max(np.abs(dg - post_diag) / s) <= 1e-9
     assert float(dg.sum()) < float(prior_diag.sum())           # information only removes variance
+    blk = st.landmark_blocks()                                 # the packed 2 x 2 blocks: the diagonal tiles' epilogue keeps them
+    ff = 3 + 2 * np.arange(N)
+    assert np.array_equal(blk[0], dg[ff]) and np.array_equal(blk[2], dg[ff + 1])
     sd = np.sqrt(s)
 
     def check_block(r0, c0, nr, nc, what):
