@@ -43,7 +43,7 @@ constexpr int PF_CTL_MAXOBS = 64;           // = PF_AUTO_MAXOBS
 // every peer's inbox (per-step scalars, hand-shake words): posted writes to the peer, polls of local memory.
 constexpr int PF_MAX_WORLD = 8;
 struct PfInbox {                 // lives in its owner's device memory; slot [r] is written by rank r (its own too)
-    double scal[2][PF_MAX_WORLD][8];                 // per-step scalars, two parities: {max, sum w, sum w^2, step}
+    double scal[2][PF_MAX_WORLD][8];                 // per-step scalars, two parities: {max, sum w, sum w^2, tag(values, step)}
     unsigned long long ready[PF_MAX_WORLD][8];       // [r][0]: last resampling step whose step kernel rank r has COMPLETED
     unsigned long long bar[PF_MAX_WORLD][8];         // [r][0]: rank r's count of peer barriers (materialise)
 };
@@ -1550,6 +1550,7 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
     __shared__ double sh[4];
     __shared__ double s_r6[4][6];
     __shared__ double s_g[12];
+    __shared__ double s_rv[PF_MAX_WORLD][3];      // the ranks' records of the scalar exchange (thread 0)
     __shared__ int s_tref[PF_TAB_MAX];
     __shared__ int s_i[4];          // [0] identity landmarks, [1] outcome (0 none, 1 lazy resampling, 2 halt), [2] fresh table
     const int tid = threadIdx.x;
@@ -1636,50 +1637,53 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
         int err = s_perr;                                     // a workgroup's statistics never came: halt and report
         if (a.world > 1 && !err) {
             // all-gather of (max, sum, sum2) among the ranks, two parities (a rank is at most one step ahead of the
-            // slowest), the sequence number written last.  With peers attached every rank WRITES its four words into
-            // every rank's inbox (posted stores over xGMI; its own inbox too) and polls its OWN device memory; the legacy
-            // form goes through one page of pinned host memory that every rank has mapped.
-            // (no fence: a system-scope release is a write-back of this XCD's whole L2, which the sweep has just filled
-            //  with dirty landmark records; the three write-through stores are drained, then the sequence number goes out)
+            // slowest).  With peers attached every rank WRITES its record into every rank's inbox (posted stores over
+            // xGMI; its own inbox too) and polls its OWN device memory; the legacy form goes through one page of pinned
+            // host memory that every rank has mapped.  A record is three values and a TAG = hash of their bit patterns
+            // xor key(step) (as the statistics lines of the workgroups, part_key): the reader accepts a record only when
+            // its tag fits the three values it has read and this step's key, so a record that is stale (the parity's
+            // previous step), half arrived or torn is simply polled again -- no ordering between the four stores is
+            // relied on, across a fabric or otherwise.  (No fence: a system-scope release is a write-back of this XCD's
+            // whole L2, which the sweep has just filled with dirty landmark records.)
             const int par = (int)(a.seq & 1);
-            if (a.peers) {
-                for (int r = 0; r < a.world; ++r) {
-                    double* mine = &a.peers->inbox[r]->scal[par][a.rank][0];
-                    __hip_atomic_store(mine + 0, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __hip_atomic_store(mine + 1, acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __hip_atomic_store(mine + 2, acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                for (int r = 0; r < a.world; ++r)
-                    __hip_atomic_store(&a.peers->inbox[r]->scal[par][a.rank][3], (double)a.seq, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_SYSTEM);
-            } else {
-                double* mine = a.xchg + ((size_t)par * a.world + a.rank) * 8;
+            auto rec_tag = [&](double v0, double v1, double v2) {
+                const unsigned long long b0 = (unsigned long long)__double_as_longlong(v0), b1 = (unsigned long long)__double_as_longlong(v1),
+                                         b2 = (unsigned long long)__double_as_longlong(v2);
+                return ((b0 << 7) | (b0 >> 57)) ^ ((b1 << 23) | (b1 >> 41)) ^ ((b2 << 41) | (b2 >> 23));
+            };
+            const unsigned long long xkey = part_key(a.seq) ^ 0x5851F42D4C957F2Dull;
+            const unsigned long long my_tag = rec_tag(M, acc[0], acc[1]) ^ xkey;
+            for (int r = 0; r < (a.peers ? a.world : 1); ++r) {
+                double* mine = a.peers ? &a.peers->inbox[r]->scal[par][a.rank][0] : a.xchg + ((size_t)par * a.world + a.rank) * 8;
                 __hip_atomic_store(mine + 0, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(mine + 1, acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(mine + 2, acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(mine + 3, (double)a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine + 3), my_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             const double* page = a.peers ? &a.inbox->scal[par][0][0] : a.xchg + (size_t)par * a.world * 8;
             const unsigned long long t0 = wall_clock64();
+            double (*rv)[3] = s_rv;            // (LDS: a dynamically indexed local array would put the whole kernel on scratch)
             for (int r = 0; r < a.world && !err; ++r) {
                 const double* slot = page + (size_t)r * 8;
-                while (__hip_atomic_load(slot + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (double)a.seq) {
+                for (;;) {
+                    rv[r][0] = __hip_atomic_load(slot + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    rv[r][1] = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    rv[r][2] = __hip_atomic_load(slot + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    const unsigned long long tag = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(slot + 3), __ATOMIC_RELAXED,
+                                                                     __HIP_MEMORY_SCOPE_SYSTEM);
+                    if ((rec_tag(rv[r][0], rv[r][1], rv[r][2]) ^ tag) == xkey) break;
                     __builtin_amdgcn_s_sleep(20);
                     if (wall_clock64() - t0 > 2000000000ull) { err = PF_ERR_EXCHANGE; break; }     // 20 s at 100 MHz: a rank is gone
                 }
             }
             if (!err) {
                 gM = -__builtin_inf();
-                for (int r = 0; r < a.world; ++r)
-                    gM = fmax(gM, __hip_atomic_load(page + (size_t)r * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+                for (int r = 0; r < a.world; ++r) gM = fmax(gM, rv[r][0]);
                 gs1 = gs2 = 0.0;
                 for (int r = 0; r < a.world; ++r) {                         // every rank folds the same table in rank order
-                    const double* slot = page + (size_t)r * 8;
-                    const double f = exp(__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - gM);
-                    gs1 += __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) * f;
-                    gs2 += __hip_atomic_load(slot + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) * f * f;
+                    const double f = exp(rv[r][0] - gM);
+                    gs1 += rv[r][1] * f;
+                    gs2 += rv[r][2] * f * f;
                 }
             }
         }

@@ -7,7 +7,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package
 pkg = load_package()
-NP, NL, M = 262144, 512, 16
+NP, NL, M = int(os.environ.get("PF_PROBE_NP", "262144")), 512, 16      # PF_PROBE_NP: particles (a shard of an 8-rank filter has 32768)
 Q = np.array([[0.25, 0.0], [0.0, (3 * math.pi / 180) ** 2]]); R = np.array([[0.01, 0.0], [0.0, (math.pi / 180) ** 2]])
 rng = np.random.default_rng(1)
 lm = rng.uniform(-200, 200, (NL, 2))
