@@ -165,6 +165,7 @@ struct slam_pf {
     PfPeers peers;
     PfInbox* inbox;              // this rank's inbox (device memory, exported)
     void* peer_open[PF_MAX_WORLD][9];   // what hipIpcOpenMemHandle returned (closed at detach); null for in-process peers
+    int64_t par_max_n;           // filters / shards of at most this many particles take the observation-parallel step kernel
     long long bar_count;         // peer barriers enqueued so far (the same on every rank: the calls are collective)
     long long halts;             // SLAM_PF_HALTED returns so far
     double last_out[4];          // {Neff, resampled?, resamplings, step} of the last confirmed step
@@ -378,7 +379,7 @@ __device__ __forceinline__ LmRow<T> load_row(const T* __restrict__ row, int64_t 
     return r;
 }
 
-__device__ inline double block_reduce(double v, double* sh, bool is_max);
+__device__ inline double block_reduce(double v, double* sh, bool is_max, int nw = 0);
 __device__ __forceinline__ void fold_partials(const double* __restrict__ part, int nblocks, int relative,
                                               double* __restrict__ out, double* __restrict__ host_out, long long seq);
 
@@ -1091,18 +1092,20 @@ __global__ __launch_bounds__(256) void pf_clear_lm_kernel(T* __restrict__ lm, in
 }
 
 // ---- F4: reductions ------------------------------------------------------------------------------
-__device__ inline double block_reduce(double v, double* sh, bool is_max) {
+// nw: waves taking part (0: all of the workgroup; the tail of the observation-parallel step kernel runs on four of eight)
+__device__ inline double block_reduce(double v, double* sh, bool is_max, int nw) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         const double o = __shfl_xor(v, off);
         v = is_max ? fmax(v, o) : v + o;
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (nw == 0) nw = (int)(blockDim.x >> 6);
     __syncthreads();
     if (lane == 0) sh[wave] = v;
     __syncthreads();
     double r = sh[0];
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = is_max ? fmax(r, sh[w]) : r + sh[w];
+    for (int w = 1; w < nw; ++w) r = is_max ? fmax(r, sh[w]) : r + sh[w];
     return r;
 }
 
@@ -1604,7 +1607,7 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
     for (int base = 0; base < nblocks; base += 1024) {
         if (base > 0) collect(base);
         double m = fmax(fmax(qv(0, 0), qv(1, 0)), fmax(qv(2, 0), qv(3, 0)));
-        m = block_reduce(m, sh, true);
+        m = block_reduce(m, sh, true, 4);
         const double Mn = fmax(M, m);
         const double fo = M == -__builtin_inf() ? 0.0 : exp(M - Mn);              // rescale what earlier passes summed
         acc[0] *= fo; acc[1] *= fo * fo;
@@ -1832,6 +1835,104 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void pf_auto_step_kern
     // for anything: each runs to its end on its own, whenever the dispatcher starts it (the dispatch order is not relied
     // on), and the collection ends on a time-out
     if (blockIdx.x == gridDim.x - 1) pf_auto_tail<T>(a, s_l, s_st, s_first, pcur, tside, lwcur);
+}
+
+// ---- the same step with the OBSERVATIONS in parallel (small filters / shards) -----------------------------------------
+// pf_auto_step_kernel gives a particle to a lane and walks the step's m observations one after the other: a dependent
+// chain of m record loads, ~200 instructions and stores each.  On a full-size filter four such waves per SIMD hide each
+// other's latency and the sweep runs at 5 TB/s; on a SMALL one -- a shard of an 8-rank filter has 32 768 particles, 128
+// workgroups on 256 CUs -- the chain is what the step takes: 27 us for an eighth of the particles against 43 for all of them
+// (tools/gpu_r3l.sh).  Here a workgroup owns 64 particles and wave w of its eight takes the observations w, w + 8, ...:
+// different landmarks of a call are independent given the particle's pose (the host guarantees that no landmark occurs
+// twice in the call, else the sequential kernel runs), and the log-weight is lw = (...((lw - shift) + t_0) + t_1 ...) with
+// every term t_i formed without lw -- the waves leave their terms in LDS and wave 0 adds them IN OBSERVATION ORDER: the same
+// particles and weights bit for bit.  One statistics line per workgroup of 64 particles; the collecting tail runs on
+// the first four waves of the last workgroup (the others have ended: a barrier counts live waves only).
+constexpr int PAR_WAVES = 8;
+constexpr int PF_PAR_MAX_N = 49152;          // one-box sweep (tools/gpu_r3m.sh): 16384: 26.4 -> 15.2 us, 32768: 27.2 -> 17.1, 65536: 28.4 -> 29.2, 98304: 31.9 -> 43.5
+template <typename T, bool SH>
+__global__ __launch_bounds__(64 * PAR_WAVES) void pf_auto_step_par_kernel(PfAutoArgs a) {
+    PfCtl* ctl = a.ctl;
+    typedef const __attribute__((address_space(4))) PfAutoArgs* KargPtr;
+    const KargPtr ka = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    int l_pre = 0;
+    int32_t st_pre = 0;
+    if ((int)threadIdx.x < a.m) {
+        l_pre = ka->ids[threadIdx.x] - 1;
+        st_pre = a.lmstate[l_pre];
+    }
+    const long long halted = ctl->halt_seq;
+    const int pcur = ctl->pcur, tside = ctl->tside, lwcur = ctl->lwcur;
+    const double shift_next = ctl->shift_next;
+    if (halted != 0 || ctl->error != 0) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->stamps[0] = wall_clock64();
+    __shared__ T s_obs[2 * PF_AUTO_MAXOBS];
+    __shared__ int32_t s_ids[PF_AUTO_MAXOBS], s_meta[PF_AUTO_MAXOBS], s_l[PF_AUTO_MAXOBS], s_st[PF_AUTO_MAXOBS], s_first[PF_AUTO_MAXOBS];
+    __shared__ T s_pose[3][64];
+    __shared__ T s_term[PF_AUTO_MAXOBS][64];
+    const int m = a.m;
+    for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) s_obs[i] = (T)ka->z[i];
+    const T pend = (T)shift_next;
+    T* pose = (T*)(pcur ? a.pose1 : a.pose0);
+    T* logw = (T*)(lwcur ? a.logw1 : a.logw0);
+    const int32_t* tabs = tside ? a.tab1 : a.tab0;
+    const int64_t n = a.n;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int64_t pi = (int64_t)blockIdx.x * 64 + lane;
+    const bool valid = pi < n;
+    const int64_t p = valid ? pi : n - 1;
+    PfShardCtx sc{};
+    if constexpr (SH) sc = PfShardCtx{a.peers, (uint32_t)a.first, (uint32_t)a.n, a.rank, a.world};
+    T x = 0, y = 0, phi = 0, lw = 0;
+    if (wave == 0) {                                     // F1: the motion model, once per particle
+        x = pose[p]; y = pose[n + p]; phi = pose[2 * n + p];
+        lw = logw[p];
+        T e1, e2;
+        normals2<T>((uint64_t)(a.first + p), a.step, STREAM_PREDICT, a.seed, e1, e2);
+        const T Vn = (T)a.V + (T)a.a0 * e1;              // sim/sim-utils.jl:36
+        const T Gn = (T)a.G + (T)a.a1 * e2;              // :37
+        T sgp, cgp, sg, cg;
+        m_sincos<T>(Gn + phi, sgp, cgp);
+        m_sincos<T>(Gn, sg, cg);
+        const T xn = x + Vn * (T)a.dt * cgp;             // src/ekf.jl:39-41
+        const T yn = y + Vn * (T)a.dt * sgp;
+        const T pn = wrap_pi<T>(phi + Vn * (T)a.dt * sg / (T)a.wheelbase);
+        x = xn; y = yn; phi = pn;
+        if (valid) { pose[p] = x; pose[n + p] = y; pose[2 * n + p] = phi; }
+        s_pose[0][lane] = x; s_pose[1][lane] = y; s_pose[2][lane] = phi;
+    }
+    plan_obs(l_pre, st_pre, m, s_l, s_st, s_ids, s_meta, s_first);       // (two barriers: the pose is in LDS behind them)
+    if (wave != 0) { x = s_pose[0][lane]; y = s_pose[1][lane]; phi = s_pose[2][lane]; }
+    const T R00 = (T)a.R00, R10 = (T)a.R10, R01 = (T)a.R01, R11 = (T)a.R11;
+    T* lm0 = (T*)a.lm0;
+    T* lm1 = (T*)a.lm1;
+    for (int i = wave; i < m; i += PAR_WAVES) {          // F2 / F3: this wave's observations (uniform per wave)
+        const int32_t code = __builtin_amdgcn_readfirstlane(s_ids[i]), meta = __builtin_amdgcn_readfirstlane(s_meta[i]);
+        const int l = code & ID_MASK;
+        const T r = s_obs[2 * i], b = s_obs[2 * i + 1];
+        const BufRow<T, decltype(lm_rsrc<T>(lm0, n))> row{lm_rsrc<T>(((meta & META_WBUF) ? lm1 : lm0) + (size_t)l * 5 * n, n),
+                                                          (uint32_t)p * (uint32_t)sizeof(T), (uint32_t)n * (uint32_t)sizeof(T)};
+        T term = 0;
+        if (code & NEW_FLAG) {
+            lm_init<T>(row, n, x, y, phi, r, b, R00, R10, R01, R11, valid);
+        } else {
+            const LmRow<T> cur = sweep_load<T, 2, SH>(lm0, lm1, tabs, n, (uint32_t)p, code, meta, sc);
+            lm_update<T>(row, n, cur, x, y, phi, r, b, R00, R10, R01, R11, valid, term);      // term = 0 + (this observation's log-weight term)
+        }
+        s_term[i][lane] = term;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        lw -= pend;
+        for (int i = 0; i < m; ++i)
+            if (!(__builtin_amdgcn_readfirstlane(s_ids[i]) & NEW_FLAG)) lw += s_term[i][lane];     // observation order
+        if (valid) logw[p] = lw;
+    }
+    block_weight_stats<T, true, false>(lw, x, y, phi, valid && wave == 0, 1, a.part, a.seq);
+    if (blockIdx.x == gridDim.x - 1) {
+        if (threadIdx.x >= 256) return;                  // the tail is written for four waves
+        pf_auto_tail<T>(a, s_l, s_st, s_first, pcur, tside, lwcur);
+    }
 }
 
 // ---- the resampling of a SHARDED filter on the device --------------------------------------------------------------
@@ -2091,7 +2192,8 @@ static int pf_create_impl(slam_pf* h) {
     HIP_TRY(hipMemsetAsync(h->inbox, 0, sizeof(PfInbox), h->stream));
     h->ocap = PF_OCAP;
     h->red_blocks = grid_for(h->n);                  // one partial record per 256 particles
-    if ((rc = pf_alloc(&h->d_part, sizeof(double) * 8 * h->red_blocks, h->stream))) return rc;
+    // (room for one statistics line per 64 particles: the observation-parallel step kernel's workgroups)
+    if ((rc = pf_alloc(&h->d_part, sizeof(double) * 8 * (size_t)((h->n + 63) / 64), h->stream))) return rc;
     if ((rc = pf_alloc(&h->d_out, sizeof(double) * 8, h->stream))) return rc;
     if ((rc = pf_alloc(&h->d_cdf, sizeof(double) * (size_t)h->n_global, h->stream))) return rc;
     const size_t nb = ((size_t)h->n_global + SCAN_BLOCK - 1) / SCAN_BLOCK;
@@ -2157,6 +2259,7 @@ extern "C" int slam_pf_create(slam_pf_t* out, int dtype, int64_t n_local, int64_
     h->lazy_off = getenv("SLAMHIP_PF_EAGER") && atoi(getenv("SLAMHIP_PF_EAGER")) ? 1 : 0;
     h->pose[0] = h->pose[1] = h->lm[0] = h->lm[1] = h->logw = h->logw2[0] = h->logw2[1] = nullptr;
     h->lwcur = 0; h->d_peers = nullptr; h->inbox = nullptr; h->bar_count = 0; h->halts = 0;
+    h->par_max_n = slam_exp_env("SLAMHIP_PF_PAR_MAX", PF_PAR_MAX_N);      // (the knob is read by the experiments build only)
     memset(&h->peers, 0, sizeof(h->peers));
     memset(h->peer_open, 0, sizeof(h->peer_open));
     h->h_ids = nullptr; h->h_obs = nullptr; h->ocap = 0;
@@ -2947,6 +3050,22 @@ static int pf_auto_enqueue(slam_pf* h, const PfStepRec& r) {
     a.peers = sh ? h->d_peers : nullptr;
     a.inbox = h->inbox;
     const dim3 grid(grid_for(h->n));
+    // small filter / shard: the observations in parallel (pf_auto_step_par_kernel) -- FastSLAM-1.0 step, no landmark twice
+    // in the call; above PF_PAR_MAX_N particles the sequential sweep already fills the chip
+    bool par = !r.proposal && r.m >= 2 && h->n <= h->par_max_n;
+    for (int i = 1; i < r.m && par; ++i)
+        for (int j = 0; j < i; ++j)
+            if (r.ids[i] == r.ids[j]) { par = false; break; }
+    if (par) {
+        const dim3 pgrid((unsigned)((h->n + 63) / 64));
+        if (h->dtype == SLAM_F32) {
+            if (sh) hipLaunchKernelGGL((pf_auto_step_par_kernel<float, true>), pgrid, dim3(64 * PAR_WAVES), 0, h->stream, a);
+            else hipLaunchKernelGGL((pf_auto_step_par_kernel<float, false>), pgrid, dim3(64 * PAR_WAVES), 0, h->stream, a);
+        } else {
+            if (sh) hipLaunchKernelGGL((pf_auto_step_par_kernel<double, true>), pgrid, dim3(64 * PAR_WAVES), 0, h->stream, a);
+            else hipLaunchKernelGGL((pf_auto_step_par_kernel<double, false>), pgrid, dim3(64 * PAR_WAVES), 0, h->stream, a);
+        }
+    } else
 #define PF_STEP_LAUNCH(TT)                                                                                                   \
     do {                                                                                                                     \
         if (sh) {                                                                                                            \
@@ -2957,8 +3076,10 @@ static int pf_auto_enqueue(slam_pf* h, const PfStepRec& r) {
             else hipLaunchKernelGGL((pf_auto_step_kernel<TT, false, false>), grid, dim3(256), 0, h->stream, a);              \
         }                                                                                                                    \
     } while (0)
-    if (h->dtype == SLAM_F32) PF_STEP_LAUNCH(float);
-    else PF_STEP_LAUNCH(double);
+    {
+        if (h->dtype == SLAM_F32) PF_STEP_LAUNCH(float);
+        else PF_STEP_LAUNCH(double);
+    }
 #undef PF_STEP_LAUNCH
     HIP_TRY(hipGetLastError());
     if (a.lazy_ok && r.force != 0) {                        // (force == 0: this step never resamples, nothing to gate)

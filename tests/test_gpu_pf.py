@@ -660,6 +660,46 @@ def test_auto_mode_equals_the_synchronous_driver(pkg, dtype, proposal):
         g.shard.close()
 
 
+@pytest.mark.parametrize("m", [2, 8, 9, 16, 23])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_auto_mode_observation_parallel_kernel(pkg, dtype, m):
+    """Small filters (and the shards of a sharded one) take pf_auto_step_par_kernel when no landmark occurs twice in the call:
+    a workgroup owns 64 particles, its eight waves take the observations w, w + 8, ..., the log-weight terms are added in
+    observation order afterwards.  Against the host-driven FastSLAM.step (the sequential kernel): the same particles bit for
+    bit, log-weights within 4 ulp, the same resampling steps -- with first sightings, a particle count that is no multiple
+    of 64, fewer / exactly / more observations than waves, Neff-triggered and forced resamplings and a step whose
+    repeated landmark sends it back to the sequential kernel."""
+    n, nl, seed = 5000 + 13, 40, 57
+    lm = scene(nl, 29)
+    f = {}
+    for name in ("auto", "sync"):
+        sh = pkg.PFShard(n, nl, seed, dtype=dtype)
+        sh.set_pose([0.5, 1.5, -0.2])
+        sh.init_landmarks(lm[:30], 0.01, 0.1)                 # 31..40 are first seen later
+        f[name] = pkg.FastSLAM(sh, None, neff_frac=0.75)
+    rng = np.random.default_rng(60 + m)
+    pose = np.array([0.5, 1.5, -0.2])
+    hist = []
+    for t in range(24):
+        pose = np.array([pose[0] + 0.6 * math.cos(pose[2]), pose[1] + 0.6 * math.sin(pose[2]), pose[2]])
+        ids = rng.choice(np.arange(1, nl + 1), size=m, replace=False)
+        if t == 11:
+            ids[-1] = ids[0]                                  # a repeat: this step takes the sequential kernel
+        z = observe(lm, pose, ids, rng)
+        force = True if t % 6 == 2 else (False if t % 6 == 4 else None)
+        f["auto"].step_async(6.0, 0.01 * (t % 5), 4.0, Q, 0.1, z, ids, R, force_resample=force)
+        hist.append(f["sync"].step(6.0, 0.01 * (t % 5), 4.0, Q, 0.1, z, ids, R, force_resample=force))
+        if t in (3, 12, 23):
+            neff, did = f["auto"].flush()
+            assert did == hist[-1][1], f"step {t}"
+            assert neff == pytest.approx(hist[-1][0], rel=1e-12 if dtype == "f64" else 1e-6)
+            assert f["auto"].resamples == f["sync"].resamples
+            _compare(f["auto"].shard, f["sync"].shard, f"m {m} step {t}", exact_logw=False)
+    assert f["sync"].resamples >= 4
+    for g in f.values():
+        g.shard.close()
+
+
 @pytest.mark.parametrize("n", [200, 1024 * 256 + 700])
 def test_auto_mode_grid_sizes_of_the_statistics_hand_over(pkg, n):
     """The step kernel's last workgroup collects one tagged statistics line per workgroup, 1024 lines per pass: a grid of ONE
