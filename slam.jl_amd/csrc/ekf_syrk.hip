@@ -143,11 +143,10 @@ __device__ __forceinline__ void store_p_tile(const DdCtx& c, int R0, int C0, con
             if (dbg & 1) continue;                                 // experiment: no stores (P stays as it is)
             if (!diag) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rs, voff, soff, 0);
-                if (R0 == C0 + TILE) {          // the tile below a diagonal tile: P[f+1, f] of the landmark straddling the boundary
-                    const float vs[4] = {val.x, val.y, val.z, val.w};
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) side_note(c.side, c.side_n, rowb + 4 * q + t, colb + col, vs[t]);
-                }
+                // the tile below a diagonal tile holds P[f+1, f] of the landmark straddling the boundary: (row 0, column 127) of the
+                // tile = wave (0, 3), (rb, s) = (0, 3), lane (q, cl) = (0, 7), element 0
+                if (rb == 0 && s == 3 && R0 == C0 + TILE && c.wr == 0 && c.wc == 3 && q == 0 && cl == 7)
+                    c.side[(size_t)c.side_n + ((C0 + TILE - 4) >> 1)] = val.x;
             } else {
                 // (scalar copies: bit-casting val[t] directly made hipcc 7.2 store element 0 four times)
                 const float ve[4] = {val.x, val.y, val.z, val.w};
@@ -340,7 +339,8 @@ __device__ __forceinline__ void store_p_mfma(const DdCtx& c, int R0, int C0, con
             const int soff = ((32 * c.wc + 8 * (r >> 2) + (r & 3)) * TILE + 64 * c.wr + 32 * rb) * 4;
             const float v = pold[rb][r] - acc[rb][r];
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, AUX);
-            if (adj) side_note(c.side, c.side_n, R0 + 64 * c.wr + 32 * rb + c.l31, C0 + 32 * c.wc + 8 * (r >> 2) + (r & 3) + 4 * c.lh, v);
+            // the one entry of such a tile that belongs to the side array: (row 0, column 127) = wave (0, 3), lane 32, (rb, r) = (0, 15)
+            if (rb == 0 && r == 15 && adj && c.wr == 0 && c.wc == 3 && c.lh == 1 && c.l31 == 0) c.side[(size_t)c.side_n + ((C0 + TILE - 4) >> 1)] = v;
             acc[rb][r] = 0.0f;
         }
 }
