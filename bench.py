@@ -145,6 +145,8 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
     import torch
     import torch.distributed as dist
     NP, NL, M = 262144, 512, 16
+    if os.environ.get("SLAM_BENCH_REHEARSE") == "1" and os.environ.get("SLAM_BENCH_NP"):
+        NP = int(os.environ["SLAM_BENCH_NP"])        # one-card rehearsal only (e.g. 6 ranks x 32768: the shard size of 8 GPUs)
     Q = np.array([[0.5 ** 2, 0.0], [0.0, (3 * math.pi / 180) ** 2]])
     rng = np.random.default_rng(20240602)                      # same scene and observations on every rank
     lm = rng.uniform(-200, 200, (NL, 2))
