@@ -2137,6 +2137,7 @@ inline int grid_for(int64_t n) { return (int)((n + 255) / 256); }
     } while (0)
 
 static void pf_detach_peers_impl(slam_pf* h);
+static const char* pf_error_text(long long code);
 static int pf_auto_flush(slam_pf* h);      // wait for the steps slam_pf_step_auto has queued (resolving a halted one)
 static int pf_auto_leave(slam_pf* h);      // auto mode -> legacy mode: wait for the queue, bring the bookkeeping back to the host
 #define PF_LEGACY_ENTRY(h)                    \
@@ -2340,7 +2341,20 @@ static int pf_materialise(slam_pf* h) {
                 h->lbuf[l] = (int8_t)(pass == 0 ? (B ^ 1) : B);
             }
     }
-    if (sh) { const int rcb = pf_peer_barrier(h); if (rcb) return rcb; }
+    if (sh) {
+        const int rcb = pf_peer_barrier(h);
+        if (rcb) return rcb;
+        // a barrier that timed out (a rank is gone, or -- several shards of ONE process -- two of their streams share a
+        // hardware queue and the kernel that waits sits in front of the kernel it waits for) has let the passes run on
+        // unfinished data: that must not pass silently
+        int32_t err = 0;
+        HIP_TRY(hipMemcpyAsync(&err, &h->d_ctl->error, sizeof(err), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (err) {
+            slam_set_error("%s", pf_error_text(err));
+            return SLAM_E_HIP;
+        }
+    }
     h->lazy_dirty = 0;
     return SLAM_OK;
 }
@@ -2956,7 +2970,9 @@ static const char* pf_error_text(long long code) {
     switch (code) {
         case PF_ERR_HANDOVER: return "auto mode: a workgroup's statistics line never reached the collecting workgroup (2 s)";
         case PF_ERR_EXCHANGE: return "the scalar exchange between the ranks of the sharded filter timed out (a rank is gone)";
-        case PF_ERR_PEER: return "a hand-shake between the ranks of the sharded filter timed out (a rank is gone)";
+        case PF_ERR_PEER:
+            return "a hand-shake between the ranks of the sharded filter timed out (a rank is gone; or, for shards of ONE process, "
+                   "their streams share a hardware queue: set GPU_MAX_HW_QUEUES >= the number of shards + 2 before the first HIP call)";
         default: return "auto mode: the device reported an unknown error";
     }
 }

@@ -785,8 +785,10 @@ class PFSlamState(FastSLAM):
 
 
 def attach_local_peers(shards):
-    """Several shards of ONE process (one host thread driving several GPUs, or -- the tests -- several shards on one
-    card) become the ranks of one sharded filter: every shard attaches every shard's blob (raw pointers, no IPC)."""
+    """Several shards of ONE process (one host thread per shard; several GPUs, or -- the tests -- several shards on one
+    card) become the ranks of one sharded filter: every shard attaches every shard's blob (raw pointers, no IPC).
+    Shards on ONE card wait for each other inside their kernels, so each shard's stream needs a hardware queue of its own:
+    set ``GPU_MAX_HW_QUEUES`` (default 4 per device) to at least ``len(shards) + 2`` before the first HIP call."""
     blobs = [sh.export_peer() for sh in shards]
     for r, sh in enumerate(shards):
         sh.attach_peers(r, len(shards), blobs)

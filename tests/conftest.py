@@ -4,6 +4,13 @@ import sys
 
 import pytest
 
+# Several shards of ONE process (tests/test_gpu_pf.py::test_sharded_filter_resamples_on_the_device: one host thread and one
+# stream per shard) wait for each other's records inside their kernels: every such stream needs a hardware queue of its
+# own -- two streams on one queue put the kernel that waits in front of the kernel it waits for.  The runtime's default
+# is four queues per device; it is read at the first HIP call, hence here.  (One process per GPU -- the deployment -- has
+# no such limit to mind.)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
