@@ -127,6 +127,29 @@ int slam_ekf_predict(slam_ekf_t h, double v, double g, double wheelbase,
 int slam_ekf_associate(slam_ekf_t h, const double* z, int nz, const double R[4],
                        double gate1, double gate2, int32_t* assoc);
 
+/* How associate / observe search the map -- the reference's TODO, src/data-association.jl:18-20 ("a quick bounding-box
+ * threshold to remove distant features; or, better yet, a balanced k-d tree lookup").  Every form returns IDENTICAL
+ * decisions; the choice is cost only.
+ *   SLAM_GATE_SWEEP  every (observation, landmark) pair, O(N) per call (with the threshold pre-gate from 32768
+ *                    landmarks on).
+ *   SLAM_GATE_GRID   a uniform grid over the landmark means, kept on the device: an observation visits only the
+ *                    landmarks of the cells its gate can reach -- O(candidates).  The grid follows the filter by itself
+ *                    (updates record how far they moved a mean, add_features appends to a tail, a rebuild happens on
+ *                    the device when either grows too large).  Needs R positive definite and gate1 <= gate2 < inf;
+ *                    otherwise the call falls back to the sweep.  "Identical" presumes what the bound's proof does: every
+ *                    landmark's S = H P H' + R positive definite AS COMPUTED (a landmark whose 2 x 2 block has lost its
+ *                    definiteness to rounding -- condition above 1/eps of the dtype -- yields a negative nis in the
+ *                    sweep, which the grid, like the threshold pre-gate, may not visit).
+ *   SLAM_GATE_AUTO   (default) the grid from 16384 landmarks on (below that the two cost the same: 11-14 us).
+ * slam_ekf_gate_info: out = {form of the last gating, cells per axis, landmarks in the grid, landmarks in the tail,
+ * rebuilds, grid queries, landmarks visited, landmarks fully evaluated (the last four: totals since create)}.
+ * Synchronises. */
+#define SLAM_GATE_AUTO   0
+#define SLAM_GATE_SWEEP  1
+#define SLAM_GATE_GRID   2
+int slam_ekf_set_gate_mode(slam_ekf_t h, int mode);
+int slam_ekf_gate_info(slam_ekf_t h, int64_t out[8]);
+
 /* compute_association(x, P, z, R, idf)  src/data-association.jl:53-63.
  * out = {nis, nd}.  Synchronises. */
 int slam_ekf_nis(slam_ekf_t h, const double z1[2], int j, const double R[4], double out[2]);

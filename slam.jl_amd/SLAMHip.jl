@@ -14,7 +14,7 @@ module SLAMHip
 
 export SlamState, EKFSlamState, set_state!, predict, update, add_features, associate,
        compute_association, predict_observation, mpi_to_pi,
-       ekf_predict!, ekf_update!, augment!, observe!, cov_block, cov_diag, landmark_blocks, feature_ellipses, vehicle_ellipse,
+       ekf_predict!, ekf_update!, augment!, observe!, cov_block, cov_diag, landmark_blocks, gate_mode!, gate_info, feature_ellipses, vehicle_ellipse,
        PFSlamState, set_pose!, init_landmarks!, pf_predict!, update_known!, step!, step_async!, flush!,
        resample!, mean_pose, weights, particles, peer_blob, attach_peers!, peer_selftest, detach_peers!, comm_info
 
@@ -191,6 +191,27 @@ function landmark_blocks(s::EKFSlamState{T}) where {T}
     out = Matrix{T}(undef, N, 3)                     # the library writes three rows of N values
     check(ccall((:slam_ekf_get_landmark_blocks, libslamhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), handle(s), out))
     permutedims(out)
+end
+
+"""
+    gate_mode!(s, mode)    mode in (:auto, :sweep, :grid)
+
+How `associate` / `observe!` search the map -- the TODO of src/data-association.jl:18-20: `:sweep` visits every landmark,
+`:grid` keeps a uniform grid over the landmark means on the device and visits only the cells an observation's gate can
+reach (O(candidates)), `:auto` (default) takes the grid from 16384 landmarks on.  The decisions are identical.
+"""
+function gate_mode!(s::EKFSlamState, mode::Symbol)
+    m = mode === :auto ? 0 : mode === :sweep ? 1 : mode === :grid ? 2 : throw(ArgumentError("gate mode must be :auto, :sweep or :grid"))
+    check(ccall((:slam_ekf_set_gate_mode, libslamhip), Cint, (Ptr{Cvoid}, Cint), handle(s), m))
+    s
+end
+
+"slam_ekf_gate_info: (form of the last gating, cells per axis, landmarks in the grid, tail, rebuilds, queries, visited, evaluated)."
+function gate_info(s::EKFSlamState)
+    out = zeros(Int64, 8)
+    check(ccall((:slam_ekf_gate_info, libslamhip), Cint, (Ptr{Cvoid}, Ptr{Int64}), handle(s), out))
+    (form = (nothing, :sweep, :grid)[out[1] + 1], cells_per_axis = out[2], in_grid = out[3], tail = out[4],
+     rebuilds = out[5], queries = out[6], visited = out[7], evaluated = out[8])
 end
 
 "feature_ellipses(x, cov) of the browser monitor (sim/browser/wsserver.jl:72-85): 5 x N [cx; cy; rx; ry; phi], on the device."

@@ -80,6 +80,8 @@ SIGNATURES = {
     "slam_ekf_get_block": (C.c_int, [_h, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "slam_ekf_get_diag": (C.c_int, [_h, C.c_void_p]),
     "slam_ekf_get_landmark_blocks": (C.c_int, [_h, C.c_void_p]),
+    "slam_ekf_set_gate_mode": (C.c_int, [_h, C.c_int]),
+    "slam_ekf_gate_info": (C.c_int, [_h, C.POINTER(C.c_int64)]),
     "slam_ekf_get_pose": (C.c_int, [_h, _dp]),
     "slam_ekf_num_landmarks": (C.c_int, [_h, C.POINTER(C.c_int)]),
     "slam_ekf_dtype": (C.c_int, [_h, C.POINTER(C.c_int)]),

@@ -135,6 +135,17 @@ struct slam_ekf {
     double* d_pmax;      // device double, >= max diag(P_ff)
     int pmax_valid;      // 0: recompute before the next sweep (upload, Joseph-form update)
 
+    // N2, the O(candidates) form: a uniform grid over the landmark means (ekf_gate.hip)
+    int gate_mode;       // SLAM_GATE_AUTO / SLAM_GATE_SWEEP / SLAM_GATE_GRID
+    int gate_last;       // the form the last gating used
+    void* grid_meta;     // device GridMeta (origin, cell size, drift bound, counters, the updates' displacement slots)
+    int32_t* grid_cells; // [G*G + 1] first item of every cell
+    void* grid_items;    // [maxN]    GridItem: landmark index + its mean at build time, sorted by cell
+    int grid_force;      // rebuild at the next query (state upload, too many updates between two queries)
+    int grid_upd;        // updates enqueued since the last query (their displacement bounds: GridMeta::slot[0 .. grid_upd))
+    int grid_live;       // a grid exists: updates record their displacement bounds
+    int grid_n_seen;     // N when the fold / rebuild check was last enqueued
+
     // gating partials
     double* gate_part;   // [gate_blocks][ocap][3]
     int gate_blocks_cap;
@@ -182,6 +193,11 @@ int launch_augment(slam_ekf* h, int nn, const double R[4], const double* zn_dev)
 int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gate2, const double* z_host, bool compact);
 // z_src: device-readable (obsbuf or pinned host); compact (observe()): d_assoc -> idfbuf/obsbuf (matched, in order),
 // znbuf (new), d_count = {m, nn}, h_assoc (pinned) -- done by the last gate_final launch
+constexpr int SLAM_GRID_SLOTS = 64;    // updates whose displacement bounds the grid keeps apart; an update's bound is the max over
+                                       // 16 words SLAM_GRID_SLOTS apart (ekf_gate.hip: GridMeta::slot[sub][update])
+int gate_kernels_init();
+int gate_info(slam_ekf* h, int64_t out[8]);
+unsigned long long* grid_drift_slot(slam_ekf* h);   // where the update about to be enqueued records its largest landmark displacement (null: no grid)
 int ensure_pmax(slam_ekf* h);       // the pre-gate's variance bound is current
 int launch_nis(slam_ekf* h, const double z1[2], int j, const double R[4]);
 int launch_obs_model(slam_ekf* h, int j);

@@ -217,6 +217,7 @@ extern "C" int slam_ekf_destroy(slam_ekf_t h) {
     dev_free(h->x); dev_free(h->P); dev_free(h->Pside); dev_free(h->tiles);
     dev_free(h->obsbuf); dev_free(h->idfbuf); dev_free(h->d_assoc); dev_free(h->gate_part); dev_free(h->znbuf);
     dev_free(h->d_small); dev_free(h->d_status); dev_free(h->d_count); dev_free(h->d_pmax); dev_free(h->dd_claim);
+    dev_free(h->grid_meta); dev_free(h->grid_cells); dev_free(h->grid_items);
     if (h->h_flag) (void)hipHostFree(h->h_flag);
     if (h->h_obs) (void)hipHostFree(h->h_obs);
     if (h->h_idf) (void)hipHostFree(h->h_idf);
@@ -239,6 +240,7 @@ static int create_impl(slam_ekf* h) {
     HIP_TRY(hipEventCreateWithFlags(&h->stage_ev, hipEventDisableTiming | hipEventDisableSystemFence));
     int rc;
     if ((rc = update_kernels_init())) return rc;
+    if ((rc = gate_kernels_init())) return rc;
     if ((rc = dev_alloc_zero(&h->x, h->esz * (size_t)h->ncap, h->stream))) return rc;
     {   // tile-major, block lower (device_math.h): T (T + 1) / 2 tiles of E x E elements
         const int E = h->dtype == SLAM_F32 ? 128 : 64;
@@ -295,6 +297,8 @@ extern "C" int slam_ekf_create(slam_ekf_t* out, int dtype, int max_landmarks, in
     h->gate_part = nullptr; h->gate_blocks_cap = 0;
     h->d_small = h->h_small = nullptr;
     h->d_pmax = nullptr; h->pmax_valid = 0; h->dd_claim = nullptr;
+    h->gate_mode = SLAM_GATE_AUTO; h->gate_last = 0; h->grid_meta = nullptr; h->grid_cells = nullptr; h->grid_items = nullptr;
+    h->grid_force = 1; h->grid_upd = 0; h->grid_live = 0; h->grid_n_seen = 0;
     h->znbuf = nullptr; h->d_count = nullptr; h->h_flag = nullptr; h->h_flag_dev = nullptr; h->obs_seq = 0;
     h->d_status = h->h_status = nullptr;
     h->async_updates = 0; h->deferred = 0; h->pending_status = 0; h->debug_stamps = 0;
@@ -376,6 +380,7 @@ static int set_state_impl(slam_ekf* h, const void* x, const void* P, int n, int 
     }
     h->N = N;
     h->pmax_valid = 0;                  // the pre-gate's variance bound belongs to the old matrix
+    h->grid_force = 1;                  // ... and the grid to the old means
     return SLAM_OK;
 }
 
@@ -590,6 +595,20 @@ extern "C" int slam_ekf_associate(slam_ekf_t h, const double* z, int nz, const d
     HIP_TRY(hipStreamSynchronize(h->stream));
     memcpy(assoc, h->h_assoc, sizeof(int32_t) * (size_t)nz);
     return SLAM_OK;
+}
+
+extern "C" int slam_ekf_set_gate_mode(slam_ekf_t h, int mode) {
+    ARG_CHECK(h != nullptr, "null handle");
+    ARG_CHECK(mode == SLAM_GATE_AUTO || mode == SLAM_GATE_SWEEP || mode == SLAM_GATE_GRID, "unknown gate mode");
+    h->gate_mode = mode;
+    h->grid_force = 1;          // (also the way to say "the means were written through the raw device view")
+    return SLAM_OK;
+}
+
+extern "C" int slam_ekf_gate_info(slam_ekf_t h, int64_t out[8]) {
+    ARG_CHECK(h != nullptr && out != nullptr, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    return gate_info(h, out);
 }
 
 extern "C" int slam_ekf_nis(slam_ekf_t h, const double z1[2], int j, const double R[4], double out[2]) {

@@ -800,10 +800,14 @@ __device__ __forceinline__ void split_bf16(float v, unsigned short& h, unsigned 
     l = __builtin_bit_cast(unsigned short, bl);
 }
 
+// max that keeps a NaN (fmax drops it)
+__device__ __forceinline__ double fmax_nan(double a, double b) { return (a != a || a > b) ? a : b; }
+
 template <typename TO, int NCB>      // NCB = kp / 16
 __device__ __forceinline__ void w1_mfma_body(const double* __restrict__ PHt, int pitchA, const double* __restrict__ Cmat,
                                              int pitchC, double* sC, TO* __restrict__ W1, int pitchW, TO* __restrict__ x,
-                                             int n, const double* __restrict__ g, char* __restrict__ img, int img_nch) {
+                                             int n, const double* __restrict__ g, char* __restrict__ img, int img_nch,
+                                             unsigned long long* __restrict__ drift) {
     constexpr int kp = 16 * NCB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, kk = lane >> 4;
@@ -875,7 +879,31 @@ __device__ __forceinline__ void w1_mfma_body(const double* __restrict__ PHt, int
     }
     sx += __shfl_xor(sx, 16);
     sx += __shfl_xor(sx, 32);
-    if (kk == 0 && r0 + i < n) x[r0 + i] = (TO)((double)x[r0 + i] + sx);
+    double moved = 0.0;
+    if (kk == 0 && r0 + i < n) {
+        const double xo = (double)x[r0 + i];
+        const TO xn = (TO)(xo + sx);
+        x[r0 + i] = xn;
+        if (r0 + i >= 3) moved = fabs((double)xn - xo);        // a landmark coordinate, as stored
+    }
+    if (drift) {
+        // the grid form of the gating (ekf_gate.hip) widens its boxes by how far the means have moved since the grid
+        // was built: the largest displacement of this update (bit pattern of a non-negative double orders like the
+        // integer; a NaN sorts above everything and makes the next fold rebuild).  One atomic per WORKGROUP, spread over
+        // 16 words in different cache lines: one atomic per wave to one address cost this kernel 12 us at n = 20k.
+        __shared__ double s_moved[W1_THREADS / 64];
+        moved = fmax_nan(moved, __shfl_xor(moved, 1));
+        moved = fmax_nan(moved, __shfl_xor(moved, 2));
+        moved = fmax_nan(moved, __shfl_xor(moved, 4));
+        moved = fmax_nan(moved, __shfl_xor(moved, 8));
+        if (lane == 0) s_moved[wave] = moved;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int w = 1; w < W1_THREADS / 64; ++w) moved = fmax_nan(moved, s_moved[w]);
+            if (!(moved == 0.0)) atomicMax(drift + (blockIdx.x & 15) * SLAM_GRID_SLOTS, (unsigned long long)__double_as_longlong(moved));
+        }
+    }
 }
 
 template <typename TO>
@@ -885,7 +913,8 @@ __global__ __launch_bounds__(W1_THREADS) void w1_mfma_kernel(const double* __res
                                                              const double* __restrict__ g,
                                                              const int32_t* __restrict__ status,
                                                              const int32_t* __restrict__ dcount, char* __restrict__ img,
-                                                             int img_nch, unsigned* __restrict__ dd_claim) {
+                                                             int img_nch, unsigned* __restrict__ dd_claim,
+                                                             unsigned long long* __restrict__ drift) {
     // the tile counters of the down-date that follows (its persistent grid claims tiles from them): zeroed here, one
     // launch ahead, instead of by a memset node of its own in front of the dominant kernel
     if (dd_claim && blockIdx.x == 0 && threadIdx.x < 128) dd_claim[threadIdx.x] = 0u;
@@ -897,10 +926,10 @@ __global__ __launch_bounds__(W1_THREADS) void w1_mfma_kernel(const double* __res
     }
     extern __shared__ double sC[];                    // [kp][kp], staged inside the body
     // (the barrier is inside the body, after the wave's PHt loads have been issued)
-    if (kp == 32) w1_mfma_body<TO, 2>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g, img, img_nch);
-    else if (kp == 64) w1_mfma_body<TO, 4>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g, img, img_nch);
-    else if (kp == 96) w1_mfma_body<TO, 6>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g, img, img_nch);
-    else w1_mfma_body<TO, 8>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g, img, img_nch);
+    if (kp == 32) w1_mfma_body<TO, 2>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g, img, img_nch, drift);
+    else if (kp == 64) w1_mfma_body<TO, 4>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g, img, img_nch, drift);
+    else if (kp == 96) w1_mfma_body<TO, 6>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g, img, img_nch, drift);
+    else w1_mfma_body<TO, 8>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g, img, img_nch, drift);
 }
 
 // x += PHt * g      (ekf.jl:74 with W*v = PHt*(C*C'*v)); 8 lanes per row
@@ -908,7 +937,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void x_update_kernel(T* __restrict__ x, const double* __restrict__ PHt, int pitch, int n,
                                                         int k, const double* __restrict__ g,
                                                         const int32_t* __restrict__ status,
-                                                        const int32_t* __restrict__ dcount) {
+                                                        const int32_t* __restrict__ dcount,
+                                                        unsigned long long* __restrict__ drift) {
     if (status[0] != 0) return;
     if (dcount) k = 2 * dcount[0];
     const int r = blockIdx.x * 32 + (threadIdx.x >> 3);
@@ -921,7 +951,25 @@ __global__ __launch_bounds__(256) void x_update_kernel(T* __restrict__ x, const 
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
     s += __shfl_xor(s, 4);
-    if (part == 0 && r < n) x[r] = (T)((double)x[r] + s);
+    double moved = 0.0;
+    if (part == 0 && r < n) {
+        const double xo = (double)x[r];
+        const T xn = (T)(xo + s);
+        x[r] = xn;
+        if (r >= 3) moved = fabs((double)xn - xo);
+    }
+    if (drift) {                // (see w1_mfma_body)
+        __shared__ double s_moved[4];
+        moved = fmax_nan(moved, __shfl_xor(moved, 8));
+        moved = fmax_nan(moved, __shfl_xor(moved, 16));
+        moved = fmax_nan(moved, __shfl_xor(moved, 32));
+        if ((threadIdx.x & 63) == 0) s_moved[threadIdx.x >> 6] = moved;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w) moved = fmax_nan(moved, s_moved[w]);
+            if (!(moved == 0.0)) atomicMax(drift + (blockIdx.x & 15) * SLAM_GRID_SLOTS, (unsigned long long)__double_as_longlong(moved));
+        }
+    }
 }
 
 template <typename T>
@@ -936,6 +984,7 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form, const int32_t*
     T* W1 = (T*)h->W1;
     T* W2 = (T*)h->W2;
     const bool joseph = form == SLAM_FORM_JOSEPH;
+    unsigned long long* drift = grid_drift_slot(h);      // the grid form of the gating follows the means (ekf_gate.hip)
 
     // K2c: the 3 + 2m rows of P*H' the factorisation needs (compact panel PHtS); the full panel is formed by the
     // fused kernel below, next to the factorisation
@@ -977,7 +1026,7 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form, const int32_t*
             hipLaunchKernelGGL(w1_mfma_kernel<T>, dim3(h->npad / 128), dim3(W1_THREADS), (size_t)kp * kp * sizeof(double),
                                h->stream, (const double*)h->PHt, pitchA, (const double*)h->Cmat, pitchA, kp, W1, pitchW, x, n,
                                (const double*)h->gvec, h->d_status, dcount, use_img ? (char*)h->Wimg : (char*)nullptr, h->kcap / 16,
-                               use_img ? h->dd_claim : (unsigned*)nullptr);
+                               use_img ? h->dd_claim : (unsigned*)nullptr, drift);
             kp_total = round_up(k, 16);
         } else if (!joseph) {
             // W1 = PHt*C
@@ -998,7 +1047,7 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form, const int32_t*
         }
         if (joseph || kp > 128)
             hipLaunchKernelGGL(x_update_kernel<T>, dim3((n + 31) / 32), dim3(256), 0, h->stream, x, h->PHt, pitchA, n, k,
-                               h->gvec, h->d_status, dcount);
+                               h->gvec, h->d_status, dcount, drift);
     }
     HIP_TRY(hipGetLastError());
     return launch_downdate(h, kp_total, W1, joseph ? (const void*)W2 : (const void*)W1, pitchW, dcount, joseph ? 1 : 0, round_up(k, 16),
@@ -1018,10 +1067,11 @@ int launch_update(slam_ekf* h, int m, const double R[4], int form, bool device_c
 int update_kernels_init() {
     // the factor kernel keeps a 128 x 129 double matrix in LDS: raise the dynamic-LDS cap
     const int big = 160 * 1024;
+    // (the W1 kernel needs 128 KiB for C at kp = 128, plus 64 bytes of static LDS: static + dynamic <= 160 KiB)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&w1_mfma_kernel<float>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, big));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, big - 1024));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&w1_mfma_kernel<double>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, big));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, big - 1024));
     // (the fused factor kernel also holds ~1.4 KiB of static LDS for its panel workgroups: static + dynamic <= 160 KiB)
     const int fbig = big - 4096;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_kernel<float, true>),

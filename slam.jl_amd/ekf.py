@@ -212,6 +212,24 @@ class EKFSlamState(SlamState):
         check(lib.slam_ekf_get_landmark_blocks(self._h, out.ctypes.data))
         return out
 
+    GATE_MODES = {"auto": 0, "sweep": 1, "grid": 2}
+
+    def set_gate_mode(self, mode):
+        """How associate / observe search the map (slam_ekf_set_gate_mode; the reference's TODO, src/data-association.jl:18-20):
+        "sweep" = every landmark, "grid" = the uniform grid over the landmark means (O(candidates)), "auto" = the grid
+        from 16384 landmarks on.  Decisions are identical in every mode."""
+        check(lib.slam_ekf_set_gate_mode(self._h, self.GATE_MODES[mode]))
+
+    def gate_info(self):
+        """slam_ekf_gate_info as a dict: which form the last gating used, the grid's size, and what the grid queries have
+        visited / fully evaluated so far."""
+        out = (C.c_int64 * 8)()
+        check(lib.slam_ekf_gate_info(self._h, out))
+        keys = ("form", "cells_per_axis", "in_grid", "tail", "rebuilds", "queries", "visited", "evaluated")
+        d = dict(zip(keys, (int(v) for v in out)))
+        d["form"] = {0: None, 1: "sweep", 2: "grid"}[d["form"]]
+        return d
+
     def device_ptrs(self):
         """(x_ptr, P_ptr, ld, stream_ptr) raw device addresses for zero-copy interop."""
         dx, dP, st = C.c_void_p(), C.c_void_p(), C.c_void_p()

@@ -859,6 +859,122 @@ def test_full_size_50k_landmarks_fp64_joseph(pkg):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_grid_gating_changes_no_decision(pkg, dtype):
+    """Row N2, the O(candidates) form (the reference's TODO, src/data-association.jl:18-20: "a balanced k-d tree lookup"):
+    with slam_ekf_set_gate_mode(SLAM_GATE_GRID) an observation visits only the landmarks of the grid cells its gate can
+    reach.  Same scenarios as the pre-gate's test: the decisions must be those of the plain sweep and of the oracle on
+    maps with tiny and with huge covariances, with observations matched, dropped (dead band), new, repeated, at a
+    negative / zero / enormous range and with an unwrapped bearing; the filter itself bit-identical after every
+    observe (updates move the means the grid was built from, add_features appends to its tail)."""
+    rng = np.random.default_rng(92)
+    N = 400
+    for scale, spread in ((1.0, 300.0), (1e-3, 300.0), (50.0, 60.0)):
+        x, P = random_state(rng, N, spread=spread)
+        P = P * scale
+        sts = {}
+        for name in ("grid", "sweep"):
+            sts[name] = pkg.EKFSlamState(x, P, dtype=dtype, max_landmarks=N + 60)
+            sts[name].set_gate_mode(name)
+        xo, Po = rounded(sts["grid"])
+        for rnd in range(5):
+            ids = rng.choice(np.arange(1, sts["grid"].N + 1), size=20, replace=False)
+            zm = noisy_obs(rng, xo, ids)
+            zd = noisy_obs(rng, xo, ids[:6]) + np.array([[0.35 * math.sqrt(scale) + 0.25], [0.0]])     # around the dead band
+            znew = np.vstack([rng.uniform(500, 900, 3), rng.uniform(-3, 3, 3)])
+            zrep = zm[:, :2] + 1e-3
+            # (a landmark initialised from a range of 1e7 has a 2 x 2 block of condition 1e10: representable in fp64 only --
+            # in fp32 its S comes out indefinite, and identical decisions are promised for positive definite S)
+            far = 1e7 if dtype == "f64" else 5e3
+            zodd = np.array([[-5.0, 0.0, far, zm[0, 3]], [0.3, -1.0, 2.0, zm[1, 3] + 2 * math.pi]])
+            z = np.hstack([zm, zd, znew, zrep, zodd])[:, rng.permutation(35)]
+            nis, nd = O.association_table_sparse(xo, Po, z, R)
+            ao = O.assoc_vector(nis, nd, 4.0, 25.0)
+            form = "joseph" if rnd % 2 else "cholesky"
+            a_grid = sts["grid"].observe(z, R, 4.0, 25.0, form=form)
+            a_sweep = sts["sweep"].observe(z, R, 4.0, 25.0, form=form)
+            assert np.array_equal(a_grid, a_sweep), f"scale {scale} round {rnd}"
+            assert np.array_equal(a_grid, ao), f"scale {scale} round {rnd} (oracle)"
+            xa, Pa = sts["grid"].download()
+            xb, Pb = sts["sweep"].download()
+            assert np.array_equal(xa, xb) and np.array_equal(Pa, Pb)
+            for st in sts.values():
+                st.predict(6.0, 0.05, 4.0, Q, 0.025)
+            xo, Po = rounded(sts["grid"])
+        info = sts["grid"].gate_info()
+        assert info["form"] == "grid" and sts["sweep"].gate_info()["form"] == "sweep"
+        assert info["queries"] == 5 and info["rebuilds"] >= 1 and info["in_grid"] + info["tail"] == sts["grid"].N
+        for st in sts.values():
+            st.close()
+
+
+def test_grid_gating_follows_the_filter(pkg):
+    """The grid form on a map large enough to be selective (6000 landmarks over 3 km, 8 landmarks per cell): the visited
+    landmarks are a small fraction of N per observation, the decisions those of the sweep through (i) updates that move
+    the means (a loose prior: the displacement bound grows until the device rebuilds the grid by itself), (ii) 70
+    updates between two queries (more than the bounds the grid keeps apart: the next query rebuilds), (iii) landmarks
+    appended by add_features (the tail) and (iv) a state upload."""
+    rng = np.random.default_rng(93)
+    N, spread = 6000, 3000.0
+    n = 3 + 2 * N
+    x = np.concatenate([[50.0, 50.0, 0.4], rng.uniform(50 - spread / 2, 50 + spread / 2, 2 * N)])
+    A = rng.normal(0, 0.6, (n, 4))
+    P = A @ A.T + 0.05 * np.eye(n)
+    sts = {}
+    for name in ("grid", "sweep"):
+        sts[name] = pkg.EKFSlamState(x, P, dtype="f32", max_landmarks=N + 400)
+        sts[name].set_gate_mode(name)
+    g, s = sts["grid"], sts["sweep"]
+
+    def both(z, what):
+        a = g.observe(z, R, 4.0, 25.0)
+        b = s.observe(z, R, 4.0, 25.0)
+        assert np.array_equal(a, b), what
+        xa, xb = g.download("x"), s.download("x")
+        assert np.array_equal(xa, xb), what
+        return a
+
+    def scene(k, n_new=4):
+        xo = g.download("x").astype(np.float64)
+        d = np.hypot(xo[3::2] - xo[0], xo[4::2] - xo[1])
+        near = np.argsort(d)[:200]
+        ids = rng.choice(near, size=k, replace=False) + 1
+        znew = np.vstack([rng.uniform(20, 120, n_new), rng.uniform(-3, 3, n_new)])
+        return np.hstack([noisy_obs(rng, xo, ids), znew])
+
+    seen = []
+    for rnd in range(12):                                         # (i) and (iii)
+        a = both(scene(24), f"round {rnd}")
+        seen.append(int((a > 0).sum()))
+        for st in sts.values():
+            st.predict(25.0, 0.02, 4.0, Q, 0.2)
+    assert max(seen) >= 12                                        # the scenes do match landmarks
+    info = g.gate_info()
+    assert info["form"] == "grid" and info["queries"] == 12
+    assert info["visited"] < 0.05 * 12 * 28 * g.N, info           # a sweep evaluates N landmarks per observation
+    assert info["evaluated"] <= info["visited"]
+    assert info["tail"] > 0 or info["rebuilds"] > 1               # the appended landmarks were in the tail at some point
+    r0 = info["rebuilds"]
+    xo = g.download("x").astype(np.float64)                              # (ii) 70 updates with known correspondences, no query
+    d = np.hypot(xo[3::2] - xo[0], xo[4::2] - xo[1])
+    near = np.argsort(d)[:100] + 1
+    for k in range(70):
+        ids = rng.choice(near, size=6, replace=False)
+        z = noisy_obs(rng, g.download("x").astype(np.float64), ids)
+        for st in sts.values():
+            st.update(z, R, ids)
+    both(scene(24), "after 70 updates")
+    assert g.gate_info()["rebuilds"] == r0 + 1
+    xd, Pd = s.download()                                         # (iv)
+    shift = np.zeros_like(xd); shift[3:] = rng.uniform(-40, 40, xd.size - 3).astype(xd.dtype)
+    for st in sts.values():
+        st.set_state(xd + shift, Pd)
+    both(scene(24, n_new=0), "after an upload")
+    assert g.gate_info()["rebuilds"] == r0 + 2
+    for st in sts.values():
+        st.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_spatial_pre_gate_changes_no_decision(pkg, monkeypatch, dtype):
     """Row N2 (the reference's TODO, src/data-association.jl:18-20): the sweep skips a landmark's covariance loads when a
     bound that needs its MEAN only proves nis > gate2 for all observations (forced on with SLAMHIP_X=64; by default it
