@@ -366,17 +366,16 @@ __global__ __launch_bounds__(64) void gate_final_kernel(
 // of a landmark coordinate (one atomicMax per wave of the kernel that applies x += W v), a query adds the bounds up
 // (`drift`) and widens box and annulus by it; landmarks appended since the build sit in a tail that every query scans.
 // The item list carries each landmark's mean AT BUILD TIME, so the annulus test needs no second round trip (the exact
-// evaluation reads the current mean together with the covariance entries).  Now and then (every 16th update, 512
-// appended landmarks, a state upload) the host puts a one-workgroup kernel in front of the query that folds the bounds
+// evaluation reads the current mean together with the covariance entries).  Now and then (every 16th update, a tail
+// of min(512, 32 + a quarter of the grid's landmarks), a state upload) the host puts a one-workgroup kernel in front of the query that folds the bounds
 // and REBUILDS the grid -- histogram in LDS, scan, scatter: a counting sort by cell -- if drift exceeds a quarter of a
-// cell or the tail 2048 landmarks.  A query costs O(landmarks in the box + tail), whatever N is, in ONE launch: the
+// cell or the tail that size.  A query costs O(landmarks in the box + tail), whatever N is, in ONE launch: the
 // per-observation decision and the compaction of the sweep's second kernel ride in the same kernel.
 constexpr int GRID_MAX_G = 128;          // cells per axis: the build's histogram (G^2 ints) sits in LDS
 constexpr int GRID_SLOTS = SLAM_GRID_SLOTS;   // updates whose displacement bounds are kept apart until the next fold
 constexpr int GRID_SUBS = 16;            // an update's bound arrives as 16 partial maxima (its workgroups spread their atomics)
 constexpr int GRID_FOLD_UPDATES = 16;    // the host enqueues the fold / rebuild check after this many updates ...
-constexpr int GRID_FOLD_APPENDED = 512;  // ... or this many appended landmarks
-constexpr int GRID_TAIL_MAX = 2048;
+constexpr int GRID_TAIL_MAX = 512;       // ... or when the tail has reached min(this, 32 + a quarter of the grid's population)
 constexpr int GRID_AUTO_N = 16384;       // SLAM_GATE_AUTO: the grid from this many landmarks on (measured)
 constexpr int GRID_BUILD_THREADS = 1024;
 constexpr int GRID_QUERY_THREADS = 256;
@@ -429,8 +428,9 @@ __global__ __launch_bounds__(GRID_BUILD_THREADS) void grid_prepare_kernel(const 
         for (int off = 32; off >= 1; off >>= 1) d += __shfl_xor(d, off);
         if (lane == 0) {
             d = (meta->drift + d) * (1.0 + 1e-12);
+            const int tail_max = min(GRID_TAIL_MAX, 32 + meta->n_built / 4);
             const bool rebuild = force || !meta->valid || !(d <= 0.25 * meta->cellmin) || N < meta->n_built ||
-                                 N - meta->n_built > GRID_TAIL_MAX;
+                                 N - meta->n_built >= tail_max;
             meta->drift = d;
             s_do = rebuild ? 1 : 0;
         }
@@ -798,8 +798,8 @@ static int launch_gate_grid(slam_ekf* h, int nz, const double R[4], double gate1
     GridItem* items = (GridItem*)h->grid_items;
     const int tlog = h->dtype == SLAM_F32 ? 7 : 6;
     KTimer t(h, SLAM_K_GATE);
-    if (h->grid_force || !h->grid_live || h->grid_upd >= GRID_FOLD_UPDATES || h->N - h->grid_n_seen >= GRID_FOLD_APPENDED ||
-        h->N < h->grid_n_seen) {
+    const int tail_max = GRID_TAIL_MAX < 32 + h->grid_n_seen / 4 ? GRID_TAIL_MAX : 32 + h->grid_n_seen / 4;
+    if (h->grid_force || !h->grid_live || h->grid_upd >= GRID_FOLD_UPDATES || h->N - h->grid_n_seen >= tail_max || h->N < h->grid_n_seen) {
         // folds the updates' displacement bounds; rebuilds the grid when they, the tail or the host say so
         const size_t lds = sizeof(int) * GRID_MAX_G * GRID_MAX_G;
         if (h->dtype == SLAM_F32)

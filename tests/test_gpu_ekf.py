@@ -612,8 +612,39 @@ def test_headless_sim_end_to_end(pkg, golden_dir, config1):
     x1, P1 = st.download()
     x2, P2 = st2.download()
     assert np.array_equal(x1, x2) and np.array_equal(P1, P2)
+    # ... and with the grid form of the gating (N2's O(candidates) form), grown from the empty map: identical again
+    st3 = pkg.EKFSlamState(S.initial_pose(wp), np.zeros((3, 3)), dtype="f64", max_landmarks=40)
+    st3.set_gate_mode("grid")
+    log3 = S.sim(st3, wp, config1["landmarks"], seed=int(config1["seed"][1]), nlaps=2, fused=True)
+    assert np.array_equal(np.array(log3.slam_track), np.array(log.slam_track)) and st3.N == 35
+    x3, P3 = st3.download()
+    assert np.array_equal(x1, x3) and np.array_equal(P1, P3)
+    assert st3.gate_info()["form"] == "grid" and st3.gate_info()["queries"] > 100
     st.close()
     st2.close()
+    st3.close()
+
+
+def test_headless_sim_dense_scene_grid_against_sweep(pkg, golden_dir):
+    """The sim! loop on a scene with 400 landmarks (fp32, one lap, fused step): the filter driven through the grid form
+    of the gating is the filter driven through the sweep, bit for bit, over its observe steps, which append landmarks
+    as the vehicle goes (tail, fold every 16th update, rebuilds decided on the device as the map grows from nothing)."""
+    S = pkg.sim
+    wp = S.get_waypoints(os.path.join(golden_dir, "course1.txt"))
+    lms = S.make_landmarks(400, (0.0, 100.0, 0.0, 100.0), 0.02, np.random.default_rng(5))
+    out = {}
+    for mode in ("sweep", "grid"):
+        st = pkg.EKFSlamState(S.initial_pose(wp), np.zeros((3, 3)), dtype="f32", max_landmarks=1500)
+        st.set_gate_mode(mode)
+        log = S.sim(st, wp, lms, seed=11, nlaps=1, fused=True)
+        out[mode] = (np.array(log.slam_track), st.download(), st.N, st.gate_info(), [a for a in log.assoc])
+        st.close()
+    assert out["grid"][2] == out["sweep"][2] and out["grid"][2] > 100
+    assert out["grid"][4] == out["sweep"][4]
+    assert np.array_equal(out["grid"][0], out["sweep"][0])
+    assert np.array_equal(out["grid"][1][0], out["sweep"][1][0]) and np.array_equal(out["grid"][1][1], out["sweep"][1][1])
+    info = out["grid"][3]
+    assert info["form"] == "grid" and info["rebuilds"] >= 4 and info["queries"] > 50
 
 
 def test_timing_hooks(pkg):
