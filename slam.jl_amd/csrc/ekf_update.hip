@@ -124,6 +124,68 @@ __global__ __launch_bounds__(128) void pht_compact_kernel(const T* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------
+// K2s (kp <= 128): S = H*P*H' + RR (ekf.jl:68) formed DIRECTLY, one workgroup per observation i (rows 2i, 2i + 1 of S),
+// one thread per column b -- the same two steps as the compact panel followed by the factor kernel's build_S, with the
+// same expressions (PHt[r][b] for the five rows r = 0, 1, 2, f_i, f_i + 1 that row pair needs, then h_i times them), but
+// spread over kp/2 CUs instead of 7 us of ONE workgroup's gathers at the head of the serial factorisation.  The pose
+// rows are recomputed by every workgroup (3 of its 5 rows): 2.5x the compact panel's gathers, all L2 hits.  Rows and
+// columns >= k: the identity (the factor kernel used to pad in LDS).  Written to the compact panel's buffer.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(128) void s_build_kernel(const T* __restrict__ x, const T* __restrict__ P, int ld,
+                                                       const int32_t* __restrict__ idf, int m, int k, int kp,
+                                                       double* __restrict__ Sg, int pitch, int tile_log2,
+                                                       const int32_t* __restrict__ dcount, double R0, double R1, double R2, double R3) {
+    SLAM_DEVICE_COUNT(dcount, m, k, kp)
+    const int i = blockIdx.x;
+    if (2 * i >= kp) return;
+    double* row0 = Sg + (size_t)(2 * i) * pitch;
+    double* row1 = row0 + pitch;
+    if (i >= m) {                                                      // padding rows
+        for (int b = threadIdx.x; b < kp; b += blockDim.x) {
+            row0[b] = (b == 2 * i) ? 1.0 : 0.0;
+            row1[b] = (b == 2 * i + 1) ? 1.0 : 0.0;
+        }
+        return;
+    }
+    const double xv = (double)x[0], yv = (double)x[1], phi = (double)x[2];
+    const int fi = 3 + 2 * (idf[i] - 1);
+    const ObsModel oi = obs_model(xv, yv, phi, (double)x[fi], (double)x[fi + 1]);
+    const int rows[5] = {0, 1, 2, fi, fi + 1};
+    for (int b = threadIdx.x; b < kp; b += blockDim.x) {
+        if (b >= k) {                                                  // padding columns
+            row0[b] = 0.0;
+            row1[b] = 0.0;
+            continue;
+        }
+        const int j = b >> 1, bb = b & 1;
+        const int fj = 3 + 2 * (idf[j] - 1);
+        const ObsModel oj = obs_model(xv, yv, phi, (double)x[fj], (double)x[fj + 1]);
+        double pr[5][5];                                               // all 25 gathers before the first use
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            pr[t][0] = (double)sym_at(P, ld, tile_log2, rows[t], 0);
+            pr[t][1] = (double)sym_at(P, ld, tile_log2, rows[t], 1);
+            pr[t][2] = (double)sym_at(P, ld, tile_log2, rows[t], 2);
+            pr[t][3] = (double)sym_at(P, ld, tile_log2, rows[t], fj);
+            pr[t][4] = (double)sym_at(P, ld, tile_log2, rows[t], fj + 1);
+        }
+        double ph[5];                                                  // PHt[rows[t]][b]   (pht_compact_kernel's expression)
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+            ph[t] = bb == 0 ? oj.Hv[0] * pr[t][0] + oj.Hv[1] * pr[t][1] + oj.Hv[2] * pr[t][2] + oj.Hf[0] * pr[t][3] + oj.Hf[1] * pr[t][4]
+                            : oj.Hv[3] * pr[t][0] + oj.Hv[4] * pr[t][1] + oj.Hv[5] * pr[t][2] + oj.Hf[2] * pr[t][3] + oj.Hf[3] * pr[t][4];
+#pragma unroll
+        for (int ra = 0; ra < 2; ++ra) {                               // (factor_body's build_S expression)
+            double sv = oi.Hv[3 * ra + 0] * ph[0] + oi.Hv[3 * ra + 1] * ph[1] + oi.Hv[3 * ra + 2] * ph[2] + oi.Hf[2 * ra + 0] * ph[3] +
+                        oi.Hf[2 * ra + 1] * ph[4];
+            if (j == i) sv += ra ? (bb ? R3 : R1) : (bb ? R2 : R0);     // RR block = R (column-major args)
+            (ra ? row1 : row0)[b] = sv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K4: one workgroup builds S, factors it and emits C = inv(chol(S)).
 //
 // Factorisation: in-place Gauss-Jordan elimination without pivoting on the SPD
@@ -510,39 +572,25 @@ __device__ __forceinline__ void factor_body(
 
     // S = H*PHt + RR (ekf.jl:68); rows/cols >= k are padded with the identity
     if constexpr (INLDS) {
-        // kp <= 128: thread (grp, b) owns column b and the observations grp, grp+G, ... (at most 16);
-        // its <= 35 loads of PHt are all issued before the first use.
-        const int G = nt / kp;
-        const int b = tid % kp, grp = tid / kp;
-        for (int a = tid >> 5; a < kp; a += nt >> 5)                    // identity padding first
-            for (int bb = tid & 31; bb < kp; bb += 32)
-                if (a >= k || bb >= k) M[(size_t)a * mp + bb] = (a == bb) ? 1.0 : 0.0;
-        if (grp < G && b < k) {
-            const double p0 = PHt[(size_t)0 * pht_pitch + b];
-            const double p1 = PHt[(size_t)1 * pht_pitch + b];
-            const double p2 = PHt[(size_t)2 * pht_pitch + b];
-            double q0[16], q1[16];
+        // kp <= 128: S was formed by s_build_kernel (kp/2 workgroups) and sits where the compact panel used to: one
+        // coalesced copy into LDS, every load in flight before the first LDS store
+        const int a0 = tid >> 5, bcol = tid & 31;                     // rows a0 + 16 u, columns bcol + 32 v
+        for (int u0 = 0; u0 < kp; u0 += 8 * (nt >> 5)) {              // (one pass at 512 threads: 32 loads per thread)
+            double v[8][4];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int i = grp + t * G;
-                const int ii = i < m ? i : 0;               // PHt is the COMPACT panel: rows 3 + 2i, 3 + 2i + 1 belong to observation i
-                q0[t] = PHt[(size_t)(3 + 2 * ii) * pht_pitch + b];
-                q1[t] = PHt[(size_t)(4 + 2 * ii) * pht_pitch + b];
-            }
+            for (int u = 0; u < 8; ++u)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int i = grp + t * G;
-                if (i < m) {
-                    const double* h = hb + 10 * i;
-#pragma unroll
-                    for (int ra = 0; ra < 2; ++ra) {
-                        double sv = h[3 * ra + 0] * p0 + h[3 * ra + 1] * p1 + h[3 * ra + 2] * p2 + h[6 + 2 * ra + 0] * q0[t] +
-                                    h[6 + 2 * ra + 1] * q1[t];
-                        if ((b >> 1) == i) sv += ra ? ((b & 1) ? R3 : R1) : ((b & 1) ? R2 : R0);   // RR block = R
-                        M[(size_t)(2 * i + ra) * mp + b] = sv;
-                    }
+                for (int w = 0; w < 4; ++w) {
+                    const int a = u0 + a0 + u * (nt >> 5), b = bcol + 32 * w;
+                    v[u][w] = (a < kp && b < kp) ? PHt[(size_t)a * pht_pitch + b] : 0.0;
                 }
-            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int a = u0 + a0 + u * (nt >> 5), b = bcol + 32 * w;
+                    if (a < kp && b < kp) M[(size_t)a * mp + b] = v[u][w];
+                }
         }
     } else {
     for (int a = tid >> 5; a < kp; a += nt >> 5)      // 32 consecutive columns per row visit: no integer division
@@ -991,8 +1039,12 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form, const int32_t*
     const int tlog = h->dtype == SLAM_F32 ? 7 : 6;
     {
         KTimer t(h, SLAM_K_PHT);
-        hipLaunchKernelGGL(pht_compact_kernel<T>, dim3(3 + 2 * m), dim3(128), 0, h->stream, x, P, h->ld, n, h->idfbuf, m, k, kp,
-                           h->PHtS, pitchA, tlog, dcount);
+        if (kp <= 128)      // S itself, kp/2 workgroups (the factor kernel copies it into LDS)
+            hipLaunchKernelGGL(s_build_kernel<T>, dim3(kp / 2), dim3(128), 0, h->stream, x, P, h->ld, h->idfbuf, m, k, kp, h->PHtS,
+                               pitchA, tlog, dcount, R[0], R[1], R[2], R[3]);
+        else                // the compact panel; the factor kernel forms S from it
+            hipLaunchKernelGGL(pht_compact_kernel<T>, dim3(3 + 2 * m), dim3(128), 0, h->stream, x, P, h->ld, n, h->idfbuf, m, k, kp,
+                               h->PHtS, pitchA, tlog, dcount);
     }
     HIP_TRY(hipGetLastError());
     {   // K4 + K2/K3 (full panel), one launch
