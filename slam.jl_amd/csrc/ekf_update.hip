@@ -855,7 +855,7 @@ template <typename TO, int NCB>      // NCB = kp / 16
 __device__ __forceinline__ void w1_mfma_body(const double* __restrict__ PHt, int pitchA, const double* __restrict__ Cmat,
                                              int pitchC, double* sC, TO* __restrict__ W1, int pitchW, TO* __restrict__ x,
                                              int n, const double* __restrict__ g, char* __restrict__ img, int img_nch,
-                                             unsigned long long* __restrict__ drift) {
+                                             unsigned long long* __restrict__ drift, int dbg) {
     constexpr int kp = 16 * NCB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, kk = lane >> 4;
@@ -896,14 +896,20 @@ __device__ __forceinline__ void w1_mfma_body(const double* __restrict__ PHt, int
                 acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][t], brow[16 * cb], acc[cb], 0, 0, 0);
         }
     }
+    // (dbg: SLAMHIP_W1DBG of the experiments build -- 1: no image stores, 2: no W1 stores; timing only, wrong numbers)
+    if (!(dbg & 2)) {
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             W1[(size_t)(r0 + 4 * r + kk) * pitchW + 16 * cb + i] = (TO)acc[cb][r];
-    if (img) {
+    }
+    if (img && !(dbg & 1)) {
         // the same panel, split into bf16 (h, m, l) and laid out as the LDS image of the split-bf16 down-date
         // (ekf_syrk.hip, "PRE-SPLIT panel"): [row block = this workgroup][chunk cb][split][row][32 B, halves swizzled]
+        // (96 two-byte stores per lane; packed into 24 eight-byte stores by two DPP exchanges per quad they cost the
+        //  same -- 25.6 against 24.6 us for the kernel, tools/gpu_r3v.sh: what the stores cost, 5.4 us with them switched
+        //  off, is their 7.7 MB draining at the end of a short kernel, not their instruction count)
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
@@ -962,7 +968,7 @@ __global__ __launch_bounds__(W1_THREADS) void w1_mfma_kernel(const double* __res
                                                              const int32_t* __restrict__ status,
                                                              const int32_t* __restrict__ dcount, char* __restrict__ img,
                                                              int img_nch, unsigned* __restrict__ dd_claim,
-                                                             unsigned long long* __restrict__ drift) {
+                                                             unsigned long long* __restrict__ drift, int dbg) {
     // the tile counters of the down-date that follows (its persistent grid claims tiles from them): zeroed here, one
     // launch ahead, instead of by a memset node of its own in front of the dominant kernel
     if (dd_claim && blockIdx.x == 0 && threadIdx.x < 128) dd_claim[threadIdx.x] = 0u;
@@ -974,10 +980,10 @@ __global__ __launch_bounds__(W1_THREADS) void w1_mfma_kernel(const double* __res
     }
     extern __shared__ double sC[];                    // [kp][kp], staged inside the body
     // (the barrier is inside the body, after the wave's PHt loads have been issued)
-    if (kp == 32) w1_mfma_body<TO, 2>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g, img, img_nch, drift);
-    else if (kp == 64) w1_mfma_body<TO, 4>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g, img, img_nch, drift);
-    else if (kp == 96) w1_mfma_body<TO, 6>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g, img, img_nch, drift);
-    else w1_mfma_body<TO, 8>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g, img, img_nch, drift);
+    if (kp == 32) w1_mfma_body<TO, 2>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g, img, img_nch, drift, dbg);
+    else if (kp == 64) w1_mfma_body<TO, 4>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g, img, img_nch, drift, dbg);
+    else if (kp == 96) w1_mfma_body<TO, 6>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g, img, img_nch, drift, dbg);
+    else w1_mfma_body<TO, 8>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g, img, img_nch, drift, dbg);
 }
 
 // x += PHt * g      (ekf.jl:74 with W*v = PHt*(C*C'*v)); 8 lanes per row
@@ -1078,7 +1084,7 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form, const int32_t*
             hipLaunchKernelGGL(w1_mfma_kernel<T>, dim3(h->npad / 128), dim3(W1_THREADS), (size_t)kp * kp * sizeof(double),
                                h->stream, (const double*)h->PHt, pitchA, (const double*)h->Cmat, pitchA, kp, W1, pitchW, x, n,
                                (const double*)h->gvec, h->d_status, dcount, use_img ? (char*)h->Wimg : (char*)nullptr, h->kcap / 16,
-                               use_img ? h->dd_claim : (unsigned*)nullptr, drift);
+                               use_img ? h->dd_claim : (unsigned*)nullptr, drift, slam_exp_env("SLAMHIP_W1DBG", 0));
             kp_total = round_up(k, 16);
         } else if (!joseph) {
             // W1 = PHt*C
