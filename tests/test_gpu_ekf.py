@@ -450,6 +450,17 @@ def test_edge_cases(pkg, dtype):
         st.update(z[:, :1], np.diag([-50.0, -50.0]), [4])
     xa, Pa = st.download()
     assert np.array_equal(xa, xb) and np.array_equal(Pa, Pb)
+    # an unknown gate mode is refused; a grid asked for with an R that is not positive definite (the bound's premise)
+    # quietly takes the sweep -- same decisions either way
+    assert pkg._lib.lib.slam_ekf_set_gate_mode(st._h, 7) == pkg._lib.SLAM_E_BADARG
+    st.set_gate_mode("grid")
+    zq = np.array([[30.0], [0.2]])
+    a1 = st.associate_vector(zq, np.diag([0.01, 0.0]), 4.0, 25.0)
+    assert st.gate_info()["form"] == "sweep"
+    a2 = st.associate_vector(zq, R, 4.0, 25.0)
+    assert st.gate_info()["form"] == "grid"
+    st.set_gate_mode("sweep")
+    assert np.array_equal(a2, st.associate_vector(zq, R, 4.0, 25.0)) and a1.shape == (1,)
     # ... and the same error deferred in async mode
     st.set_async(True)
     st.update(z[:, :1], np.diag([-50.0, -50.0]), [4])
