@@ -890,6 +890,10 @@ int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gat
     if (grid_ok && (h->gate_mode == SLAM_GATE_GRID || (h->gate_mode == SLAM_GATE_AUTO && h->N >= GRID_AUTO_N)))
         return launch_gate_grid(h, nz, R, gate1, gate2, z_host, compact);
     h->gate_last = SLAM_GATE_SWEEP;
+    if (h->grid_live) {                // the sweep is in use: updates stop recording displacements; a later grid query rebuilds
+        h->grid_live = 0;
+        h->grid_force = 1;
+    }
     // observations are swept in chunks so the LDS footprint stays bounded for any nz
     constexpr int CHUNK = GATE_CHUNK;
     for (int o = 0; o < nz; o += CHUNK) {
