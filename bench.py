@@ -615,6 +615,17 @@ def main():
     st.sync()
     stamps = st.debug_stamps(False)
     phases = [(b - a) / 100.0 for a, b in zip(stamps[:6], stamps[1:7])]     # 100 MHz ticks -> us
+    # predict (src/ekf.jl:8-43: it runs nine times as often as the update in sim!) and add_features (:84-122) are timed
+    # SEPARATELY, after the timed region: device time of their kernels by HIP events
+    Qp = np.array([[0.5 ** 2, 0.0], [0.0, (3 * math.pi / 180) ** 2]])
+    st.timing(True, kernels=["predict"])
+    st.timing_reset()
+    for _ in range(20):
+        st.predict(8.0, 0.05, 4.0, Qp, 0.025)
+    st.sync()
+    pr_ms, pr_n = st.timing_read()["predict"]
+    st.timing(False)
+    other = {"predict_us": 1e3 * pr_ms / max(pr_n, 1), "predict_calls": pr_n}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=RED_DEVICE)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -626,6 +637,19 @@ def main():
         matched_all = float(matched)
 
     st.close()
+    if not big and rank == 0:
+        # add_features needs head-room in the pre-allocated capacity: a second handle with 64 spare landmarks, same state
+        st2 = pkg.EKFSlamState(x, P, dtype=args.dtype, max_landmarks=N + 64, device=local_rank)
+        rng_af = np.random.default_rng(SEED + 31)
+        st2.add_features(np.vstack([rng_af.uniform(20, 60, 8), rng_af.uniform(-1, 1, 8)]), R)      # (warm)
+        st2.timing(True, kernels=["augment"])
+        st2.timing_reset()
+        for _ in range(6):
+            st2.add_features(np.vstack([rng_af.uniform(20, 60, 8), rng_af.uniform(-1, 1, 8)]), R)
+        st2.sync()
+        af_ms, af_n = st2.timing_read()["augment"]
+        other.update({"add_features_us": 1e3 * af_ms / max(af_n, 1), "add_features_new_per_call": 8, "add_features_calls": af_n})
+        st2.close()
 
     out = None
     if rank == 0:
@@ -686,6 +710,7 @@ def main():
             "kernel_ms_per_step": {k: v[0] / max(ndiag, 1) for k, v in tim_all.items()},
             "traffic_note": traffic_note,
             "kernel_ms_per_step_note": f"{ndiag} extra steps after the timed region with every kernel bracketed by events",
+            "other_kernels": other,
             "factor_phases_us": dict(zip(["innovation", "build_S", "symmetrise", "eliminate", "y_g", "emit_C"], phases)),
         }
         # the gating sweep (K1): 12 state values per landmark read once per sweep, nz * N pairs evaluated

@@ -9,6 +9,8 @@ for l in open(sys.argv[1]):
         print("roofline", {k: r.get(k) for k in ("bound", "achieved", "peak", "frac", "traffic", "avg_launch_ms")})
         print(" ", j.get("traffic_note"))
         print("kernels", {k: round(v * 1e3, 1) for k, v in j["kernel_ms_per_step"].items()})
+        if "other_kernels" in j:
+            print("other kernels (us)", {k: round(v, 1) for k, v in j["other_kernels"].items()})
         if "cpu_baseline" in j:
             c = j["cpu_baseline"]
             print("cpu", round(c["value"], 1), c["unit"], c["cores"], c["kind"], "| gpu/cpu", round(j.get("gpu_over_cpu", 0)))
