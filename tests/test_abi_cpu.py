@@ -51,6 +51,27 @@ def test_product_package_never_imports_the_oracle():
                 assert "ekf_ref" not in src, f
 
 
+def build_c_client(tmpdir):
+    """tests/abi_client.c compiled AS C (c99, warnings are errors) against include/slamhip.h and linked with the library
+    alone: what a cgo / ccall / JNI binding does.  Returns the executable's path."""
+    exe = os.path.join(str(tmpdir), "abi_client")
+    libdir = os.path.join(ROOT, "slam.jl_amd")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "abi_client.c"), "-o", exe, "-L", libdir, "-lslamhip", "-lm",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    return exe
+
+
+def test_plain_c_client_compiles_links_and_fails_loudly_without_a_device(pkg, tmp_path):
+    exe = build_c_client(tmp_path)
+    if pkg.device_count() > 0:
+        pytest.skip("a HIP device is present (the GPU suite runs the client)")
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 2 and "no HIP device" in res.stderr      # no silent CPU path behind the C ABI either
+
+
 def test_no_device_means_loud_failure_not_fallback(pkg):
     if pkg.device_count() > 0:
         pytest.skip("a HIP device is present")

@@ -658,6 +658,18 @@ def test_headless_sim_dense_scene_grid_against_sweep(pkg, golden_dir):
     assert info["form"] == "grid" and info["rebuilds"] >= 4 and info["queries"] > 50
 
 
+def test_plain_c_client_of_the_abi(pkg, tmp_path):
+    """tests/abi_client.c: the hand-derived KATs 1-4 of SURVEY 8c (both dtypes), the two forms of the gating, the fused
+    step and an enqueued FastSLAM step driven from PLAIN C through include/slamhip.h -- the drop-in boundary with no
+    Python, torch or C++ on the caller's side."""
+    import subprocess
+    from test_abi_cpu import build_c_client
+    exe = build_c_client(tmp_path)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "all checks passed" in res.stdout
+
+
 def test_timing_hooks(pkg):
     rng = np.random.default_rng(8)
     x, P = random_state(rng, 50)
