@@ -43,6 +43,17 @@ KAT-11 ``update`` with a ROTATED heading, an OFF-AXIS landmark and a COUPLED cov
     INFORMATION form of the same linear-Gaussian update, whose only inverses are a 2 x 2 diagonal one (R) and 5 x 5
     ones:        Lambda+ = P^-1 + H' R^-1 H,     P+ = (Lambda+)^-1,     x+ = x + P+ H' R^-1 v
     (Woodbury: (P^-1 + H' R^-1 H)^-1 = P - P H' (H P H' + R)^-1 H P, and P+ H' R^-1 = P H' S^-1 = K.)
+
+KAT-12 ``predict`` (src/ekf.jl:8-43) with a ROTATED heading, a STEERING angle, a COUPLED covariance and a landmark
+    (KAT-3 starts from x = 0, P = 0: nothing there exercises Gv P_vv Gv', the map strip Gv P_vm or sin g / cos g).
+    phi = pi/3, g = pi/6, so g + phi = pi/2: s = 1, c = 0; v = 4, dt = 0.25: v dt = 1, vts = 1, vtc = 0; w = 2:
+        x+ = [x + vtc, y + vts, mpi_to_pi(phi + v dt sin(g) / w)] = [1, 3, pi/3 + 0.25]          (:39-41, pre-update phi)
+        Gv = [[1, 0, -1], [0, 1, 0], [0, 0, 1]]                                                  (:24-26)
+        Gu = [[dt c, -vts], [dt s, vtc], [dt sin(g)/w, v dt cos(g)/w]] = [[0, -1], [1/4, 0], [1/16, sqrt(3)/4]]   (:27-29)
+    With Pvv = [[a, d, e], [d, b, f], [e, f, g0]], Pvm = [[h1, h2], [i1, i2], [j1, j2]] (KAT-10's matrix), Q = diag(q1, q2):
+        Gv Pvv Gv' = [[a - 2e + g0, d - f, e - g0], [d - f, b, f], [e - g0, f, g0]]
+        Gu Q Gu'   = q1 [[0, 0, 0], [0, 1/16, 1/64], [0, 1/64, 1/256]] + q2 [[1, 0, -r3], [0, 0, 0], [-r3, 0, 3/16]],  r3 = sqrt(3)/4
+        P_vm+ = Gv Pvm = [[h1 - j1, h2 - j2], [i1, i2], [j1, j2]],     P_mm unchanged                (:32-36)
 """
 import math
 
@@ -128,3 +139,22 @@ def kat11():
     Pp = 0.5 * (Pp + Pp.T)
     xp = x + Pp @ H.T @ Ri @ v
     return x, P, z, np.array([[1]]), xp, Pp
+
+
+def kat12():
+    """(x, P, (v, g, w, Q, dt), x_plus, P_plus): predict with heading, steering, coupled P and a landmark"""
+    a, b, g0, d, e, f = 0.30, 0.20, 0.01, 0.05, 0.02, -0.01
+    h1, h2, i1, i2, j1, j2 = 0.03, -0.02, 0.01, 0.04, 0.005, -0.003
+    _, P, _, _, _ = kat10()
+    x = np.array([1.0, 2.0, math.pi / 3, 4.0, 6.0])
+    q1, q2 = 0.5 ** 2, (3 * math.pi / 180) ** 2
+    Q = np.diag([q1, q2])
+    r3 = math.sqrt(3.0) / 4
+    xp = np.array([1.0, 3.0, math.pi / 3 + 0.25, 4.0, 6.0])
+    Pp = P.copy()
+    Pp[0:3, 0:3] = (np.array([[a - 2 * e + g0, d - f, e - g0], [d - f, b, f], [e - g0, f, g0]])
+                    + q1 * np.array([[0, 0, 0], [0, 1 / 16, 1 / 64], [0, 1 / 64, 1 / 256]])
+                    + q2 * np.array([[1, 0, -r3], [0, 0, 0], [-r3, 0, 3 / 16]]))
+    Pp[0:3, 3:5] = np.array([[h1 - j1, h2 - j2], [i1, i2], [j1, j2]])
+    Pp[3:5, 0:3] = Pp[0:3, 3:5].T
+    return x, P, (4.0, math.pi / 6, 2.0, Q, 0.25), xp, Pp

@@ -334,7 +334,7 @@ def test_observe_capacity_overflow_together_with_a_failed_update(pkg, dtype, use
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_kat8_to_kat11_through_the_abi(pkg, dtype):
+def test_kat8_to_kat12_through_the_abi(pkg, dtype):
     """The hand-derived closed forms of tests/kat_vectors.py (update with one and with two stacked observations of the
     same landmark, add_features with vehicle covariance and an existing landmark) through the C ABI."""
     tx, tP = (1e-12, 1e-12) if dtype == "f64" else (2e-6, 2e-6)
@@ -373,6 +373,14 @@ def test_kat8_to_kat11_through_the_abi(pkg, dtype):
     assert st.observe(z, KV.R, 4.0, 25.0).tolist() == [1]
     xg, Pg = st.download()
     assert np.allclose(xg, xp, rtol=t11, atol=t11 * 6.0) and np.allclose(Pg, Pp, rtol=0, atol=t11 * 0.5)
+    st.close()
+    # KAT-12: predict with a rotated heading, a steering angle, a coupled covariance and a landmark
+    x, P, (v, g, w, Qk, dtk), xp, Pp = KV.kat12()
+    st = pkg.EKFSlamState(x, P, dtype=dtype, max_landmarks=2)
+    st.predict(v, g, w, Qk, dtk)
+    xg, Pg = st.download()
+    assert np.allclose(xg, xp, rtol=0, atol=tx * 10) and np.allclose(Pg, Pp, rtol=tP, atol=tP * 0.5), np.abs(Pg - Pp).max()
+    assert np.array_equal(Pg, Pg.T) and np.array_equal(Pg[3:, 3:], P[3:, 3:].astype(Pg.dtype))
     st.close()
     x, P, zn, xp, Pp = KV.kat10()
     st = pkg.EKFSlamState(x, P, dtype=dtype, max_landmarks=2)

@@ -265,6 +265,19 @@ def test_kat10_add_features_with_vehicle_covariance_and_existing_landmark():
     assert Pp[5, 3] == pytest.approx(0.03 - 2 * 0.005) and Pp[5, 5] == pytest.approx(0.30 - 0.08 + 0.04 + 4 * KV.R[1, 1])
 
 
+def test_kat12_predict_with_heading_steering_and_coupled_covariance():
+    # src/ekf.jl:8-43 at phi = pi/3, g = pi/6 (s = 1, c = 0), v dt = 1, with KAT-10's coupled P and a landmark
+    x, P, (v, g, w, Q, dt), xp, Pp = KV.kat12()
+    for fn in (O.predict, O.predict_sparse):
+        xn, Pn = fn(x.copy(), P.copy(), v, g, w, Q, dt)
+        assert np.allclose(xn, xp, rtol=0, atol=1e-15), fn.__name__
+        assert np.allclose(Pn, Pp, rtol=1e-13, atol=1e-17), fn.__name__
+        assert np.array_equal(Pn[3:, 3:], P[3:, 3:])
+    # spot values: P+[0,0] = a - 2e + g0 + q2 = 0.30 - 0.04 + 0.01 + (3 deg)^2, P+[0,3] = h1 - j1 = 0.025
+    assert Pp[0, 0] == pytest.approx(0.27 + (3 * math.pi / 180) ** 2, rel=1e-15) and Pp[0, 3] == pytest.approx(0.025, rel=1e-15)
+    assert Pp[1, 1] == pytest.approx(0.20 + 0.25 / 16, rel=1e-15)
+
+
 def test_low_rank_covariance_view_equals_the_dense_matrix():
     """LowRankCov (test infrastructure for the N = 50k configuration: P = A A' + d I is never materialised) must index
     exactly like the dense matrix in every pattern the sparse oracle uses, and update_joseph_factors must reproduce
