@@ -249,6 +249,14 @@ function selftest()
             isapprox(xu[4], 10.0 + 0.5 / 1.51; rtol = 1e-14)
     xb, Pb = batch_update_blocks!(copy(x), Matrix(Diagonal(p)), reshape([10.5, 0.02], 2, 1), R, [1])
     @assert isapprox(xb, xu; rtol = 1e-13) && isapprox(Pb, Pu; rtol = 1e-12)
+    # KAT-12 (tests/kat_vectors.py): predict at phi = pi/3, g = pi/6 (s = 1, c = 0), v dt = 1, coupled P, one landmark
+    Pc = [0.30 0.05 0.02 0.03 -0.02; 0.05 0.20 -0.01 0.01 0.04; 0.02 -0.01 0.01 0.005 -0.003;
+          0.03 0.01 0.005 0.5 0.1; -0.02 0.04 -0.003 0.1 0.4]
+    q2 = (3pi / 180)^2
+    x12, P12 = motion_predict!([1.0, 2.0, pi / 3, 4.0, 6.0], copy(Pc), 4.0, pi / 6, 2.0, [0.25 0.0; 0.0 q2], 0.25)
+    @assert isapprox(x12, [1.0, 3.0, pi / 3 + 0.25, 4.0, 6.0]; atol = 1e-14)
+    @assert isapprox(P12[1, 1], 0.27 + q2; rtol = 1e-13) && isapprox(P12[2, 2], 0.20 + 0.25 / 16; rtol = 1e-13) &&
+            isapprox(P12[1, 4], 0.025; rtol = 1e-13) && isapprox(P12[1, 3], 0.01 - q2 * sqrt(3) / 4; rtol = 1e-12) && P12[4:5, 4:5] == Pc[4:5, 4:5]
     println("selftest ok")
 end
 
