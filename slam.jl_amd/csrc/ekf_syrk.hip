@@ -563,14 +563,18 @@ __device__ __forceinline__ void mfma_chunk_p(const DdCtx& c, const char* sm, int
 #pragma unroll
         for (int sp = 0; sp < 3; ++sp) b[sp] = *reinterpret_cast<const bf16x8*>(base + sp * IMG_ARR + (64 * c.wr + 32 * rb) * 32);
         }
-        if (!(c.xflags & 2)) __builtin_amdgcn_s_setprio(3);
+        // (experiments build, SLAMHIP_X bit 128: the priorities the other way round -- a wave is favoured while it ISSUES
+        //  memory and LDS operations and steps back during its MFMAs)
+        if (c.xflags & 128) __builtin_amdgcn_s_setprio(0);
+        else if (!(c.xflags & 2)) __builtin_amdgcn_s_setprio(3);
         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[rb], 0, 0, 0);      // (m, m)
         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[rb], 0, 0, 0);      // (h, l)
         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[rb], 0, 0, 0);      // (l, h)
         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[rb], 0, 0, 0);      // (h, m)
         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[rb], 0, 0, 0);      // (m, h)
         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[rb], 0, 0, 0);      // (h, h)
-        if (!(c.xflags & 2)) __builtin_amdgcn_s_setprio(0);
+        if (c.xflags & 128) __builtin_amdgcn_s_setprio(3);
+        else if (!(c.xflags & 2)) __builtin_amdgcn_s_setprio(0);
     }
 }
 
