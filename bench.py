@@ -682,6 +682,15 @@ def main():
                     "fp32_equivalent_TFLOPs": tflops, "frac_of_fp32_mfma_peak_157TF": tflops / MFMA_F32_PEAK_TFLOPS,
                     "bf16_mfma_TFLOPs_executed": 6.0 * tflops,        # (k padded to a multiple of 16 adds a few per cent)
                     "bf16_mfma_peak_TFLOPs": 2500.0}
+        elif args.dtype == "f32" and alg_bytes / (HBM_PEAK_GBPS * 1e9) >= alg_flops / (MFMA_F32_PEAK_TFLOPS * 1e12):
+            # small k on the fp32 matrix cores (C2: k = 32): the P traffic's floor is above the matrix work's (SURVEY 8d:
+            # "memory / launch-bound"), so HBM is the roofline that bounds the kernel
+            roof = {"kernel": "downdate (P -= W1*W1'), fp32 matrix cores, small k", "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic, "avg_launch_ms": syrk_avg_s * 1e3, "launches": syrk_n,
+                    "launches_note": f"every {TIMING_STRIDE}th step of the timed region is bracketed by HIP events",
+                    "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
+                    "fp32_mfma_TFLOPs": tflops, "frac_of_fp32_mfma_peak_157TF": tflops / MFMA_F32_PEAK_TFLOPS,
+                    "note": "a launch of ~11 us: the covariance (16 MB at C2) fits the Infinity Cache and the kernel sits at its latency floor"}
         elif args.dtype == "f32":
             roof = {"kernel": "downdate (P -= W1*W1')", "bound": "mfma", "achieved": tflops,
                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_F32_PEAK_TFLOPS,
