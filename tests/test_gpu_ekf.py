@@ -16,6 +16,7 @@ from fp64 where the oracle's own margin to a gate is below 1e-3 (none in these s
 """
 import math
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -664,6 +665,32 @@ def test_headless_sim_dense_scene_grid_against_sweep(pkg, golden_dir):
     assert np.array_equal(out["grid"][1][0], out["sweep"][1][0]) and np.array_equal(out["grid"][1][1], out["sweep"][1][1])
     info = out["grid"][3]
     assert info["form"] == "grid" and info["rebuilds"] >= 4 and info["queries"] > 50
+
+
+def test_roctx_switch(pkg):
+    """SLAMHIP_ROCTX (the one environment switch of the tracing hooks): 1 = the library loads the roctx library itself and
+    brackets its entry points with ranges, 0 = never; the results are the same either way."""
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from __graft_entry__ import load_package\n"
+        "pkg = load_package()\n"
+        "st = pkg.EKFSlamState(np.array([0.0, 0.0, 0.0, 10.0, 0.0]), np.eye(5), dtype='f64', max_landmarks=2)\n"
+        "st.predict(8.0, 0.1, 4.0, np.diag([0.25, 0.003]), 0.025)\n"
+        "st.update(np.array([[10.3], [0.01]]), np.diag([0.01, 0.0003]), [1])\n"
+        "x, P = st.download()\n"
+        "print('STATE', repr(x.tolist()), repr(float(P.sum())))\n"
+        "print('ROCTX_MAPPED', 'roctx' in open('/proc/self/maps').read())\n" % ROOT)
+    outs = {}
+    for val in ("1", "0"):
+        env = dict(os.environ, SLAMHIP_ROCTX=val)
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs[val] = {l.split(" ", 1)[0]: l.split(" ", 1)[1] for l in res.stdout.splitlines() if l.startswith(("STATE", "ROCTX_MAPPED"))}
+    assert outs["1"]["STATE"] == outs["0"]["STATE"]
+    assert outs["1"]["ROCTX_MAPPED"] == "True"
 
 
 def test_plain_c_client_of_the_abi(pkg, tmp_path):
