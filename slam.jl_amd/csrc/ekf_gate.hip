@@ -363,14 +363,15 @@ __global__ __launch_bounds__(64) void gate_final_kernel(
 // bounding box of that sector, in cells, and of the landmarks in those cells the ones inside the annulus.
 //
 // The means MOVE with every update.  The grid is not rebuilt for that: every update records the largest displacement
-// of a landmark coordinate (one atomicMax per wave of the kernel that applies x += W v), a query adds the bounds up
+// of a landmark coordinate (one atomicMax per WORKGROUP of the kernel that applies x += W v), a query adds the bounds up
 // (`drift`) and widens box and annulus by it; landmarks appended since the build sit in a tail that every query scans.
 // The item list carries each landmark's mean AT BUILD TIME, so the annulus test needs no second round trip (the exact
 // evaluation reads the current mean together with the covariance entries).  Now and then (every 16th update, a tail
-// of min(512, 32 + a quarter of the grid's landmarks), a state upload) the host puts a one-workgroup kernel in front of the query that folds the bounds
-// and REBUILDS the grid -- histogram in LDS, scan, scatter: a counting sort by cell -- if drift exceeds a quarter of a
-// cell or the tail that size.  A query costs O(landmarks in the box + tail), whatever N is, in ONE launch: the
-// per-observation decision and the compaction of the sweep's second kernel ride in the same kernel.
+// of min(512, 32 + a quarter of the grid's landmarks), a state upload) the host puts a one-workgroup kernel in front
+// of the query that folds the bounds and REBUILDS the grid -- histogram in LDS, scan, scatter: a counting sort by
+// cell -- if drift exceeds a quarter of a cell or the tail has that size.  A query costs O(landmarks in the box +
+// tail), whatever N is, in ONE launch: the per-observation decision and the compaction of the sweep's second kernel
+// ride in the same kernel.
 constexpr int GRID_MAX_G = 128;          // cells per axis: the build's histogram (G^2 ints) sits in LDS
 constexpr int GRID_SLOTS = SLAM_GRID_SLOTS;   // updates whose displacement bounds are kept apart until the next fold
 constexpr int GRID_SUBS = 16;            // an update's bound arrives as 16 partial maxima (its workgroups spread their atomics)
