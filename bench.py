@@ -320,7 +320,7 @@ def fastslam_guarded(out_partial, rank, world, *a):
             if rank == 0 and out_partial is not None:
                 out_partial["fastslam"] = {"error": f"the FastSLAM leg did not finish within {budget:.0f} s on {world} rank(s): abandoned"}
                 print(json.dumps(out_partial), flush=True)
-            os._exit(0)
+            os._exit(3)                    # a hang is a failure: the line (with fastslam.error) is out, the exit code says so
 
     timer = threading.Timer(budget, expire)
     timer.daemon = True
@@ -335,7 +335,7 @@ def fastslam_guarded(out_partial, rank, world, *a):
     return fast
 
 
-def measure_traffic(args, want_fastslam):
+def measure_traffic(args, want_fastslam, landmarks=None, obs=None, dtype=None, form=None):
     """HBM-side traffic of the dominant kernels, MEASURED in this run: two child passes of this script under
     `rocprofv3 --kernel-trace --pmc <counter>` (FETCH_SIZE and WRITE_SIZE need separate passes: TCC slots), started
     BEFORE this process touches the GPU (children are plain subprocesses).  Returns {kernel: {"fetch_kb": ..,
@@ -351,9 +351,9 @@ def measure_traffic(args, want_fastslam):
         return {"error": "rocprofv3 not found"}
     names = {"downdate_f32_mfma": "downdate", "downdate_f64_mfma": "downdate", "pf_auto_step_kernel": "pf_step"}
     out = {}
-    child = [sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-pmc",
-             "--prewarm-ms", "20", "--landmarks", str(args.landmarks), "--obs", str(args.obs), "--dtype", args.dtype,
-             "--form", args.form] + ([] if want_fastslam else ["--no-fastslam"])
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-pmc", "--no-configs",
+             "--prewarm-ms", "20", "--landmarks", str(landmarks or args.landmarks), "--obs", str(obs or args.obs),
+             "--dtype", dtype or args.dtype, "--form", form or args.form] + ([] if want_fastslam else ["--no-fastslam"])
     for counter, key in (("FETCH_SIZE", "fetch_kb"), ("WRITE_SIZE", "write_kb")):
         d = tempfile.mkdtemp(prefix="slam_pmc_", dir="/tmp")
         try:
@@ -437,6 +437,116 @@ def literal_cpu_legs(budget_s=12.0, landmarks=10000, nobs=64):
     legs.append(leg)
     return legs
 
+OTHER_CONFIGS = (
+    # BASELINE.json configs[1] and configs[4]: driver-timed beside the headline (configs[2]) in every default run
+    {"name": "C2", "landmarks": 1000, "obs": 16, "dtype": "f32", "form": "cholesky", "cpu_budget": 6.0},
+    {"name": "C5", "landmarks": 50000, "obs": 8, "dtype": "f64", "form": "joseph", "cpu_budget": 0.0},
+)
+
+
+def config_leg(pkg, cfg, steps, warmup, local_rank, pmc_rec):
+    """One of BASELINE.json's other single-GPU EKF configurations, timed like the headline: W warm-up steps, K timed
+    slam_ekf_observe steps between synchronisations, the down-date bracketed by HIP events on every 4th of them.  Returns
+    the sub-object for `configs` (ms_per_step, value, roofline with the in-run traffic of this configuration's own
+    rocprofv3 --pmc child passes, and -- where the host can hold the covariance -- cpu_baseline)."""
+    import gc
+    N, nz, dtype, form = cfg["landmarks"], cfg["obs"], cfg["dtype"], cfg["form"]
+    n = 3 + 2 * N
+    total = warmup + steps
+    big = n > 30000
+    if big:
+        st, zs = make_workload_on_device(pkg, N, nz, total, SEED, dtype, local_rank)
+        x = P = None
+    else:
+        x, P, zs = make_workload(N, nz, total, SEED)
+        st = pkg.EKFSlamState(x, P, dtype=dtype, max_landmarks=N, device=local_rank)
+    st.set_async(True)
+    gc.collect()
+    gc.disable()
+    try:
+        rng_pw = np.random.default_rng(SEED + 7919)
+        t_pw = time.perf_counter()
+        k = 0
+        while (time.perf_counter() - t_pw) < 0.05:              # device warm-up, as the headline's (shorter: the GPU is warm)
+            st.observe(zs[k % len(zs)] + rng_pw.normal(0, 1, zs[0].shape) * np.array([[0.02], [0.2 * math.pi / 180]]), R, GATE1, GATE2, form=form)
+            k += 1
+            if k % 16 == 0:
+                st.sync()
+        st.sync()
+        for i in range(warmup):
+            st.observe(zs[i], R, GATE1, GATE2, form=form)
+        st.sync()
+        st.timing_reset()
+        stride = 4
+        matched = matched_timed = 0
+        t0 = time.perf_counter()
+        for i in range(warmup, total):
+            timed = (i - warmup) % stride == 0
+            st.timing(timed, kernels=["syrk"])
+            a = st.observe(zs[i], R, GATE1, GATE2, form=form)
+            mi = int((a > 0).sum())
+            matched += mi
+            if timed:
+                matched_timed += mi
+        st.sync()
+        el = time.perf_counter() - t0
+    finally:
+        gc.enable()
+    tim = st.timing_read()
+    st.timing(True)
+    st.timing_reset()
+    nd = min(5, total)
+    for i in range(nd):
+        st.observe(zs[total - 1 - i], R, GATE1, GATE2, form=form)
+    st.sync()
+    tim_all = st.timing_read()
+    st.timing(False)
+    try:
+        floor_ms, _form = st.copy_floor(5)
+    except Exception:  # noqa: BLE001
+        floor_ms = None
+    st.close()
+    esz = 4 if dtype == "f32" else 8
+    syrk_ms, syrk_n = tim["syrk"]
+    t_dd = syrk_ms / max(syrk_n, 1) * 1e-3
+    k_avg = 2.0 * matched_timed / max(syrk_n, 1) * (2.0 if form == "joseph" else 1.0)
+    alg_bytes = 1.0 * n * n * esz
+    alg_flops = 1.0 * n * n * k_avg
+    gbps = alg_bytes / t_dd / 1e9 if t_dd > 0 else 0.0
+    traffic = hbm_bytes(pmc_rec)
+    out = {"workload": f"EKF-SLAM observation step, N={N} landmarks (n={n}), nz={nz} obs/step, {dtype}, {form} form, state resident in HBM",
+           "value": matched / el, "unit": "obs-updates/s", "ms_per_step": el / steps * 1e3, "steps_per_s": steps / el,
+           "steps": steps, "warmup": warmup, "matched_per_step": matched / steps, "dtype": dtype,
+           "roofline": {"kernel": "downdate (P -= X*Y')", "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic, "avg_launch_ms": t_dd * 1e3, "launches": syrk_n,
+                        "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_flops_per_launch": alg_flops,
+                        "copy_floor_ms": floor_ms, "kernel_over_floor": (t_dd * 1e3 / floor_ms) if floor_ms else None,
+                        "traffic_note": ("FETCH_SIZE x 2 + WRITE_SIZE per launch from this configuration's own two rocprofv3 --pmc child "
+                                         f"passes ({(pmc_rec or {}).get('launches', 0)} launches)") if traffic is not None else "not measured"},
+           "kernel_ms_per_step": {kk: v[0] / max(nd, 1) for kk, v in tim_all.items()}}
+    if N <= 2000:
+        out["roofline"]["note"] = ("a launch of ~11 us: the covariance (16 MB) fits the Infinity Cache and the kernel sits at its latency "
+                                   "floor; the step is six dependent kernels of 5-19 us")
+    if cfg.get("cpu_budget", 0) > 0 and not big:
+        out["cpu_baseline"] = cpu_baseline(x, P, zs, cfg["cpu_budget"])
+    return out
+
+
+def configs_guarded(pkg, steps, warmup, local_rank, pmc_by_cfg, budget_s=150.0):
+    """C2 and C5 after the headline, each under an exception guard and a shared wall-clock budget: whatever happens here,
+    the headline line still comes out."""
+    res = {}
+    t0 = time.perf_counter()
+    for cfg in OTHER_CONFIGS:
+        if time.perf_counter() - t0 > budget_s:
+            res[cfg["name"]] = {"error": f"skipped: the configs leg's budget of {budget_s:.0f} s was spent"}
+            continue
+        try:
+            res[cfg["name"]] = config_leg(pkg, cfg, steps, warmup, local_rank, (pmc_by_cfg or {}).get(cfg["name"]))
+        except Exception as e:  # noqa: BLE001 -- reported in the line
+            res[cfg["name"]] = {"error": f"{type(e).__name__}: {e}"}
+    return res
+
 
 def spawn_ranks(n):
     """One child process per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, the same command line; children
@@ -469,7 +579,7 @@ def spawn_ranks(n):
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
         print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
-        return 1
+        return 3 if any(c == 3 for _r, c in bad) else 1      # 3: a watchdog fired (the FastSLAM leg or the final barrier hung)
     return 0
 
 
@@ -485,6 +595,7 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="three library calls per step instead of slam_ekf_observe")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fastslam", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C2 / C5 sub-benchmarks (`configs` in the line)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
@@ -505,6 +616,13 @@ def main():
         pmc = {"error": "this run is itself under rocprofv3"}
     elif not args.no_pmc and "WORLD_SIZE" not in os.environ and args.gpus == 1:
         pmc = measure_traffic(args, not args.no_fastslam)
+    headline_cfg = args.landmarks == 10000 and args.obs == 64 and args.dtype == "f32" and args.form == "cholesky"
+    want_configs = headline_cfg and not args.no_configs and "WORLD_SIZE" not in os.environ and args.gpus == 1
+    pmc_cfg = {}
+    if want_configs and pmc is not None and "error" not in pmc and not args.no_pmc:
+        for cfg in OTHER_CONFIGS:                                 # (each configuration's own two --pmc child passes, still before this process touches the GPU)
+            rec = measure_traffic(args, False, cfg["landmarks"], cfg["obs"], cfg["dtype"], cfg["form"])
+            pmc_cfg[cfg["name"]] = rec.get("downdate") if isinstance(rec, dict) else None
 
     import torch
     import torch.distributed as dist
@@ -626,6 +744,12 @@ def main():
     pr_ms, pr_n = st.timing_read()["predict"]
     st.timing(False)
     other = {"predict_us": 1e3 * pr_ms / max(pr_n, 1), "predict_calls": pr_n}
+    # the copy floor: the bare read + rewrite of the covariance tiles the down-date touches, on THIS
+    # box, in THIS run, on the SAME buffer -- the boxes of the pool differ by +-6 %, kernel time / floor does not
+    try:
+        floor_ms, floor_form = st.copy_floor(10)
+    except Exception as e:  # noqa: BLE001 -- a diagnostic, never fatal
+        floor_ms, floor_form = None, f"{type(e).__name__}: {e}"
     gate_info = st.gate_info()             # which form of the gating the steps used (SLAM_GATE_AUTO: the grid from 16384 landmarks on)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=RED_DEVICE)
@@ -702,6 +826,11 @@ def main():
                     "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic,
                     "avg_launch_ms": syrk_avg_s * 1e3, "launches": syrk_n,
                     "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes}
+        roof["copy_floor_ms"] = floor_ms
+        roof["kernel_over_floor"] = (syrk_avg_s * 1e3 / floor_ms) if floor_ms else None
+        roof["copy_floor_note"] = (f"slam_ekf_copy_floor: every stored tile read once and written back unchanged (non-temporal, 16 B per lane, "
+                                   f"the down-date's band-major order, no panels, no matrix cores), 10 passes of each launch form on this run's "
+                                   f"own matrix; faster form: {floor_form}")
         out = {
             "metric": "EKF updates/sec @ 10k landmarks" if N == 10000 else f"EKF updates/sec @ {N} landmarks",
             "value": matched_all / elapsed,
@@ -741,6 +870,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(x, P, zs, args.cpu_budget)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             out["cpu_baseline"]["other_legs"] = literal_cpu_legs(landmarks=N, nobs=nz)
+    if want_configs and rank == 0:
+        out["configs"] = configs_guarded(pkg, max(args.steps, 20), args.warmup, local_rank, pmc_cfg)
     # the FastSLAM leg comes AFTER the headline's numbers are complete, under a deadline: whatever happens to it on a node
     # this code has never seen (ranks on several physical GPUs, IPC mappings, a peer that dies), the line still comes out
     fast = None if args.no_fastslam else fastslam_guarded(out, rank, world, pkg, world, rank, local_rank, max(args.steps, 10),
@@ -753,7 +884,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         # (a rank that failed above may have left the others' collectives out of step: do not wait for ever)
-        t = threading.Timer(90.0, lambda: os._exit(0))
+        t = threading.Timer(90.0, lambda: os._exit(3))      # (the line is out; a barrier that hangs is still a failure)
         t.daemon = True
         t.start()
         dist.barrier()

@@ -110,6 +110,16 @@ int slam_ekf_dtype(slam_ekf_t h, int* dtype);
  * block * E*E + (c % E) * E + (r % E).  Diagonal tiles are complete and symmetric.  slam_ekf_get_state /
  * slam_ekf_get_block return ordinary column-major data. */
 int slam_ekf_device_ptrs(slam_ekf_t h, void** d_x, void** d_P, int* ld, void** stream);
+/* The raw views are READ-ONLY as far as the landmarks go -- unless the caller says so afterwards.  The gating
+ * (associate / observe, src/data-association.jl:21-63) does not read the landmarks' 2 x 2 covariance blocks from d_P but
+ * from a packed side array that every writer INSIDE the library keeps, bounds the landmarks' variances with a value kept
+ * on the device, and from 16384 landmarks on visits a grid of the landmark means built earlier: a caller who writes
+ * landmark entries of x or P through the raw views (the reference's callers assign state.x / state.cov freely,
+ * sim/ekfslam-sim.jl:100,117,120) must call slam_ekf_state_written before the next associate / observe, or the
+ * decisions are made against the old values.  It rebuilds the side array from d_P, invalidates the variance bound and
+ * forces a grid rebuild (all on the device, enqueued).  Writes of the POSE entries x[0:3] / P[0:3, 0:3] and of the
+ * landmark-pose cross blocks need no call: the gating reads those from x and P. */
+int slam_ekf_state_written(slam_ekf_t h);
 
 /* ---- the hot path ----------------------------------------------------------- */
 
@@ -208,6 +218,13 @@ int slam_ekf_timing_reset(slam_ekf_t h);
 /* Diagnostics: when enabled the factorisation kernel records 100 MHz wall-clock stamps at its
  * phase boundaries; out8 (may be NULL) receives the stamps of the last update. */
 int slam_ekf_debug_stamps(slam_ekf_t h, int enable, uint64_t* out8);
+/* Measurement hook (bench.py: roofline.copy_floor_ms): the bare memory side of the covariance down-date (src/ekf.jl:75) on
+ * THIS handle's matrix -- every stored tile the down-date touches read once and written back unchanged (bit-exact), in
+ * the down-date's own band-major order, no panels, no matrix-core work; `reps` timed passes of each of two launch forms.
+ * out = {milliseconds per pass of the faster form, its index (0: one workgroup per tile, 1: persistent grid)}.  The
+ * down-date's launch time over this figure compares across the boxes of a pool whose memory systems differ by a few
+ * per cent.  Synchronises; the state is unchanged. */
+int slam_ekf_copy_floor(slam_ekf_t h, int reps, double out[2]);
 
 /* ---- FastSLAM-1.0 particle path (known correspondences) ----------------------------
  *

@@ -14,7 +14,7 @@ module SLAMHip
 
 export SlamState, EKFSlamState, set_state!, predict, update, add_features, associate,
        compute_association, predict_observation, mpi_to_pi,
-       ekf_predict!, ekf_update!, augment!, observe!, cov_block, cov_diag, landmark_blocks, gate_mode!, gate_info, feature_ellipses, vehicle_ellipse,
+       ekf_predict!, ekf_update!, augment!, observe!, cov_block, cov_diag, landmark_blocks, gate_mode!, gate_info, state_written!, feature_ellipses, vehicle_ellipse,
        PFSlamState, set_pose!, init_landmarks!, pf_predict!, update_known!, step!, step_async!, flush!,
        resample!, mean_pose, weights, particles, peer_blob, attach_peers!, peer_selftest, detach_peers!, comm_info
 
@@ -212,6 +212,17 @@ function gate_info(s::EKFSlamState)
     check(ccall((:slam_ekf_gate_info, libslamhip), Cint, (Ptr{Cvoid}, Ptr{Int64}), handle(s), out))
     (form = (nothing, :sweep, :grid)[out[1] + 1], cells_per_axis = out[2], in_grid = out[3], tail = out[4],
      rebuilds = out[5], queries = out[6], visited = out[7], evaluated = out[8])
+end
+
+"""
+    state_written!(s)
+
+After writing landmark entries of `x` / `cov` through raw device views (slam_ekf_device_ptrs): refreshes what the gating
+keeps beside the matrix (packed 2 x 2 blocks, variance bound, grid of means).  Assigning `s.x` / `s.cov` needs no call.
+"""
+function state_written!(s::EKFSlamState)
+    check(ccall((:slam_ekf_state_written, libslamhip), Cint, (Ptr{Cvoid},), handle(s)))
+    s
 end
 
 "feature_ellipses(x, cov) of the browser monitor (sim/browser/wsserver.jl:72-85): 5 x N [cx; cy; rx; ry; phi], on the device."

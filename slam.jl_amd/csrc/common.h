@@ -188,6 +188,8 @@ int launch_ellipses(slam_ekf* h, double* d_out);     // [N + 1][5]: vehicle, the
 int launch_block_gather(slam_ekf* h, int r0, int c0, int nr, int nc, int diag, void* d_out);   // dense nr x nc copy of P[r0.., c0..] (symmetric view)
 int launch_pack(slam_ekf* h, const void* d_src, int lds, int n, int cf, int ncols);    // columns [cf, cf + ncols) of the column-major matrix (d_src: that band) -> the tile-major state
 int launch_unpack(slam_ekf* h, void* d_dst, int ldd, int n, int cf, int ncols);       // columns [cf, cf + ncols) of the full symmetric matrix -> d_dst (that band, column-major)
+int launch_side_rebuild(slam_ekf* h);    // Pside <- the entries of the matrix itself (slam_ekf_state_written)
+int launch_copy_floor(slam_ekf* h, int reps, double out[2]);   // bare read + rewrite of the stored tiles, timed (ekf_syrk.hip)
 int launch_predict(slam_ekf* h, double v, double g, double w, const double Q[4], double dt);
 int launch_augment(slam_ekf* h, int nn, const double R[4], const double* zn_dev);   // zn already on the device (obsbuf or znbuf)
 int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gate2, const double* z_host, bool compact);

@@ -542,6 +542,23 @@ extern "C" int slam_ekf_device_ptrs(slam_ekf_t h, void** d_x, void** d_P, int* l
     return SLAM_OK;
 }
 
+extern "C" int slam_ekf_state_written(slam_ekf_t h) {
+    SLAM_RANGE();
+    ARG_CHECK(h != nullptr, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    h->pmax_valid = 0;                  // the pre-gate's variance bound is recomputed before the next sweep
+    h->grid_force = 1;                  // the grid of landmark means is rebuilt at the next query
+    return launch_side_rebuild(h);      // the packed 2 x 2 diagonal blocks follow the matrix again
+}
+
+extern "C" int slam_ekf_copy_floor(slam_ekf_t h, int reps, double out[2]) {
+    SLAM_RANGE();
+    ARG_CHECK(h != nullptr && out != nullptr, "null argument");
+    ARG_CHECK(reps >= 1 && reps <= 1000, "reps out of range");
+    HIP_TRY(hipSetDevice(h->device));
+    return launch_copy_floor(h, reps, out);
+}
+
 // ---- hot path ----------------------------------------------------------------------
 static int check_R(const double* R) {
     ARG_CHECK(R != nullptr, "R is null");

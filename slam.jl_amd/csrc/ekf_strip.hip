@@ -215,6 +215,32 @@ int launch_ellipses(slam_ekf* h, double* d_out) {
     return SLAM_OK;
 }
 
+// The packed 2 x 2 diagonal blocks rebuilt FROM the matrix (slam_ekf_state_written: a caller has written landmark rows of
+// P through the raw views): one thread per landmark, three reads of the diagonal tile that holds them (the landmark whose
+// two rows straddle a tile boundary takes P[f+1, f] from the tile below).
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void side_rebuild_kernel(const T* __restrict__ P, int ld, int tlog, int N, T* __restrict__ side, int side_n) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const int f = 3 + 2 * j;
+    side[j] = P[p_off(ld, tlog, f, f)];
+    side[(size_t)side_n + j] = P[p_off(ld, tlog, f + 1, f)];
+    side[(size_t)2 * side_n + j] = P[p_off(ld, tlog, f + 1, f + 1)];
+}
+}  // namespace
+
+int launch_side_rebuild(slam_ekf* h) {
+    if (h->N == 0) return SLAM_OK;
+    const dim3 grid((h->N + 255) / 256);
+    if (h->dtype == SLAM_F32)
+        hipLaunchKernelGGL(side_rebuild_kernel<float>, grid, dim3(256), 0, h->stream, (const float*)h->P, h->ld, 7, h->N, (float*)h->Pside, h->npad / 2);
+    else
+        hipLaunchKernelGGL(side_rebuild_kernel<double>, grid, dim3(256), 0, h->stream, (const double*)h->P, h->ld, 6, h->N, (double*)h->Pside, h->npad / 2);
+    HIP_TRY(hipGetLastError());
+    return SLAM_OK;
+}
+
 // columns [cf, cf + ncols) of the tile-major state (cf, ncols multiples of 32; up to npad: the zero padding is written too)
 // from d_src, which holds that band column-major with leading dimension lds
 int launch_pack(slam_ekf* h, const void* d_src, int lds, int n, int cf, int ncols) {

@@ -1032,7 +1032,80 @@ int ensure_tile_order(slam_ekf* h, int T) {
     return SLAM_OK;
 }
 
+// ---- the copy floor (bench.py: roofline.copy_floor_ms) -------------------------------------------------------------------
+// What the memory system alone asks for the down-date's P traffic ON THIS BOX, IN THIS RUN, on the handle's own buffer: every
+// stored tile read once and written back unchanged (x * one, `one` = 1.0 from the kernel arguments so that the store is
+// not elided; bit-exact for every value), 16 bytes per lane, non-temporal like the kernel's own P accesses, in the order
+// the split-bf16 down-date walks them (band-major = one linear stream through the tile-major matrix).  No panels, no
+// MFMAs, no LDS.  Two launch forms, as tools/micro_tilewalk.hip found them to differ: one workgroup per tile from the
+// dispatcher, and the persistent grid of two workgroups per CU.  The boxes of the pool differ by +-6 %: the down-date's
+// time divided by this floor does not.
+template <typename T>
+__global__ __launch_bounds__(512) void tile_copy_floor_kernel(T* __restrict__ P, long long ntiles, int tile_elems, T one) {
+    typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
+    constexpr int VE = 16 / sizeof(T);
+    const int per_thread = tile_elems / VE / 512;            // fp32 128 x 128: 8;  fp64 64 x 64: 4
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        vec_t* base = reinterpret_cast<vec_t*>(P + (size_t)t * tile_elems);
+        vec_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (u < per_thread) v[u] = __builtin_nontemporal_load(base + u * 512 + threadIdx.x);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (u < per_thread) __builtin_nontemporal_store(v[u] * one, base + u * 512 + threadIdx.x);
+    }
+}
+
 }  // namespace
+
+// out = {milliseconds per pass of the faster launch form, 0 = one workgroup per tile / 1 = persistent}.  Synchronises.
+int launch_copy_floor(slam_ekf* h, int reps, double out[2]) {
+    const int n = 3 + 2 * h->N;
+    const int tlog = h->dtype == SLAM_F32 ? 7 : 6, E = 1 << tlog;
+    const long long T = (n + E - 1) / E;                       // tile rows in use
+    const long long Tall = h->ld >> tlog;                      // tile rows of the allocation
+    // Column band J stores its tiles from the diagonal one down: T - J of its Tall - J tiles are in use.  A map that fills
+    // its capacity (the benchmark's case) is ONE contiguous run of T (T + 1) / 2 tiles = one launch; otherwise one launch
+    // per band over the band's in-use prefix.
+    auto one_pass = [&](int form) {
+        for (long long J = 0; J < (Tall == T ? 1 : T); ++J) {
+            const long long cnt = Tall == T ? T * (T + 1) / 2 : T - J;
+            char* base = (char*)h->P + h->esz * tile_base((int)J, (int)J, (int)Tall, tlog);
+            const long long grid = form == 0 ? cnt : std::min<long long>(cnt, 2 * h->num_cus);
+            if (h->dtype == SLAM_F32)
+                hipLaunchKernelGGL(tile_copy_floor_kernel<float>, dim3((unsigned)grid), dim3(512), 0, h->stream, (float*)base, cnt, E * E, 1.0f);
+            else
+                hipLaunchKernelGGL(tile_copy_floor_kernel<double>, dim3((unsigned)grid), dim3(512), 0, h->stream, (double*)base, cnt, E * E, 1.0);
+        }
+    };
+    hipEvent_t a = nullptr, b = nullptr;
+    HIP_TRY(hipEventCreate(&a));
+    hipError_t e = hipEventCreate(&b);
+    double best = 1e30;
+    int best_form = 0;
+    for (int form = 0; form < 2 && e == hipSuccess; ++form) {
+        one_pass(form);                                                     // warm-up
+        one_pass(form);
+        e = hipEventRecord(a, h->stream);
+        for (int r = 0; r < reps; ++r) one_pass(form);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(b, h->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(b);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+        if (e == hipSuccess && ms / reps < best) { best = ms / reps; best_form = form; }
+    }
+    (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    if (e != hipSuccess) {
+        slam_set_error("HIP error in the copy-floor measurement: %s", hipGetErrorString(e));
+        return SLAM_E_HIP;
+    }
+    out[0] = best;
+    out[1] = (double)best_form;
+    return SLAM_OK;
+}
 
 int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int pitch, const int32_t* dcount, int joseph, int k16,
                     const void* img) {

@@ -384,6 +384,18 @@ class EKFSlamState(SlamState):
                 mask |= 2 << _lib.KERNEL_IDS[name]
         check(lib.slam_ekf_timing(self._h, mask))
 
+    def state_written(self):
+        """Tell the library that landmark entries of x / P were written through the raw device views
+        (:meth:`device_ptrs`): the gating's side array, variance bound and grid are refreshed on the device."""
+        check(lib.slam_ekf_state_written(self._h))
+
+    def copy_floor(self, reps=10):
+        """Bare read + rewrite of the stored covariance tiles (the memory side of the down-date, nothing else), timed on
+        this handle's own matrix: ``(milliseconds per pass, launch form)``.  The state is unchanged."""
+        out = (C.c_double * 2)()
+        check(lib.slam_ekf_copy_floor(self._h, int(reps), out))
+        return float(out[0]), ("one workgroup per tile", "persistent grid")[int(out[1])]
+
     def debug_stamps(self, enable=True):
         """Diagnostics: 100 MHz wall-clock stamps of the factorisation kernel's phases (last update)."""
         out = (C.c_uint64 * 8)()

@@ -54,6 +54,20 @@ KAT-12 ``predict`` (src/ekf.jl:8-43) with a ROTATED heading, a STEERING angle, a
         Gv Pvv Gv' = [[a - 2e + g0, d - f, e - g0], [d - f, b, f], [e - g0, f, g0]]
         Gu Q Gu'   = q1 [[0, 0, 0], [0, 1/16, 1/64], [0, 1/64, 1/256]] + q2 [[1, 0, -r3], [0, 0, 0], [-r3, 0, 3/16]],  r3 = sqrt(3)/4
         P_vm+ = Gv Pvm = [[h1 - j1, h2 - j2], [i1, i2], [j1, j2]],     P_mm unchanged                (:32-36)
+
+KAT-13 ``compute_association`` / ``associate`` (src/data-association.jl:53-63, :21-50) with a NON-SYMMETRIC innovation
+    covariance.  :59-60 form ``S = H*P*H' + R`` and ``nis = dot(v, inv(S)*v)`` WITHOUT symmetrising S (``update`` does
+    symmetrise, src/ekf.jl:69; the association does not), so a P_vv or an R whose two off-diagonal entries differ gives
+    S[1,2] != S[2,1] and  inv(S) = [[s22, -s12], [-s21, s11]] / (s11 s22 - s12 s21):
+        nis = (s22 v1^2 - (s12 + s21) v1 v2 + s11 v2^2) / (s11 s22 - s12 s21)            (1-based, the reference's indices)
+    -- NOT the value a symmetrised S' = (S + S')/2 gives (its determinant is s11 s22 - ((s12 + s21)/2)^2).
+    KAT-2's geometry: x = [0, 0, 0, 10, 0], H = [[-1, 0, 0, 1, 0], [0, -0.1, -1, 0, 0.1]], H H' = diag(2, 1.02).
+    P = I + a e1 e2' + b e2 e1' (only P[1,2] = a and P[2,1] = b differ from the identity): H e1 = (-1, 0)', H e2 = (0, -0.1)',
+        H P H' = diag(2, 1.02) + a (H e1)(H e2)' + b (H e2)(H e1)' = [[2, 0.1 a], [0.1 b, 1.02]]
+    and R = [[r11, r12], [r21, r22]] is added entry by entry:  S = [[2 + r11, 0.1 a + r12], [0.1 b + r21, 1.02 + r22]].
+    With a = 4, b = -2, r12 = 0.1, r21 = -0.1:  s12 = 0.5, s21 = -0.3: det S = s11 s22 + 0.15, the symmetrised
+    determinant is s11 s22 - 0.01 -- the two nis differ by 8 %, and gate1 is put between them: the reference's rule
+    matches the observation, a symmetrising implementation would drop it.
 """
 import math
 
@@ -158,3 +172,25 @@ def kat12():
     Pp[0:3, 3:5] = np.array([[h1 - j1, h2 - j2], [i1, i2], [j1, j2]])
     Pp[3:5, 0:3] = Pp[0:3, 3:5].T
     return x, P, (4.0, math.pi / 6, 2.0, Q, 0.25), xp, Pp
+
+
+# ---- KAT-13 -------------------------------------------------------------------------------------------------
+def kat13():
+    """(x, P, R13, z (2,), nis, nd, nis_if_symmetrised, gate1, gate2): one landmark, non-symmetric P_vv and R"""
+    a, b = 4.0, -2.0
+    r11, r22, r12, r21 = R[0, 0], R[1, 1], 0.1, -0.1
+    x = np.array([0.0, 0.0, 0.0, 10.0, 0.0])
+    P = np.eye(5)
+    P[0, 1] = a
+    P[1, 0] = b
+    R13 = np.array([[r11, r12], [r21, r22]])
+    s11, s12, s21, s22 = 2.0 + r11, 0.1 * a + r12, 0.1 * b + r21, 1.02 + r22
+    v1, v2 = 1.5, 1.0                                    # z = zhat + v, zhat = (10, 0)
+    det = s11 * s22 - s12 * s21
+    nis = (s22 * v1 * v1 - (s12 + s21) * v1 * v2 + s11 * v2 * v2) / det
+    nd = nis + math.log(det)
+    sm = 0.5 * (s12 + s21)
+    det_s = s11 * s22 - sm * sm
+    nis_s = (s22 * v1 * v1 - 2.0 * sm * v1 * v2 + s11 * v2 * v2) / det_s
+    gate1 = 0.5 * (nis + nis_s)                          # nis < gate1 < nis_s
+    return x, P, R13, np.array([10.0 + v1, v2]), nis, nd, nis_s, gate1, 25.0

@@ -178,6 +178,114 @@ def test_gating_rules_through_the_abi(pkg, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_kat13_non_symmetric_innovation_covariance_through_the_abi(pkg, dtype):
+    """KAT-13 (tests/kat_vectors.py): src/data-association.jl:59-60 inverts S = H*P*H' + R WITHOUT symmetrising it.
+    A P_vv and an R whose off-diagonal entries differ give S[1,2] != S[2,1]; nis / nd must be the hand-derived values of
+    the non-symmetric inverse, and with gate1 between that nis and the one a symmetrised S would give, the observation is
+    MATCHED (a symmetrising kernel would drop it).  The inputs are exact in fp32 too (small dyadic / decimal values are
+    rounded once, the geometry is evaluated in double), so fp32 is held to 1e-6."""
+    x, P, R13, z, nis, nd, nis_s, gate1, gate2 = KV.kat13()
+    assert nis < gate1 < nis_s                              # the KAT separates the two rules
+    st = pkg.EKFSlamState(x, P, dtype=dtype, max_landmarks=4)
+    xg, Pg = st.download()
+    assert Pg[0, 1] == P[0, 1] and Pg[1, 0] == P[1, 0]      # both triangles of the pose block are state
+    rt = 1e-12 if dtype == "f64" else 1e-6
+    got_nis, got_nd = st.compute_association(z, R13, 1)
+    assert got_nis == pytest.approx(nis, rel=rt) and got_nd == pytest.approx(nd, rel=rt)
+    for mode in ("sweep", "grid"):                          # the grid form evaluates candidates with the same pair code
+        st.set_gate_mode(mode)
+        a = st.associate_vector(z.reshape(2, 1), R13, gate1, gate2)
+        assert a.tolist() == [1], mode
+        a = st.associate_vector(z.reshape(2, 1), R13, 0.5 * (nis + 0.0), gate2)      # gate1 below nis: dead band -> dropped
+        assert a.tolist() == [0], mode
+    st.close()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_state_written_refreshes_what_the_gating_keeps_beside_the_matrix(pkg, dtype):
+    """slam_ekf_state_written (include/slamhip.h): a caller who writes landmark entries of P through the raw device views
+    must say so -- the gating reads the landmarks' 2 x 2 blocks from a packed side array, not from the matrix.  Here the
+    blocks are rewritten behind the library's back (torch views over the raw pointers): before the call the side array
+    still holds the old values, after it it equals the matrix bit for bit and the decisions follow the new covariance."""
+    import torch
+    rng = np.random.default_rng(5)
+    N = 40
+    x, P = random_state(rng, N)
+    st = pkg.EKFSlamState(x, P, dtype=dtype, max_landmarks=N)
+    xr, Pr = rounded(st)
+    ids = rng.choice(np.arange(1, N + 1), 6, replace=False)
+    z = noisy_obs(rng, xr, ids)
+    a0 = st.associate_vector(z, R, 4.0, 25.0)
+    d_x, d_P, ld, _stream = st.device_ptrs()
+    E = 128 if dtype == "f32" else 64
+    tdt = torch.float32 if dtype == "f32" else torch.float64
+    T = ld // E
+    ntiles = T * (T + 1) // 2
+    # a torch view over the tile-major buffer (slam_ekf_device_ptrs documents the layout); tile (0, 0) is block 0
+    class _Raw:
+        __cuda_array_interface__ = {"shape": (ntiles * E * E,), "typestr": "<f4" if dtype == "f32" else "<f8", "data": (d_P, False), "version": 2}
+    view = torch.as_tensor(_Raw(), device="cuda")
+    assert view.dtype == tdt
+    st.sync()
+    # inflate every landmark variance inside tile (0, 0) by 400: P[f, f] *= 400 for the landmarks whose rows lie in the first tile
+    nloc = min(N, (E - 3) // 2)
+    f = 3 + 2 * np.arange(nloc)
+    for ff in (f, f + 1):
+        idx = torch.as_tensor(ff * E + ff, device="cuda")
+        view[idx] = view[idx] * 400.0
+    torch.cuda.synchronize()
+    Pn = Pr.copy()
+    Pn[f, f] *= 400.0
+    Pn[f + 1, f + 1] *= 400.0
+    blk = st.landmark_blocks()
+    assert not np.array_equal(blk[0][:nloc], Pn[f, f].astype(st.np_dtype))          # the side array is stale ...
+    st.state_written()
+    _x2, Pg = st.download()
+    check_side(st, Pg, "after slam_ekf_state_written")                              # ... and current after the call
+    assert np.array_equal(np.asarray(Pg, dtype=np.float64)[f, f], Pn[f, f].astype(st.np_dtype).astype(np.float64))
+    for mode in ("sweep", "grid"):
+        st.set_gate_mode(mode)
+        a1 = st.associate_vector(z, R, 4.0, 25.0)
+        zf_o, idf_o, zn_o = O.associate_sparse(xr, np.asarray(Pg, dtype=np.float64), z, R, 4.0, 25.0)
+        got_idf = a1[a1 > 0]
+        assert got_idf.tolist() == idf_o.reshape(-1).tolist() and int((a1 < 0).sum()) == zn_o.shape[1], mode
+    assert a0.shape == a1.shape
+    st.close()
+
+
+def test_consecutive_fp32_observation_steps_on_the_bench_workload(pkg):
+    """The bench workload runs hundreds of consecutive fp32 observation steps on ONE filter; a single update at C3 size is
+    checked elsewhere.  Here: bench.py's own workload generator, 50 consecutive slam_ekf_observe steps at C2 size (N = 1000,
+    16 observations) and 5 at C3 size (N = 10000, 64 observations) in fp32, against the fp64 sparse oracle started from the
+    same fp32-rounded state and fed the same observations: decisions identical at EVERY step, and at the end x <= 1e-5
+    (max-relative), P <= 1e-4 on relerr_cov, the side array bit-equal to the matrix."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench as B
+    for N, nz, steps in ((1000, 16, 50), (10000, 64, 5)):
+        x, P, zs = B.make_workload(N, nz, steps, B.SEED)
+        st = pkg.EKFSlamState(x, P, dtype="f32", max_landmarks=N)
+        xo, Po = rounded(st)
+        prior = np.diag(Po).copy()
+        for k in range(steps):
+            a = st.observe(zs[k], B.R, B.GATE1, B.GATE2)
+            zf, idf, zn = O.associate_sparse(xo, Po, zs[k], B.R, B.GATE1, B.GATE2)
+            got_idf = a[a > 0]
+            assert got_idf.tolist() == idf.reshape(-1).tolist(), f"N={N} step {k}: matched landmarks differ"
+            assert int((a < 0).sum()) == zn.shape[1] and int((a == 0).sum()) == nz - idf.shape[1] - zn.shape[1], f"N={N} step {k}"
+            assert zn.shape[1] == 0                                         # (the workload never creates features)
+            xo, Po = O.update_sparse(xo, Po, zf, B.R, idf, inplace=True)
+        xg, Pg = st.download()
+        ex, eP = relerr(xg, xo), relerr_cov(Pg, Po, prior)
+        print(f"bench workload N={N}: {steps} fp32 steps, x {ex:.2e}, P {eP:.2e}")
+        assert ex <= 1e-5 and eP <= 1e-4, (N, ex, eP)
+        check_side(st, Pg, f"bench workload N={N}, after {steps} steps")
+        st.close()
+        del P, Po, Pg
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("N", [0, 1, 2, 35, 100])
 def test_single_calls_against_golden(pkg, single, dtype, N):
     t = f"N{N}"
@@ -608,7 +716,10 @@ def test_config1_replay(pkg, config1, dtype):
     check_side(st, Pg, "config 1, end of the replay")
     print(f"config1 {dtype}: worst rel err x {worst_x:.3e} P {worst_P:.3e}; association agreement {agree}/{total}")
     assert worst_x <= tol_x and worst_P <= tol_P
-    assert agree >= 0.99 * total
+    # index work is asserted EQUAL in both dtypes (fp32 measured: 1271/1271).  The margin rule of this file's header --
+    # an fp32 decision may differ only where the oracle's own margin to a gate is below 1e-3 -- has no case in this
+    # replay; if a future kernel change produces one, it has to be argued here, observation by observation.
+    assert agree == total, f"{total - agree} of {total} association decisions differ from the fp64 oracle's"
     assert st.N == 35
     st.close()
 

@@ -39,6 +39,24 @@ def test_kat2_compute_association():
     assert nd_s == pytest.approx(nd, rel=1e-13)
 
 
+def test_kat13_non_symmetric_innovation_covariance():
+    # src/data-association.jl:59-60: S = H*P*H' + R is inverted WITHOUT being symmetrised; hand-derived in tests/kat_vectors.py
+    from tests import kat_vectors as KV
+    x, P, R13, z, nis, nd, nis_s, gate1, gate2 = KV.kat13()
+    _, H = O.predict_observation(x, 1)
+    S = H @ P @ H.T + R13
+    assert S[0, 1] == pytest.approx(0.5, abs=1e-15) and S[1, 0] == pytest.approx(-0.3, abs=1e-15)
+    for fn in (O.compute_association, O.compute_association_sparse):
+        got = fn(x, P, z, R13, 1)
+        assert got[0] == pytest.approx(nis, rel=1e-13) and got[1] == pytest.approx(nd, rel=1e-13)
+    assert nis < gate1 < nis_s
+    for fn in (O.associate, O.associate_sparse):
+        zf, idf, zn = fn(x, P, z.reshape(2, 1), R13, gate1, gate2)
+        assert idf.tolist() == [[1]] and zn.shape[1] == 0          # matched (a symmetrised S would give nis_s > gate1: dropped)
+        zf, idf, zn = fn(x, P, z.reshape(2, 1), R13, 0.5 * nis, gate2)
+        assert idf.shape[1] == 0 and zn.shape[1] == 0              # dead band: gate1 <= nis <= gate2
+
+
 def test_kat3_predict():
     # src/ekf.jl:8-43 from x = 0, P = 0
     x = np.zeros(3)
