@@ -152,6 +152,22 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
     rng = np.random.default_rng(20240602)                      # same scene and observations on every rank
     lm = rng.uniform(-200, 200, (NL, 2))
     pf = pkg.PFSlamState(NP, NL, seed=20240602, dtype="f32", device=local_rank, distributed=world > 1)
+    try:
+        return _bench_fastslam_body(pkg, pf, world, rank, local_rank, steps, warmup, fence, NP, NL, M, Q, rng, lm)
+    except BaseException:
+        # never leave an attached shard to the garbage collector: the orderly close is a collective (detach, barrier) and the
+        # other ranks may be anywhere -- destroy THIS shard alone; slam_pf_destroy tells the peers first (their queued steps
+        # then fail with "a peer is gone" instead of reading freed memory)
+        try:
+            pf.shard.close()
+        except Exception:  # noqa: BLE001
+            pass
+        raise
+
+
+def _bench_fastslam_body(pkg, pf, world, rank, local_rank, steps, warmup, fence, NP, NL, M, Q, rng, lm):
+    import torch
+    import torch.distributed as dist
     pf.shard.set_pose([0.0, 0.0, 0.3])
     pf.shard.init_landmarks(lm, 0.01, 0.1)
     pose = np.array([0.0, 0.0, 0.3])
@@ -259,29 +275,36 @@ def bench_fastslam(pkg, world, rank, local_rank, steps, warmup, fence):
         # the same filter with the per-GPU particle count held at 262144 (weak scaling): the strong-scaling figure
         # above divides 52 us of sweep per step by N and leaves the per-step collective latency
         pfw = pkg.PFSlamState(NP * world, NL, seed=20240602, dtype="f32", device=local_rank, distributed=True)
-        pfw.shard.set_pose([0.0, 0.0, 0.3])
-        pfw.shard.init_landmarks(lm, 0.01, 0.1)
-        say("weak-scaling filter created")
-        for j in range(n_align):
-            pfw.step_async(0.0, 0.0, 4.0, Qs, 0.025, *obs[0], Rs, force_resample=False, prepared=prep[0])
-        pfw.flush()
-        pfw.shard.set_pose(poses[0])
-        pfw.shard.init_landmarks(lm, 0.01, 0.1)
-        pfw.shard.sync()
-        fence()
-        t0 = time.perf_counter()
-        for j in range(steps):
-            pfw.step_async(8.0, 0.0, 4.0, Qs, 0.025, *obs[j], Rs, force_resample=False, prepared=prep[j])
-        pfw.flush()
-        pfw.shard.sync()
-        fence()
-        el = time.perf_counter() - t0
-        tt = torch.tensor([el], dtype=torch.float64, device=RED_DEVICE)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
-        weak = {"particles": NP * world, "particle_steps_per_s": NP * world * steps / el, "ms_per_step": el / steps * 1e3,
-                "regime": "no_resample, 262144 particles per GPU"}
-        pfw.close()
+        try:
+            pfw.shard.set_pose([0.0, 0.0, 0.3])
+            pfw.shard.init_landmarks(lm, 0.01, 0.1)
+            say("weak-scaling filter created")
+            for j in range(n_align):
+                pfw.step_async(0.0, 0.0, 4.0, Qs, 0.025, *obs[0], Rs, force_resample=False, prepared=prep[0])
+            pfw.flush()
+            pfw.shard.set_pose(poses[0])
+            pfw.shard.init_landmarks(lm, 0.01, 0.1)
+            pfw.shard.sync()
+            fence()
+            t0 = time.perf_counter()
+            for j in range(steps):
+                pfw.step_async(8.0, 0.0, 4.0, Qs, 0.025, *obs[j], Rs, force_resample=False, prepared=prep[j])
+            pfw.flush()
+            pfw.shard.sync()
+            fence()
+            el = time.perf_counter() - t0
+            tt = torch.tensor([el], dtype=torch.float64, device=RED_DEVICE)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+            weak = {"particles": NP * world, "particle_steps_per_s": NP * world * steps / el, "ms_per_step": el / steps * 1e3,
+                    "regime": "no_resample, 262144 particles per GPU", "peers_attached": bool(pfw.shard.comm_info()["peers"])}
+            pfw.close()
+        except BaseException:                  # (as in bench_fastslam: destroy this shard alone, then report)
+            try:
+                pfw.shard.close()
+            except Exception:  # noqa: BLE001
+                pass
+            raise
     bytes_per = 24 + 8 + M * 40             # pose r/w + log-weight r/w + 5 floats read and written per observed landmark
     t_step = res["no_resample"]["ms_per_step"] * 1e-3
     return {"metric": "FastSLAM particle-steps/sec", "value": res["neff_triggered"]["particle_steps_per_s"],

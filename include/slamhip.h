@@ -360,10 +360,12 @@ int slam_pf_attach_exchange(slam_pf_t h, int rank, int world, void* page, size_t
  * devices; SURVEY 8e: one process per GPU, rank r owns the global particle ids [r n, (r + 1) n).  The library links no
  * collective library: at set-up every rank exports ONE blob (SLAM_PF_PEER_BLOB_BYTES: hipIpc handles of its pose /
  * landmark / log-weight / ancestor-table buffers and of an inbox page; raw pointers for shards of the same process),
- * the CALLER moves the blobs between the ranks (MPI_Allgather, files, torch.distributed -- 1 KB per rank, once), and
+ * the CALLER moves the blobs between the ranks (MPI_Allgather, files, torch.distributed -- 4 KB per rank, once), and
  * every rank attaches all `world` blobs in rank order (<= 8 ranks, equal slices).  After that
- *   - the per-step scalars (max, sum w, sum w^2) are written by each rank's GPU into every peer's inbox over xGMI and
- *     polled in LOCAL device memory (no host page, no PCIe);
+ *   - the per-step weight statistics travel as one record {max, sum w, sum w^2} per 1024 particles, written by each rank's
+ *     GPU into every peer's inbox over xGMI and polled in LOCAL device memory (no host page, no PCIe); every rank reduces
+ *     the same records along the same fixed tree over the global particle index, so the normalised log-weights are
+ *     bit-identical to a one-rank filter's whenever a rank's slice is a multiple of 1024 particles;
  *   - a step that resamples does so ON THE DEVICE, like a one-GPU filter: the all-gather of the log-weights is the
  *     scan kernel's loads from the peers' buffers, remote ancestors' poses and ancestor-table entries are read from
  *     their owners, and the particles' MAPS do not move at all -- a table entry is a global particle id and a remote
@@ -372,12 +374,16 @@ int slam_pf_attach_exchange(slam_pf_t h, int rank, int world, void* page, size_t
  * Entry points that need plain maps (slam_pf_download with landmarks, slam_pf_pack, slam_pf_resample_apply, the legacy
  * sweeps slam_pf_update_known / slam_pf_step / slam_pf_step_proposal, slam_pf_update_unknown, slam_pf_detach_peers) are
  * COLLECTIVE while peers are attached: every rank must call them in the same order (they first bring remote records
- * home, with barriers among the ranks' streams).  Detach (collectively) before any rank destroys its handle.
- * Limit: a peer of ANOTHER process must keep its landmark buffer (5 * n_local * max_landmarks values) below 2 GiB --
- * hipIpcOpenMemHandle of a larger allocation hangs on ROCm 7.2 (tools/ipc_gen_test.py); slam_pf_attach_peers returns
- * SLAM_E_CAPACITY instead and the caller keeps the halting flow (slam.jl_amd/pf.py does that by itself).
+ * home, with barriers among the ranks' streams).  Detach (collectively) before any rank destroys its handle; a handle
+ * destroyed while attached first tells its peers (their queued steps then fail with a "peer is gone" error instead of
+ * reading freed memory -- best effort).
+ * Limits of the IPC mappings on ROCm 7.2 (both checked BEFORE anything is opened; slam_pf_attach_peers returns
+ * SLAM_E_CAPACITY and the caller keeps the halting flow -- slam.jl_amd/pf.py does that by itself): no exported buffer of a
+ * peer in ANOTHER process may exceed 2047 MiB (hipIpcOpenMemHandle of a larger allocation never returns; the landmark records
+ * are therefore kept in chunks of at most 1 GiB, so 262144 particles x 512 landmarks per rank attach), and the inbox (the only
+ * fine-grained export) must stay within 2 MiB, i.e. n_global <= 32 M particles.
  * slam_pf_comm_info: out = {ranks, 1 if peers are attached, SLAM_PF_HALTED returns so far, resamplings so far}. */
-#define SLAM_PF_PEER_BLOB_BYTES 1024
+#define SLAM_PF_PEER_BLOB_BYTES 4096
 int slam_pf_export_peer(slam_pf_t h, void* blob);
 int slam_pf_attach_peers(slam_pf_t h, int rank, int world, const void* blobs);
 int slam_pf_detach_peers(slam_pf_t h);

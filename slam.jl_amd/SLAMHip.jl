@@ -302,7 +302,7 @@ end
 # their `peer_blob`s once (MPI.Allgather, a shared file, Distributed -- 1 KB per rank) and `attach_peers!`; from then on
 # the per-step scalars travel GPU to GPU and a resampling step stays on the device (include/slamhip.h, "peers").
 
-const SLAM_PF_PEER_BLOB_BYTES = 1024
+const SLAM_PF_PEER_BLOB_BYTES = 4096
 
 """
     PFSlamState{T}(n, max_landmarks; seed = 0, device = 0, rank = 0, world = 1)

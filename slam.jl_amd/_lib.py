@@ -22,7 +22,7 @@ SLAM_E_NOTPD = -3
 SLAM_E_HIP = -4
 SLAM_E_NOMEM = -5
 SLAM_PF_HALTED = 1
-SLAM_PF_PEER_BLOB_BYTES = 1024
+SLAM_PF_PEER_BLOB_BYTES = 4096
 SLAM_F32, SLAM_F64 = 0, 1
 SLAM_FORM_CHOLESKY, SLAM_FORM_JOSEPH = 0, 1
 KERNEL_IDS = {"gate": 0, "gate_final": 1, "predict": 2, "augment": 3, "pht": 4, "factor": 5, "w1": 6, "syrk": 7}

@@ -1040,20 +1040,21 @@ int ensure_tile_order(slam_ekf* h, int T) {
 // MFMAs, no LDS.  Two launch forms, as tools/micro_tilewalk.hip found them to differ: one workgroup per tile from the
 // dispatcher, and the persistent grid of two workgroups per CU.  The boxes of the pool differ by +-6 %: the down-date's
 // time divided by this floor does not.
+// (walks 64 KiB units -- one fp32 tile, two fp64 tiles -- so that both dtypes move the same bytes per workgroup turn)
 template <typename T>
-__global__ __launch_bounds__(512) void tile_copy_floor_kernel(T* __restrict__ P, long long ntiles, int tile_elems, T one) {
+__global__ __launch_bounds__(512) void tile_copy_floor_kernel(T* __restrict__ P, long long total_bytes, T one) {
     typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
-    constexpr int VE = 16 / sizeof(T);
-    const int per_thread = tile_elems / VE / 512;            // fp32 128 x 128: 8;  fp64 64 x 64: 4
-    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        vec_t* base = reinterpret_cast<vec_t*>(P + (size_t)t * tile_elems);
+    const long long nunits = (total_bytes + 65535) >> 16;
+    for (long long t = blockIdx.x; t < nunits; t += gridDim.x) {
+        char* base = reinterpret_cast<char*>(P) + (t << 16);
+        const bool full = (t << 16) + 65536 <= total_bytes;          // (the last unit of an odd number of fp64 tiles is half)
         vec_t v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (u < per_thread) v[u] = __builtin_nontemporal_load(base + u * 512 + threadIdx.x);
+            if (full || u < 4) v[u] = __builtin_nontemporal_load(reinterpret_cast<vec_t*>(base) + u * 512 + threadIdx.x);
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (u < per_thread) __builtin_nontemporal_store(v[u] * one, base + u * 512 + threadIdx.x);
+            if (full || u < 4) __builtin_nontemporal_store(v[u] * one, reinterpret_cast<vec_t*>(base) + u * 512 + threadIdx.x);
     }
 }
 
@@ -1072,11 +1073,12 @@ int launch_copy_floor(slam_ekf* h, int reps, double out[2]) {
         for (long long J = 0; J < (Tall == T ? 1 : T); ++J) {
             const long long cnt = Tall == T ? T * (T + 1) / 2 : T - J;
             char* base = (char*)h->P + h->esz * tile_base((int)J, (int)J, (int)Tall, tlog);
-            const long long grid = form == 0 ? cnt : std::min<long long>(cnt, 2 * h->num_cus);
+            const long long bytes = cnt * (long long)E * E * (long long)h->esz, units = (bytes + 65535) >> 16;
+            const long long grid = form == 0 ? units : std::min<long long>(units, 2 * h->num_cus);
             if (h->dtype == SLAM_F32)
-                hipLaunchKernelGGL(tile_copy_floor_kernel<float>, dim3((unsigned)grid), dim3(512), 0, h->stream, (float*)base, cnt, E * E, 1.0f);
+                hipLaunchKernelGGL(tile_copy_floor_kernel<float>, dim3((unsigned)grid), dim3(512), 0, h->stream, (float*)base, bytes, 1.0f);
             else
-                hipLaunchKernelGGL(tile_copy_floor_kernel<double>, dim3((unsigned)grid), dim3(512), 0, h->stream, (double*)base, cnt, E * E, 1.0);
+                hipLaunchKernelGGL(tile_copy_floor_kernel<double>, dim3((unsigned)grid), dim3(512), 0, h->stream, (double*)base, bytes, 1.0);
         }
     };
     hipEvent_t a = nullptr, b = nullptr;

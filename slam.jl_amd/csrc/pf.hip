@@ -42,14 +42,51 @@ constexpr int PF_CTL_MAXOBS = 64;           // = PF_AUTO_MAXOBS
 // rank's kernels can read every peer's log-weights, poses, ancestor tables and landmark records over xGMI and WRITE into
 // every peer's inbox (per-step scalars, hand-shake words): posted writes to the peer, polls of local memory.
 constexpr int PF_MAX_WORLD = 8;
+
+// ---- the landmark records: [landmark][5][n] in CHUNKS of whole landmarks ----------------------------------------------------
+// One allocation per chunk of 2^shift landmarks, every chunk below 2 GiB: hipIpcOpenMemHandle of a larger allocation never
+// returns on this runtime (ROCm 7.2, dmabuf IPC), and BASELINE.json's weak-scaling shape (262144 particles x
+// 512 landmarks per rank) is 2.5 GiB per buffer.  A filter whose buffer stays below 1 GiB has ONE chunk (every shape of the
+// fixed-size filter from two ranks on).  The table lives in device memory, is written once at create and is read through the
+// constant address space (wave-uniform index: scalar loads).
+constexpr int PF_LM_MAXC = 16;
+struct PfLmTab {
+    void* c[2][PF_LM_MAXC];      // [buffer][chunk]: the landmarks [k << shift, (k + 1) << shift), 5 rows of n values each
+    int32_t shift, nchunks;
+};
+typedef const __attribute__((address_space(4))) PfLmTab* PfLmTabK;
+template <typename T>
+struct LmView {
+    const PfLmTab* tab;
+    // the five rows of landmark l in buffer `buf` (row k at + k n)
+    __device__ __forceinline__ T* rows(int buf, int l, int64_t n) const {
+        const PfLmTabK k = (PfLmTabK)tab;
+        const int sh = k->shift;
+        return (T*)k->c[buf][l >> sh] + (size_t)(l & ((1 << sh) - 1)) * 5 * (size_t)n;
+    }
+    // row `row` of the flat [5 nl][n] view of a buffer (the eager gather / pack kernels)
+    __device__ __forceinline__ T* flat_row(int buf, int64_t row, int64_t n) const {
+        const int l = (int)(row / 5), kk = (int)(row - 5 * (int64_t)l);
+        return rows(buf, l, n) + (size_t)kk * (size_t)n;
+    }
+};
+
 struct PfInbox {                 // lives in its owner's device memory; slot [r] is written by rank r (its own too)
-    double scal[2][PF_MAX_WORLD][8];                 // per-step scalars, two parities: {max, sum w, sum w^2, tag(values, step)}
     unsigned long long ready[PF_MAX_WORLD][8];       // [r][0]: last resampling step whose step kernel rank r has COMPLETED
     unsigned long long bar[PF_MAX_WORLD][8];         // [r][0]: rank r's count of peer barriers (materialise)
+    unsigned long long gone[PF_MAX_WORLD][8];        // [r][0] != 0: rank r is destroying its handle -- its buffers are about to
+                                                     // be freed; every kernel that would touch peer memory stops with PF_ERR_PEER
 };
+// Behind the header: the ranks' 1024-particle weight records of a step (the canonical tree's nodes, see WRec), two parities:
+// double rec[2][rec_cap][4] = {m, s1, s2, tag}; record (rank r, local block j) sits at index r * ceil(n_local / 1024) + j and is
+// written by rank r's step kernel into EVERY rank's inbox.  rec_cap = ceil(n_global / 1024) + PF_MAX_WORLD.
+__host__ __device__ inline double* pf_inbox_recs(PfInbox* ib) { return reinterpret_cast<double*>(ib + 1); }
+inline size_t pf_inbox_bytes(int64_t n_global) {
+    return sizeof(PfInbox) + (size_t)2 * (size_t)((n_global + 1023) / 1024 + PF_MAX_WORLD) * 4 * sizeof(double);
+}
 struct PfPeers {                 // device memory of each rank, filled at attach time
     void* pose[PF_MAX_WORLD][2];
-    void* lm[PF_MAX_WORLD][2];
+    PfLmTab lm[PF_MAX_WORLD];     // each rank's chunk table, as THIS GPU addresses the chunks
     void* logw[PF_MAX_WORLD][2];
     int32_t* tab[PF_MAX_WORLD][2];
     PfInbox* inbox[PF_MAX_WORLD];
@@ -63,7 +100,7 @@ struct PfCtl {                   // device memory; written by the LAST workgroup
     double shift_scan;           // shift of the step that decided to resample (the cdf is formed through it)
     double gmax_norm;            // largest normalised log-weight of that step, as the storage type holds it
     double u0;                   // systematic-resampling offset of that step
-    double stats[8];             // {max, sum w, sum w^2, sum w x, sum w y, sum w sin, sum w cos, Neff}, w = exp(logw - max)
+    double stats[8];             // {max, sum w, sum w^2, 0, 0, 0, 0, Neff}, w = exp(logw - ceil(max / ln 2) ln 2) (see WRec)
     long long seq;               // last completed step
     long long resample_seq;      // the step whose (lazy) resampling the conditional kernels apply
     long long halt_seq;          // != 0: that step wants a resampling the device cannot do; later steps are skipped
@@ -108,7 +145,9 @@ struct slam_pf {
     uint32_t step;
     hipStream_t stream;
     void* pose[2];       // [3][n]
-    void* lm[2];         // [nl][5][n]
+    PfLmTab lmtab;       // the landmark records [nl][5][n], two buffers, in chunks (see PfLmTab)
+    PfLmTab* d_lmtab;    // its device copy
+    size_t lm_chunk_bytes;
     void* logw;          // [n]: the LIVE one of logw2 (what the legacy entry points work on)
     void* logw2[2];
     int lwcur;
@@ -164,7 +203,8 @@ struct slam_pf {
     PfPeers* d_peers;            // device copy of the table below (null: no peers attached)
     PfPeers peers;
     PfInbox* inbox;              // this rank's inbox (device memory, exported)
-    void* peer_open[PF_MAX_WORLD][9];   // what hipIpcOpenMemHandle returned (closed at detach); null for in-process peers
+    size_t inbox_bytes;
+    void* peer_open[PF_MAX_WORLD][7 + 2 * PF_LM_MAXC];   // what hipIpcOpenMemHandle returned (closed at detach); null for in-process peers
     int64_t par_max_n;           // filters / shards of at most this many particles take the observation-parallel step kernel
     long long bar_count;         // peer barriers enqueued so far (the same on every rank: the calls are collective)
     long long halts;             // SLAM_PF_HALTED returns so far
@@ -332,14 +372,14 @@ __global__ __launch_bounds__(256) void pf_set_pose_kernel(T* __restrict__ pose, 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void pf_init_lm_kernel(T* __restrict__ lm, int64_t n, int64_t first, uint64_t seed,
+__global__ __launch_bounds__(256) void pf_init_lm_kernel(LmView<T> lv, int buf, int64_t n, int64_t first, uint64_t seed,
                                                           const double* __restrict__ xy, int nl, T var, T jitter) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     for (int l = 0; l < nl; ++l) {
         T e1, e2;
         normals2<T>((uint64_t)(first + p), (uint32_t)l, STREAM_INIT, seed, e1, e2);
-        T* row = lm + (size_t)l * 5 * n + p;
+        T* row = lv.rows(buf, l, n) + p;
         row[0] = (T)xy[2 * l] + jitter * e1;
         row[n] = (T)xy[2 * l + 1] + jitter * e2;
         row[2 * n] = var;
@@ -486,6 +526,120 @@ __device__ __forceinline__ void block_weight_stats(T lw, T x, T y, T phi, bool v
     }
 }
 
+
+// ---- the CANONICAL weight statistics of the auto mode (round 4) ---------------------------------------------------------------
+// SURVEY 8e asks for results that do not depend on the number of GPUs.  Particles and maps never did; the NORMALISATION did by
+// ulps, because a rank folded its own workgroups' partial sums and the ranks' sums were folded in rank order.  Now the three
+// statistics (max log-weight, sum w, sum w^2) are DEFINED as the root of one fixed reduction tree over the GLOBAL particle
+// index, whatever computes its nodes:
+//   leaf    a wave's 64 consecutive particles: m = their largest log-weight, k = ceil(m / ln 2) (an integer), e_i =
+//           exp(logw_i - k ln 2) in double, s1 = sum e_i, s2 = sum e_i^2 by the xor butterfly (every lane ends with the same bits)
+//   node    wrec_combine4 of its four children in index order: M = max m, K = ceil(M / ln 2), every child's sums rescaled by
+//           2^(k_child - K) -- a power of two, EXACT -- and added left to right.  An absent child is {-inf, 0, 0}, and combining
+//           with absent children returns the present one bit for bit, so ragged sizes and any padding of the depth change nothing.
+// A step kernel's workgroup stores one tagged line per 64 particles (observation-parallel kernel) or per 256 (the tree's next
+// level, formed in the workgroup); the launch's last workgroup climbs to the 1024-particle records, and -- sharded filter with
+// peers -- every rank writes ITS records into every rank's inbox and all ranks reduce the same sequence of records with the same
+// tree: log-weights bit-identical to the one-rank filter's whenever a rank's slice is a multiple of 1024 particles (every shape
+// of BASELINE.json's filter).  (The legacy entry points keep block_weight_stats / fold_partials; they agree to a few ulp.)
+struct WRec {
+    double m, s1, s2;
+};
+constexpr double PF_LN2 = 0.693147180559945309417232121458;
+constexpr double PF_INV_LN2 = 1.442695040888963407359924681002;
+__device__ __forceinline__ WRec wrec_empty() { return WRec{-__builtin_inf(), 0.0, 0.0}; }
+__device__ __forceinline__ double wrec_k(double m) { return ceil(m * PF_INV_LN2); }      // the record's binary exponent
+__device__ __forceinline__ WRec wrec_combine4(const WRec& a, const WRec& b, const WRec& c, const WRec& d) {
+    const double NEG = -__builtin_inf();
+    WRec r;
+    r.m = fmax(fmax(a.m, b.m), fmax(c.m, d.m));
+    if (!(r.m > NEG)) { r.s1 = 0.0; r.s2 = 0.0; return r; }
+    const double K = wrec_k(r.m);
+    auto sc = [&](const WRec& x, double& f1, double& f2) {
+        if (!(x.m > NEG)) { f1 = 0.0; f2 = 0.0; return; }
+        const int dk = (int)fmax(wrec_k(x.m) - K, -4000.0);            // <= 0
+        f1 = ldexp(x.s1, dk);
+        f2 = ldexp(x.s2, 2 * dk);
+    };
+    double a1, a2, b1, b2, c1, c2, d1, d2;
+    sc(a, a1, a2); sc(b, b1, b2); sc(c, c1, c2); sc(d, d1, d2);
+    r.s1 = ((a1 + b1) + c1) + d1;
+    r.s2 = ((a2 + b2) + c2) + d2;
+    return r;
+}
+// leaf: the wave's 64 particles (every lane returns the same record)
+template <typename T>
+__device__ __forceinline__ WRec wrec_wave(T lw, bool valid) {
+    const double NEG = -__builtin_inf();
+    double m = valid ? (double)lw : NEG;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    WRec r;
+    r.m = m;
+    const bool live = valid && (double)lw > NEG && m > NEG;
+#if defined(SLAMHIP_EXPERIMENTS) && defined(PF_EXP_NOSTATS)          // timing experiment: WRONG statistics
+    const double e = live ? 1.0 + ((double)lw - m) : 0.0;
+#else
+    const double e = live ? exp((double)lw - wrec_k(m) * PF_LN2) : 0.0;
+#endif
+    double s1 = e, s2 = e * e;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        s1 += __shfl_xor(s1, off);
+        s2 += __shfl_xor(s2, off);
+    }
+    r.s1 = s1; r.s2 = s2;
+    return r;
+}
+__device__ __forceinline__ unsigned long long wrec_hash(const WRec& r) {
+    const unsigned long long b0 = (unsigned long long)__double_as_longlong(r.m), b1 = (unsigned long long)__double_as_longlong(r.s1),
+                             b2 = (unsigned long long)__double_as_longlong(r.s2);
+    return ((b0 << 7) | (b0 >> 57)) ^ ((b1 << 23) | (b1 >> 41)) ^ ((b2 << 41) | (b2 >> 23));
+}
+// one tagged line {m, s1, s2, tag} at part[8 line ..]: write-through at agent scope, NOT waited for (see part_key)
+__device__ __forceinline__ void wrec_store_line(double* __restrict__ part, int line, const WRec& r, long long seq) {
+    double* o = part + (size_t)line * 8;
+    __hip_atomic_store(o + 0, r.m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(o + 1, r.s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(o + 2, r.s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(o + 3), wrec_hash(r) ^ part_key(seq), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+// a workgroup whose first four waves hold 256 consecutive particles' weights (the sweep kernels): the tree's 256-particle
+// node, stored as line `blockIdx.x`.  All threads of the workgroup must call it (one barrier).
+template <typename T>
+__device__ __forceinline__ void wrec_block_line(T lw, bool valid, double* __restrict__ part, long long seq) {
+    __shared__ double sh_w[4][3];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave < 4) {
+        const WRec r = wrec_wave<T>(lw, valid);
+        if (lane == 0) { sh_w[wave][0] = r.m; sh_w[wave][1] = r.s1; sh_w[wave][2] = r.s2; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const WRec q0{sh_w[0][0], sh_w[0][1], sh_w[0][2]}, q1{sh_w[1][0], sh_w[1][1], sh_w[1][2]},
+                   q2{sh_w[2][0], sh_w[2][1], sh_w[2][2]}, q3{sh_w[3][0], sh_w[3][1], sh_w[3][2]};
+        wrec_store_line(part, (int)blockIdx.x, wrec_combine4(q0, q1, q2, q3), seq);
+    }
+}
+// 256 threads (four waves), records held by the threads with tid % stride == 0 (stride 1, 4 or 16, consecutive tree
+// positions): the node above all of them, returned to every thread.  sh: [4][3] doubles.
+__device__ __forceinline__ WRec wrec_tree256(WRec r, int stride, double (*sh)[3]) {
+    for (int s = stride; s < 64; s *= 4) {
+        WRec b, c, d;
+        b.m = __shfl_down(r.m, s); b.s1 = __shfl_down(r.s1, s); b.s2 = __shfl_down(r.s2, s);
+        c.m = __shfl_down(r.m, 2 * s); c.s1 = __shfl_down(r.s1, 2 * s); c.s2 = __shfl_down(r.s2, 2 * s);
+        d.m = __shfl_down(r.m, 3 * s); d.s1 = __shfl_down(r.s1, 3 * s); d.s2 = __shfl_down(r.s2, 3 * s);
+        r = wrec_combine4(r, b, c, d);                     // valid in the lanes with lane % (4 s) == 0
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) { sh[wave][0] = r.m; sh[wave][1] = r.s1; sh[wave][2] = r.s2; }
+    __syncthreads();
+    return wrec_combine4(WRec{sh[0][0], sh[0][1], sh[0][2]}, WRec{sh[1][0], sh[1][1], sh[1][2]}, WRec{sh[2][0], sh[2][1], sh[2][2]},
+                         WRec{sh[3][0], sh[3][1], sh[3][2]});
+}
+
 // F3: first sighting of a landmark -- src/ekf.jl:94-103,112 without the pose term.
 // Where an updated record goes: a plain pointer to the particle's first value (rows n apart), or -- the sweep -- a buffer
 // descriptor of the landmark's rows plus the lane's byte offset (see lm_rsrc).
@@ -578,19 +732,11 @@ __device__ __forceinline__ void lm_update(const ROW& row, int64_t n, const LmRow
 // registers, the record of observation i + PF_DEPTH requested before observation i is processed, the first PF_DEPTH
 // before the motion model runs (KnownRing::start).  A landmark that one of the PF_DEPTH observations before it writes
 // (a repeat inside the call) cannot be requested ahead: it is read after that store, at its turn.  Records are read
-// where the lazy resampling left them (obs_src: buffer + slot through the landmark's ancestor table) and written to
+// where the lazy resampling left them (sweep_load: buffer + slot through the landmark's ancestor table) and written to
 // the particle's own slot of the buffer the staging chose.  The arithmetic and its order do not depend on the depth.
 #ifndef PF_DEPTH
 #define PF_DEPTH 4
 #endif
-template <typename T>
-__device__ __forceinline__ const T* obs_src(const T* lm0, const T* lm1, const int32_t* __restrict__ tabs, int64_t n, int64_t p,
-                                            int32_t code, int32_t meta) {
-    const int t = meta & META_TAB;
-    const int64_t slot = t ? (int64_t)tabs[(size_t)(t - 1) * n + p] : p;
-    return ((meta & META_RBUF) ? lm1 : lm0) + (size_t)(code & ID_MASK) * 5 * n + slot;
-}
-
 // The sweep reads and writes records through BUFFER instructions: a wave-uniform descriptor per landmark (base = the
 // landmark's five rows in the buffer read or written, 5 n values), the field's row as the scalar offset k n sizeof(T),
 // the lane's slot as a 32-bit byte offset -- no vector address arithmetic at all (it was 12 of the ~200 vector
@@ -647,10 +793,10 @@ __device__ __forceinline__ uint32_t pf_owner(uint32_t g, uint32_t n, int world) 
 // its record is then read from that rank's buffer over xGMI (system-scope loads; the owner wrote it in a kernel that
 // had completed before the resampling that created the entry, see pf_peer_gate_kernel).
 template <typename T, int AUX = 2, bool SH = false>      // AUX: cache policy of a record read from the particle's own slot (2 = non-temporal)
-__device__ __forceinline__ LmRow<T> sweep_load(const T* lm0, const T* lm1, const int32_t* __restrict__ tabs, int64_t n, uint32_t p,
+__device__ __forceinline__ LmRow<T> sweep_load(const LmView<T> lv, const int32_t* __restrict__ tabs, int64_t n, uint32_t p,
                                                int32_t code, int32_t meta, const PfShardCtx& sc) {
     const int t = meta & META_TAB;
-    const auto rs = lm_rsrc<T>(((meta & META_RBUF) ? lm1 : lm0) + (size_t)(code & ID_MASK) * 5 * n, n);
+    const auto rs = lm_rsrc<T>(lv.rows((meta & META_RBUF) ? 1 : 0, code & ID_MASK, n), n);
     const uint32_t row = (uint32_t)n * (uint32_t)sizeof(T);
     LmRow<T> r;
     if (t) {                                                           // uniform
@@ -664,8 +810,8 @@ __device__ __forceinline__ LmRow<T> sweep_load(const T* lm0, const T* lm1, const
             const uint32_t owner = pf_owner(slot, sc.n, sc.world);
             local = owner == (uint32_t)sc.rank;
             if (!local) {
-                const T* base = (const T*)sc.peers->lm[owner][(meta & META_RBUF) ? 1 : 0] + (size_t)(code & ID_MASK) * 5 * n +
-                                (slot - owner * sc.n);
+                const LmView<T> pv{&sc.peers->lm[owner]};       // the owner's chunks as this GPU addresses them
+                const T* base = pv.rows((meta & META_RBUF) ? 1 : 0, code & ID_MASK, n) + (slot - owner * sc.n);
                 r.lx = ld_sys(base);
                 r.ly = ld_sys(base + n);
                 r.pxx = ld_sys(base + 2 * n);
@@ -714,20 +860,20 @@ struct KnownRing {
         return ok;
     }
 
-    __device__ __forceinline__ void start(const T* lm0, const T* lm1, const int32_t* __restrict__ tabs, int64_t n, uint32_t p,
+    __device__ __forceinline__ void start(const LmView<T> lv, const int32_t* __restrict__ tabs, int64_t n, uint32_t p,
                                           const int32_t* s_ids, const int32_t* s_meta, int m, const PfShardCtx& sc) {
 #pragma unroll
         for (int u = 0; u < PF_DEPTH; ++u) {
             have[u] = false;
             ring[u] = LmRow<T>{0, 0, 0, 0, 0};
             if (u < m && ahead(s_ids, u)) {
-                ring[u] = sweep_load<T, 2, SH>(lm0, lm1, tabs, n, p, uni(s_ids[u]), uni(s_meta[u]), sc);
+                ring[u] = sweep_load<T, 2, SH>(lv, tabs, n, p, uni(s_ids[u]), uni(s_meta[u]), sc);
                 have[u] = true;
             }
         }
     }
 
-    __device__ __forceinline__ void run(T* lm0, T* lm1, const int32_t* __restrict__ tabs, int64_t n, uint32_t p,
+    __device__ __forceinline__ void run(const LmView<T> lv, const int32_t* __restrict__ tabs, int64_t n, uint32_t p,
                                         const T* s_obs, const int32_t* s_ids, const int32_t* s_meta, int m, T x, T y, T phi,
                                         T R00, T R10, T R01, T R11, bool valid, T& lw, const PfShardCtx& sc) {
 #if defined(SLAMHIP_EXPERIMENTS) && defined(PF_EXP_NOOBS)           // timing experiment: no map updates
@@ -741,21 +887,21 @@ struct KnownRing {
                 const int32_t code = uni(s_ids[i]), meta = uni(s_meta[i]);
                 const int l = code & ID_MASK;
                 const T r = s_obs[2 * i], b = s_obs[2 * i + 1];
-                const BufRow<T, decltype(lm_rsrc<T>(lm0, n))> row{lm_rsrc<T>(((meta & META_WBUF) ? lm1 : lm0) + (size_t)l * 5 * n, n),
+                const BufRow<T, decltype(lm_rsrc<T>((const T*)nullptr, n))> row{lm_rsrc<T>(lv.rows((meta & META_WBUF) ? 1 : 0, l, n), n),
                                                                   p * (uint32_t)sizeof(T), (uint32_t)n * (uint32_t)sizeof(T)};
                 LmRow<T> cur = ring[u];
                 const bool have_cur = have[u];
                 have[u] = false;
                 const int j = i + PF_DEPTH;
                 if (j < m && ahead(s_ids, j)) {                    // uniform
-                    ring[u] = sweep_load<T, 2, SH>(lm0, lm1, tabs, n, p, uni(s_ids[j]), uni(s_meta[j]), sc);
+                    ring[u] = sweep_load<T, 2, SH>(lv, tabs, n, p, uni(s_ids[j]), uni(s_meta[j]), sc);
                     have[u] = true;
                 }
                 if (code & NEW_FLAG) {                             // F3: src/ekf.jl:94-103,112 without the pose term
                     lm_init<T>(row, n, x, y, phi, r, b, R00, R10, R01, R11, valid);
                     continue;
                 }
-                if (!have_cur) cur = sweep_load<T, 2, SH>(lm0, lm1, tabs, n, p, code, meta, sc);
+                if (!have_cur) cur = sweep_load<T, 2, SH>(lv, tabs, n, p, code, meta, sc);
                 lm_update<T>(row, n, cur, x, y, phi, r, b, R00, R10, R01, R11, valid, lw);
             }
         }
@@ -763,12 +909,12 @@ struct KnownRing {
 };
 
 template <typename T, bool SH = false>
-__device__ __forceinline__ void apply_known(T* lm0, T* lm1, const int32_t* __restrict__ tabs, int64_t n, int64_t p,
+__device__ __forceinline__ void apply_known(const LmView<T> lv, const int32_t* __restrict__ tabs, int64_t n, int64_t p,
                                             const T* s_obs, const int32_t* s_ids, const int32_t* s_meta, int m, T x, T y,
                                             T phi, T R00, T R10, T R01, T R11, bool valid, T& lw, const PfShardCtx& sc) {
     KnownRing<T, SH> k;
-    k.start(lm0, lm1, tabs, n, (uint32_t)p, s_ids, s_meta, m, sc);
-    k.run(lm0, lm1, tabs, n, (uint32_t)p, s_obs, s_ids, s_meta, m, x, y, phi, R00, R10, R01, R11, valid, lw, sc);
+    k.start(lv, tabs, n, (uint32_t)p, s_ids, s_meta, m, sc);
+    k.run(lv, tabs, n, (uint32_t)p, s_obs, s_ids, s_meta, m, x, y, phi, R00, R10, R01, R11, valid, lw, sc);
 }
 
 // One particle's filter step: predict (PREDICT), the m known-id updates, the log-weight.  Shared by the legacy kernels
@@ -776,7 +922,7 @@ __device__ __forceinline__ void apply_known(T* lm0, T* lm1, const int32_t* __res
 // PRELOADED (the auto mode's kernel): x, y, phi hold the particle's pose, lw its stored log-weight and e1, e2 its two
 // normal deviates on entry -- requested / computed before the observation plan's barriers, off the critical path.
 template <typename T, bool PREDICT, bool PRELOADED = false, bool SH = false>
-__device__ __forceinline__ void step_core(T* __restrict__ pose, T* lm0, T* lm1, const int32_t* __restrict__ tabs,
+__device__ __forceinline__ void step_core(T* __restrict__ pose, const LmView<T> lv, const int32_t* __restrict__ tabs,
                                           T* __restrict__ logw, int64_t n, int64_t first, uint32_t step, uint64_t seed, T V, T G,
                                           T wheelbase, T sigV, T sigG, T dt, const T* s_obs, const int32_t* s_ids,
                                           const int32_t* s_meta, int m, T R00, T R10, T R01, T R11, T pend, int64_t p, bool valid,
@@ -787,7 +933,7 @@ __device__ __forceinline__ void step_core(T* __restrict__ pose, T* lm0, T* lm1, 
     }
     lw -= pend;                   // `pend`: the normalisation shift deferred by slam_pf_normalize (0 if none)
     KnownRing<T, SH> known;
-    known.start(lm0, lm1, tabs, n, (uint32_t)p, s_ids, s_meta, m, sc);  // the first records are in flight during the motion model
+    known.start(lv, tabs, n, (uint32_t)p, s_ids, s_meta, m, sc);  // the first records are in flight during the motion model
     if (PREDICT) {
 #if defined(SLAMHIP_EXPERIMENTS) && defined(PF_EXP_NOPREDICT)       // timing experiment: no noise
         e1 = (T)0.1; e2 = (T)-0.1;
@@ -806,14 +952,14 @@ __device__ __forceinline__ void step_core(T* __restrict__ pose, T* lm0, T* lm1, 
         if (valid) { pose[p] = x; pose[n + p] = y; pose[2 * n + p] = phi; }
     }
     PF_XS(3);
-    known.run(lm0, lm1, tabs, n, (uint32_t)p, s_obs, s_ids, s_meta, m, x, y, phi, R00, R10, R01, R11, valid, lw, sc);
+    known.run(lv, tabs, n, (uint32_t)p, s_obs, s_ids, s_meta, m, x, y, phi, R00, R10, R01, R11, valid, lw, sc);
     if (valid) logw[p] = lw;
 }
 
 // F1 + F2/F3 (+ F4 partials): one pass over the particle -- predict (PREDICT), the m known-id updates, and
 // (STATS) the block's weight statistics, so that a filter step is ONE sweep of HBM instead of five launches.
 template <typename T, bool PREDICT, bool STATS>
-__global__ __launch_bounds__(256) void pf_step_kernel(T* __restrict__ pose, T* lm0, T* lm1, const int32_t* __restrict__ tabs,
+__global__ __launch_bounds__(256) void pf_step_kernel(T* __restrict__ pose, LmView<T> lv, const int32_t* __restrict__ tabs,
                                                        T* __restrict__ logw,
                                                        int64_t n, int64_t first, uint32_t step, uint64_t seed, T V, T G,
                                                        T wheelbase, T sigV, T sigG, T dt, const double* __restrict__ z,
@@ -832,7 +978,7 @@ __global__ __launch_bounds__(256) void pf_step_kernel(T* __restrict__ pose, T* l
     if (!STATS && !valid) return;
     const int64_t p = valid ? pi : n - 1;          // (STATS: idle lanes shadow the last particle, stores are masked)
     T x, y, phi, lw;
-    step_core<T, PREDICT>(pose, lm0, lm1, tabs, logw, n, first, step, seed, V, G, wheelbase, sigV, sigG, dt, s_obs, s_ids, s_meta,
+    step_core<T, PREDICT>(pose, lv, tabs, logw, n, first, step, seed, V, G, wheelbase, sigV, sigG, dt, s_obs, s_ids, s_meta,
                           m, R00, R10, R01, R11, pend, p, valid, x, y, phi, lw);
     // (folding the partials in the last workgroup to finish behind an agent-scope release/acquire was tried: that is an L2
     //  write-back + invalidate on this multi-XCD part and doubled the kernel's time; here a 1-workgroup fold kernel
@@ -842,7 +988,7 @@ __global__ __launch_bounds__(256) void pf_step_kernel(T* __restrict__ pose, T* l
 
 // One particle's FastSLAM-2.0 step (see pf_proposal_kernel).  Shared by the legacy kernel and the auto mode's kernel.
 template <typename T, bool SH = false>
-__device__ __forceinline__ void proposal_core(T* __restrict__ pose, T* lm0, T* lm1, const int32_t* __restrict__ tabs,
+__device__ __forceinline__ void proposal_core(T* __restrict__ pose, const LmView<T> lv, const int32_t* __restrict__ tabs,
                                               T* __restrict__ logw, int64_t n, int64_t first, uint32_t step, uint64_t seed, T V,
                                               T G, T wheelbase, T lq00, T lq10, T lq11, T dt, const T* s_obs,
                                               const int32_t* s_ids, const int32_t* s_meta, int m, T R00, T R10, T R01, T R11,
@@ -868,7 +1014,7 @@ __device__ __forceinline__ void proposal_core(T* __restrict__ pose, T* lm0, T* l
     auto prior_row = [&](int j) {
         // (default cache policy: the second pass reads the same records again -- one-box A/B against non-temporal:
         //  69.0 against 73.5 us per step)
-        return sweep_load<T, 0, SH>(lm0, lm1, tabs, n, (uint32_t)p, uni(s_ids[j]), uni(s_meta[j]) >> META_PRIOR_SHIFT, sc);
+        return sweep_load<T, 0, SH>(lv, tabs, n, (uint32_t)p, uni(s_ids[j]), uni(s_meta[j]) >> META_PRIOR_SHIFT, sc);
     };
     auto informative = [&](int j) { return j < m && !(uni(s_ids[j]) & (NEW_FLAG | FRESH_FLAG)); };
     LmRow<T> ring[PF_DEPTH];
@@ -957,7 +1103,7 @@ __device__ __forceinline__ void proposal_core(T* __restrict__ pose, T* lm0, T* l
     const T pn = wrap_pi<T>(phi + Vn * dt * sgn / wheelbase);
     if (valid) { pose[p] = xn; pose[n + p] = yn; pose[2 * n + p] = pn; logw[p] = lw; }
     T unused = 0;
-    apply_known<T, SH>(lm0, lm1, tabs, n, p, s_obs, s_ids, s_meta, m, xn, yn, pn, R00, R10, R01, R11, valid, unused, sc);
+    apply_known<T, SH>(lv, tabs, n, p, s_obs, s_ids, s_meta, m, xn, yn, pn, R00, R10, R01, R11, valid, unused, sc);
     xo = xn; yo = yn; po = pn; lwo = lw;
 }
 
@@ -974,7 +1120,7 @@ __device__ __forceinline__ void proposal_core(T* __restrict__ pose, T* lm0, T* l
 // (Keeping the 16 records in registers between the passes, all requested up front, was measured: 166 VGPRs, three
 //  waves per SIMD instead of six, and the step went from 107 to 122 us on the same box.)
 template <typename T>
-__global__ __launch_bounds__(256) void pf_proposal_kernel(T* __restrict__ pose, T* lm0, T* lm1, const int32_t* __restrict__ tabs,
+__global__ __launch_bounds__(256) void pf_proposal_kernel(T* __restrict__ pose, LmView<T> lv, const int32_t* __restrict__ tabs,
                                                            T* __restrict__ logw,
                                                            int64_t n, int64_t first, uint32_t step, uint64_t seed, T V, T G,
                                                            T wheelbase, T lq00, T lq10, T lq11, T dt,
@@ -991,7 +1137,7 @@ __global__ __launch_bounds__(256) void pf_proposal_kernel(T* __restrict__ pose, 
     const bool valid = pi < n;
     const int64_t p = valid ? pi : n - 1;          // idle lanes shadow the last particle, stores are masked
     T xn, yn, pn, lw;
-    proposal_core<T>(pose, lm0, lm1, tabs, logw, n, first, step, seed, V, G, wheelbase, lq00, lq10, lq11, dt, s_obs, s_ids, s_meta, m,
+    proposal_core<T>(pose, lv, tabs, logw, n, first, step, seed, V, G, wheelbase, lq00, lq10, lq11, dt, s_obs, s_ids, s_meta, m,
                      R00, R10, R01, R11, pend, p, valid, xn, yn, pn, lw);
     block_weight_stats<T, false, false>(lw, xn, yn, pn, valid, 1, part);
 }
@@ -1007,7 +1153,7 @@ __global__ __launch_bounds__(256) void pf_proposal_kernel(T* __restrict__ pose, 
 constexpr int UNK_MAX = 16;
 
 template <typename T>
-__global__ __launch_bounds__(256) void pf_update_unknown_kernel(const T* __restrict__ pose, T* __restrict__ lm,
+__global__ __launch_bounds__(256) void pf_update_unknown_kernel(const T* __restrict__ pose, LmView<T> lv, int buf,
                                                                  T* __restrict__ logw, int64_t n, int nl,
                                                                  const double* __restrict__ z, int m, T R00, T R10, T R01,
                                                                  T R11, T gate1, T gate2, T pend,
@@ -1026,7 +1172,7 @@ __global__ __launch_bounds__(256) void pf_update_unknown_kernel(const T* __restr
 #pragma unroll
     for (int i = 0; i < UNK_MAX; ++i) { best_nd[i] = INF; best_l[i] = -1; }
     for (int l = 0; l < nl; ++l) {
-        const T* row = lm + (size_t)l * 5 * n + p;
+        const T* row = lv.rows(buf, l, n) + p;
         const T pxx = row[2 * n];
         if (pxx < (T)0) continue;
         const T lx = row[0], ly = row[n], pxy = row[3 * n], pyy = row[4 * n];
@@ -1065,14 +1211,14 @@ __global__ __launch_bounds__(256) void pf_update_unknown_kernel(const T* __restr
             if (assoc_out) assoc_out[(size_t)i * n + p] = a;
             const T r = (T)s_obs[2 * i], b = (T)s_obs[2 * i + 1];
             if (a >= 0) {
-                T* row = lm + (size_t)a * 5 * n + p;
+                T* row = lv.rows(buf, a, n) + p;
                 const LmRow<T> cur = load_row<T>(row, n);
                 lm_update<T>(row, n, cur, x, y, phi, r, b, R00, R10, R01, R11, true, lw);
             } else if (a == -1) {
                 int slot = next_free;
-                while (slot < nl && !(lm[((size_t)slot * 5 + 2) * n + p] < (T)0)) ++slot;
+                while (slot < nl && !(lv.rows(buf, slot, n)[2 * n + p] < (T)0)) ++slot;
                 if (slot < nl) {
-                    lm_init<T>(lm + (size_t)slot * 5 * n + p, n, x, y, phi, r, b, R00, R10, R01, R11, true);
+                    lm_init<T>(lv.rows(buf, slot, n) + p, n, x, y, phi, r, b, R00, R10, R01, R11, true);
                     next_free = slot + 1;
                 }
             }
@@ -1082,11 +1228,11 @@ __global__ __launch_bounds__(256) void pf_update_unknown_kernel(const T* __restr
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void pf_clear_lm_kernel(T* __restrict__ lm, int64_t n, int nl) {
+__global__ __launch_bounds__(256) void pf_clear_lm_kernel(LmView<T> lv, int buf, int64_t n, int nl) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     for (int l = 0; l < nl; ++l) {
-        T* row = lm + (size_t)l * 5 * n + p;
+        T* row = lv.rows(buf, l, n) + p;
         row[0] = (T)0; row[n] = (T)0; row[2 * n] = (T)-1; row[3 * n] = (T)0; row[4 * n] = (T)0;
     }
 }
@@ -1271,8 +1417,8 @@ __global__ __launch_bounds__(256) void pf_src_kernel(const int32_t* __restrict__
 // (grid.y = row chunks): the source index is read once and the row loop keeps eight independent loads in flight.
 constexpr int GATHER_ROWS = 64;
 template <typename T>
-__global__ __launch_bounds__(256) void pf_gather_kernel(const T* __restrict__ pose_old, const T* __restrict__ lm_old,
-                                                         T* __restrict__ pose_new, T* __restrict__ lm_new, int64_t n,
+__global__ __launch_bounds__(256) void pf_gather_kernel(const T* __restrict__ pose_old, LmView<T> lv, int bold,
+                                                         T* __restrict__ pose_new, int bnew, int64_t n,
                                                          int nrows, const int32_t* __restrict__ src,
                                                          const T* __restrict__ remote, int nremote) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1283,26 +1429,19 @@ __global__ __launch_bounds__(256) void pf_gather_kernel(const T* __restrict__ po
     if (s >= 0) {
         int row = row0;
         for (; row < 3 && row < row1; ++row) pose_new[(size_t)row * n + p] = pose_old[(size_t)row * n + s];
-        const T* o = lm_old + (size_t)(row - 3) * n + s;
-        T* d = lm_new + (size_t)(row - 3) * n + p;
+        // (row - 3 of the flat [5 nl][n] view: a chunk boundary may fall inside the block, so every row finds its own chunk)
         for (; row + 8 <= row1; row += 8) {
             T v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = o[(size_t)u * n];
+            for (int u = 0; u < 8; ++u) v[u] = lv.flat_row(bold, row - 3 + u, n)[s];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) d[(size_t)u * n] = v[u];
-            o += (size_t)8 * n;
-            d += (size_t)8 * n;
+            for (int u = 0; u < 8; ++u) lv.flat_row(bnew, row - 3 + u, n)[p] = v[u];
         }
-        for (; row < row1; ++row) {
-            *d = *o;
-            o += n;
-            d += n;
-        }
+        for (; row < row1; ++row) lv.flat_row(bnew, row - 3, n)[p] = lv.flat_row(bold, row - 3, n)[s];
     } else {
         const T* rr = remote + (size_t)(-s - 1);
         for (int row = row0; row < row1; ++row) {
-            T* new_row = row < 3 ? pose_new + (size_t)row * n : lm_new + (size_t)(row - 3) * n;
+            T* new_row = row < 3 ? pose_new + (size_t)row * n : lv.flat_row(bnew, row - 3, n);
             new_row[p] = rr[(size_t)row * nremote];
         }
     }
@@ -1310,12 +1449,12 @@ __global__ __launch_bounds__(256) void pf_gather_kernel(const T* __restrict__ po
 
 // records[row][c] = state[row][idx[c]]
 template <typename T>
-__global__ __launch_bounds__(256) void pf_pack_kernel(const T* __restrict__ pose, const T* __restrict__ lm, int64_t n,
+__global__ __launch_bounds__(256) void pf_pack_kernel(const T* __restrict__ pose, LmView<T> lv, int buf, int64_t n,
                                                        const int32_t* __restrict__ idx, int cnt, T* __restrict__ rec) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= cnt) return;
     const int row = blockIdx.y;
-    const T* src_row = row < 3 ? pose + (size_t)row * n : lm + (size_t)(row - 3) * n;
+    const T* src_row = row < 3 ? pose + (size_t)row * n : lv.flat_row(buf, row - 3, n);
     rec[(size_t)row * cnt + c] = src_row[idx[c]];
 }
 
@@ -1380,7 +1519,7 @@ __global__ __launch_bounds__(256) void pf_lazy_apply_kernel(const T* __restrict_
 constexpr int MAT_LMS = 12;      // landmarks per thread
 // SH (sharded filter with peers): a table entry is a global particle id; a remote ancestor's record is read from its owner.
 template <typename T, bool SH>
-__global__ __launch_bounds__(256) void pf_materialise_kernel(T* lm0, T* lm1, const int32_t* __restrict__ tabs, int64_t n, int nl,
+__global__ __launch_bounds__(256) void pf_materialise_kernel(LmView<T> lv, const int32_t* __restrict__ tabs, int64_t n, int nl,
                                                               const int32_t* __restrict__ work, PfShardCtx sc) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
@@ -1390,18 +1529,18 @@ __global__ __launch_bounds__(256) void pf_materialise_kernel(T* lm0, T* lm1, con
         if (w < 0) continue;                                   // (uniform)
         const int t = w & META_TAB;
         int64_t slot = t ? (int64_t)tabs[(size_t)(t - 1) * n + p] : p;
-        const T* src = ((w & META_RBUF) ? lm1 : lm0) + (size_t)l * 5 * n;
+        const T* src = lv.rows((w & META_RBUF) ? 1 : 0, l, n);
         bool remote = false;
         if constexpr (SH) {
             if (t) {
                 const uint32_t owner = pf_owner((uint32_t)slot, sc.n, sc.world);
                 remote = owner != (uint32_t)sc.rank;
                 slot -= (int64_t)owner * sc.n;
-                if (remote) src = (const T*)sc.peers->lm[owner][(w & META_RBUF) ? 1 : 0] + (size_t)l * 5 * n;
+                if (remote) src = LmView<T>{&sc.peers->lm[owner]}.rows((w & META_RBUF) ? 1 : 0, l, n);
             }
         }
         src += slot;
-        T* dst = ((w & META_WBUF) ? lm1 : lm0) + (size_t)l * 5 * n + p;
+        T* dst = lv.rows((w & META_WBUF) ? 1 : 0, l, n) + p;
         T v[5];
 #pragma unroll
         for (int c = 0; c < 5; ++c) {
@@ -1448,12 +1587,13 @@ __host__ __device__ inline double resample_offset(uint32_t count, uint64_t seed)
 }
 
 struct PfAutoArgs {
-    void *pose0, *pose1, *lm0, *lm1, *logw0, *logw1;
+    void *pose0, *pose1, *logw0, *logw1;
+    const PfLmTab* lmtab;        // the landmark records' chunk table (device memory)
     int32_t *tab0, *tab1;
     long long n, first, n_global, seq;
     unsigned long long seed;
     unsigned int step;
-    int m, nl, force, lazy_ok, rank, world, publish;
+    int m, nl, force, lazy_ok, rank, world, publish, rec_cap;
     double V, G, wheelbase, a0, a1, a2, dt, R00, R10, R01, R11, neff_frac;
     double* part;
     PfCtl* ctl;
@@ -1524,6 +1664,13 @@ __device__ __forceinline__ void block_reduce6(double (&v)[6], double (*sh6)[6]) 
     for (int i = 0; i < NS; ++i) v[i] = sh6[0][i] + sh6[1][i] + sh6[2][i] + sh6[3][i];
 }
 
+// has a peer announced that it is going away?  (uniform: the words sit in this rank's own inbox)
+__device__ __forceinline__ bool pf_peer_gone(const PfInbox* inbox, int world) {
+    unsigned long long g = 0;
+    for (int r = 0; r < world; ++r) g |= __hip_atomic_load(&inbox->gone[r][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return g != 0;
+}
+
 // One lane writes a step's outcome to the host's mirror (pinned memory).
 __device__ __forceinline__ void pf_publish(PfMirror* mir, double neff, long long nresamples, long long resampled_seq, int error,
                                            long long halt_seq, long long seq) {
@@ -1549,11 +1696,13 @@ __global__ void pf_auto_publish_kernel(const PfCtl* __restrict__ ctl, PfMirror* 
 // Runs in the launch's last workgroup, after its own share of the sweep (all 256 threads).  s_l / s_st / s_first: this step's plan (LDS).
 template <typename T>
 __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t* s_l, const int32_t* s_st, const int32_t* s_first,
-                                             int pcur, int tside, int lwcur) {
-    __shared__ double sh[4];
-    __shared__ double s_r6[4][6];
+                                             int pcur, int tside, int lwcur, int line_level) {
+    // line_level: what a statistics line of this launch is -- 0: the tree's leaf (64 particles, observation-parallel kernel),
+    // 1: the 256-particle node (the sweep kernels)
+    __shared__ double s_w[4][3];
+    __shared__ double s_pass[16][3];              // the tree nodes above each pass of 1024 lines / records
     __shared__ double s_g[12];
-    __shared__ double s_rv[PF_MAX_WORLD][3];      // the ranks' records of the scalar exchange (thread 0)
+    __shared__ double s_rv[PF_MAX_WORLD][3];      // the ranks' records of the legacy scalar exchange (thread 0)
     __shared__ int s_tref[PF_TAB_MAX];
     __shared__ int s_i[4];          // [0] identity landmarks, [1] outcome (0 none, 1 lazy resampling, 2 halt), [2] fresh table
     const int tid = threadIdx.x;
@@ -1572,58 +1721,88 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
     int rounds = 0;
     __shared__ int s_perr;
     if (tid == 0) s_perr = 0;
+    if (tid < PF_TAB_MAX) s_tref[tid] = my_tref;
+    if (tid == 0) s_i[0] = identity0;
     __syncthreads();
-    // This thread's four lines of 1024, polled until their tags fit (see part_key): 32 agent-scope loads in flight per try.
-    // A line beyond the grid reads as {-inf, 0, ...}.
-    double q[4][7];
-    auto qv = [&](int u, int i) { return q[u][i]; };
-    auto collect = [&](int base) {
+    // Four consecutive records {m, s1, s2, tag} starting at `first` (64 bytes apart in `src`), polled until their tags fit
+    // (see part_key: a line that is stale, half written or torn does not fit; nothing else orders the stores).  Records from
+    // `count` on read as absent.  SYS: written by peer GPUs into this rank's inbox (system-scope loads), else by this launch's
+    // workgroups (agent scope).
+    auto collect4 = [&](const double* src, int stride_d, int first, int count, unsigned long long kkey, bool sys, WRec (&q)[4]) {
         for (;;) {
             bool ok = true;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int b = base + tid + 256 * u;
-                unsigned long long tag = 0;
-#pragma unroll
-                for (int i = 0; i < 7; ++i) q[u][i] = b < nblocks ? ld_sc1(a.part + (size_t)b * 8 + i) : (i == 0 ? -__builtin_inf() : 0.0);
-                if (b < nblocks) tag = ld_sc1(reinterpret_cast<const unsigned long long*>(a.part + (size_t)b * 8 + 7));
-                if (b < nblocks && (part_hash(q[u]) ^ tag) != key) ok = false;
+                const int b = first + u;
+                q[u] = wrec_empty();
+                if (b < count) {
+                    const double* o = src + (size_t)b * stride_d;
+                    unsigned long long tag;
+                    if (sys) {
+                        q[u].m = __hip_atomic_load(o + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        q[u].s1 = __hip_atomic_load(o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        q[u].s2 = __hip_atomic_load(o + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        tag = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(o + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    } else {
+                        q[u].m = ld_sc1(o + 0); q[u].s1 = ld_sc1(o + 1); q[u].s2 = ld_sc1(o + 2);
+                        tag = ld_sc1(reinterpret_cast<const unsigned long long*>(o + 3));
+                    }
+                    if ((wrec_hash(q[u]) ^ tag) != (kkey ^ (sys ? (unsigned long long)b * 0xD6E8FEB86659FD93ull : 0ull))) ok = false;
+                }
             }
             ++rounds;
             if (ok) break;
             __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t_poll > 200000000ull) { atomicOr(&s_perr, PF_ERR_HANDOVER); break; }      // 2 s at 100 MHz: give up, report
+            // 2 s (lines of this launch) / 20 s (a rank's records: that rank is gone) at 100 MHz: give up, report
+            if (wall_clock64() - t_poll > (sys ? 2000000000ull : 200000000ull)) { atomicOr(&s_perr, sys ? PF_ERR_EXCHANGE : PF_ERR_HANDOVER); break; }
         }
     };
-    collect(0);
-    if (tid < PF_TAB_MAX) s_tref[tid] = my_tref;
-    if (tid == 0) s_i[0] = identity0;
-    __syncthreads();
-    if (tid == 0) ctl->stamps[1] = wall_clock64();            // every workgroup's statistics are in
-    if (tid == 0) ctl->stamps[7] = ctl->stamps[0] + 100ull * (unsigned long long)rounds;      // (diagnostic: polls of thread 0)
-    // ---- fold the write-through partials (the order of fold_partials); 1024 records per pass ----
-    double M = -__builtin_inf();
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    for (int base = 0; base < nblocks; base += 1024) {
-        if (base > 0) collect(base);
-        double m = fmax(fmax(qv(0, 0), qv(1, 0)), fmax(qv(2, 0), qv(3, 0)));
-        m = block_reduce(m, sh, true, 4);
-        const double Mn = fmax(M, m);
-        const double fo = M == -__builtin_inf() ? 0.0 : exp(M - Mn);              // rescale what earlier passes summed
-        acc[0] *= fo; acc[1] *= fo * fo;
-        M = Mn;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const double f = qv(u, 0) == -__builtin_inf() ? 0.0 : exp(qv(u, 0) - M);
-            acc[0] += qv(u, 1) * f;
-            acc[1] += qv(u, 2) * f * f;               // (the pose sums of a step's lines are zeros: block_weight_stats<POSE = false>)
+    // ---- this rank's lines -> the tree's 1024-particle records (C) and above, 1024 lines per pass ----
+    const bool xpeers = a.world > 1 && a.peers != nullptr;    // sharded with peers: the 1024-particle records go to every rank
+    const int lines_per_c = line_level == 0 ? 16 : 4;
+    const int nc_local = (int)((a.n + 1023) / 1024);
+    const int par = (int)(a.seq & 1);
+    const unsigned long long xkey = key ^ 0x5851F42D4C957F2Dull;
+    const int npass_l = (nblocks + 1023) / 1024;
+    for (int ps = 0; ps < npass_l; ++ps) {
+        WRec q[4];
+        collect4(a.part, 8, 1024 * ps + 4 * tid, nblocks, key, false, q);
+        WRec r = wrec_combine4(q[0], q[1], q[2], q[3]);
+        int stride = 1;
+        if (line_level == 0) {                                // leaves: one more level to reach the 1024-particle record
+            WRec b, c, d;
+            b.m = __shfl_down(r.m, 1); b.s1 = __shfl_down(r.s1, 1); b.s2 = __shfl_down(r.s2, 1);
+            c.m = __shfl_down(r.m, 2); c.s1 = __shfl_down(r.s1, 2); c.s2 = __shfl_down(r.s2, 2);
+            d.m = __shfl_down(r.m, 3); d.s1 = __shfl_down(r.s1, 3); d.s2 = __shfl_down(r.s2, 3);
+            r = wrec_combine4(r, b, c, d);
+            stride = 4;
+        }
+        if (ps == 0 && tid == 0) ctl->stamps[1] = wall_clock64();      // (first pass: every workgroup's statistics are in)
+        if (xpeers) {
+            // r (threads with tid % stride == 0) is the record of local block cj: into every rank's inbox, tagged
+            const int cj = (1024 * ps) / lines_per_c + tid / stride;
+            if (tid % stride == 0 && cj < nc_local) {
+                const int gi = a.rank * nc_local + cj;
+                const unsigned long long tag = wrec_hash(r) ^ xkey ^ ((unsigned long long)gi * 0xD6E8FEB86659FD93ull);
+                for (int rr = 0; rr < a.world; ++rr) {
+                    double* o = pf_inbox_recs(a.peers->inbox[rr]) + ((size_t)par * a.rec_cap + gi) * 4;
+                    __hip_atomic_store(o + 0, r.m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(o + 1, r.s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(o + 2, r.s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(o + 3), tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        } else {
+            const WRec pr = wrec_tree256(r, stride, s_w);
+            if (tid == 0 && ps < 16) { s_pass[ps][0] = pr.m; s_pass[ps][1] = pr.s1; s_pass[ps][2] = pr.s2; }
         }
     }
+    int npass = npass_l;
     // ---- this step's state transitions (what pf_stage does on the host): one thread per observation; the state word
-    //      of every observed landmark is still in LDS from the plan.  Written only HERE, after the LAST collect(): every
+    //      of every observed landmark is still in LDS from the plan.  Written only HERE, after the LAST local collect: every
     //      workgroup of the launch has then stored its statistics line, i.e. has long finished planning from the state
     //      words (a grid of more than 1024 workgroups is not resident at once: a workgroup beyond the first 1024 lines
-    //      may not even have started when collect(0) returns). ----
+    //      may not even have started when the first pass returns). ----
     if (tid < a.m && s_first[tid]) {
         const int32_t st = s_st[tid];
         const int tab = st & LS_TAB, rb = (st & LS_BUF) ? 1 : 0;
@@ -1633,37 +1812,52 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
         }
         a.lmstate[s_l[tid]] = LS_SEEN | ((tab ? (rb ^ 1) : rb) ? LS_BUF : 0);
     }
-    block_reduce6<2>(acc, s_r6);
+    if (xpeers) {
+        // ---- every rank's records, as they arrive in THIS rank's inbox (local memory, written by the peers over xGMI): the
+        //      all-gather of the step's statistics.  Every rank reduces the same sequence with the same tree. ----
+        const int nc_global = a.world * nc_local;
+        const double* recs = pf_inbox_recs(a.inbox) + (size_t)par * a.rec_cap * 4;
+        npass = (nc_global + 1023) / 1024;
+        for (int ps = 0; ps < npass; ++ps) {
+            WRec q[4];
+            collect4(recs, 4, 1024 * ps + 4 * tid, nc_global, xkey, true, q);
+            const WRec pr = wrec_tree256(wrec_combine4(q[0], q[1], q[2], q[3]), 1, s_w);
+            if (tid == 0 && ps < 16) { s_pass[ps][0] = pr.m; s_pass[ps][1] = pr.s1; s_pass[ps][2] = pr.s2; }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) ctl->stamps[7] = ctl->stamps[0] + 100ull * (unsigned long long)rounds;      // (diagnostic: polls of thread 0)
     if (tid == 0) {
         ctl->stamps[2] = wall_clock64();
-        double gM = M, gs1 = acc[0], gs2 = acc[1];
-        int err = s_perr;                                     // a workgroup's statistics never came: halt and report
-        if (a.world > 1 && !err) {
-            // all-gather of (max, sum, sum2) among the ranks, two parities (a rank is at most one step ahead of the
-            // slowest).  With peers attached every rank WRITES its record into every rank's inbox (posted stores over
-            // xGMI; its own inbox too) and polls its OWN device memory; the legacy form goes through one page of pinned
-            // host memory that every rank has mapped.  A record is three values and a TAG = hash of their bit patterns
-            // xor key(step) (as the statistics lines of the workgroups, part_key): the reader accepts a record only when
-            // its tag fits the three values it has read and this step's key, so a record that is stale (the parity's
-            // previous step), half arrived or torn is simply polled again -- no ordering between the four stores is
-            // relied on, across a fabric or otherwise.  (No fence: a system-scope release is a write-back of this XCD's
-            // whole L2, which the sweep has just filled with dirty landmark records.)
-            const int par = (int)(a.seq & 1);
-            auto rec_tag = [&](double v0, double v1, double v2) {
-                const unsigned long long b0 = (unsigned long long)__double_as_longlong(v0), b1 = (unsigned long long)__double_as_longlong(v1),
-                                         b2 = (unsigned long long)__double_as_longlong(v2);
-                return ((b0 << 7) | (b0 >> 57)) ^ ((b1 << 23) | (b1 >> 41)) ^ ((b2 << 41) | (b2 >> 23));
-            };
-            const unsigned long long xkey = part_key(a.seq) ^ 0x5851F42D4C957F2Dull;
-            const unsigned long long my_tag = rec_tag(M, acc[0], acc[1]) ^ xkey;
-            for (int r = 0; r < (a.peers ? a.world : 1); ++r) {
-                double* mine = a.peers ? &a.peers->inbox[r]->scal[par][a.rank][0] : a.xchg + ((size_t)par * a.world + a.rank) * 8;
-                __hip_atomic_store(mine + 0, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(mine + 1, acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(mine + 2, acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine + 3), my_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // the passes' nodes -> the root, still the radix-4 tree (absent children are the identity), in place in LDS (a register
+        // array here would raise the whole step kernel's allocation)
+        int cnt = npass < 16 ? npass : 16;
+        auto pget = [&](int k) { return k < cnt ? WRec{s_pass[k][0], s_pass[k][1], s_pass[k][2]} : wrec_empty(); };
+#pragma unroll 1
+        while (cnt > 1) {
+            const int nn = (cnt + 3) / 4;
+#pragma unroll 1
+            for (int k = 0; k < nn; ++k) {
+                const WRec g = wrec_combine4(pget(4 * k), pget(4 * k + 1), pget(4 * k + 2), pget(4 * k + 3));
+                s_pass[k][0] = g.m; s_pass[k][1] = g.s1; s_pass[k][2] = g.s2;
             }
-            const double* page = a.peers ? &a.inbox->scal[par][0][0] : a.xchg + (size_t)par * a.world * 8;
+            cnt = nn;
+        }
+        WRec root = cnt == 1 ? WRec{s_pass[0][0], s_pass[0][1], s_pass[0][2]} : wrec_empty();
+        int err = s_perr;                                     // a workgroup's statistics never came: halt and report
+        if (a.world > 1 && !xpeers && !err) {
+            // the LEGACY exchange (no peers attached): every rank's root {m, s1, s2} through one page of pinned host memory that
+            // every rank has mapped, two parities (a rank is at most one step ahead of the slowest); a record is three values
+            // and a TAG = hash of their bit patterns xor key(step): the reader accepts a record only when its tag fits, so a
+            // record that is stale, half arrived or torn is simply polled again.  The ranks' roots are combined in rank order:
+            // NOT the canonical tree (a rank's root is not a node of it unless the slices are powers of four): this path agrees
+            // with the one-rank filter to a few ulp, the peer path bit for bit.
+            double* mine = a.xchg + ((size_t)par * a.world + a.rank) * 8;
+            __hip_atomic_store(mine + 0, root.m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(mine + 1, root.s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(mine + 2, root.s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine + 3), wrec_hash(root) ^ xkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const double* page = a.xchg + (size_t)par * a.world * 8;
             const unsigned long long t0 = wall_clock64();
             double (*rv)[3] = s_rv;            // (LDS: a dynamically indexed local array would put the whole kernel on scratch)
             for (int r = 0; r < a.world && !err; ++r) {
@@ -1674,27 +1868,24 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
                     rv[r][2] = __hip_atomic_load(slot + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     const unsigned long long tag = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(slot + 3), __ATOMIC_RELAXED,
                                                                      __HIP_MEMORY_SCOPE_SYSTEM);
-                    if ((rec_tag(rv[r][0], rv[r][1], rv[r][2]) ^ tag) == xkey) break;
+                    if ((wrec_hash(WRec{rv[r][0], rv[r][1], rv[r][2]}) ^ tag) == xkey) break;
                     __builtin_amdgcn_s_sleep(20);
                     if (wall_clock64() - t0 > 2000000000ull) { err = PF_ERR_EXCHANGE; break; }     // 20 s at 100 MHz: a rank is gone
                 }
             }
             if (!err) {
-                gM = -__builtin_inf();
-                for (int r = 0; r < a.world; ++r) gM = fmax(gM, rv[r][0]);
-                gs1 = gs2 = 0.0;
-                for (int r = 0; r < a.world; ++r) {                         // every rank folds the same table in rank order
-                    const double f = exp(rv[r][0] - gM);
-                    gs1 += rv[r][1] * f;
-                    gs2 += rv[r][2] * f * f;
-                }
+                root = wrec_empty();
+                for (int r = 0; r < a.world; ++r) root = wrec_combine4(root, WRec{rv[r][0], rv[r][1], rv[r][2]}, wrec_empty(), wrec_empty());
             }
         }
+        // root: m = the largest log-weight, s1 = sum exp(logw - K ln 2), s2 = sum of its squares, K = ceil(m / ln 2)
+        const double gM = root.m, gs1 = root.s1, gs2 = root.s2;
+        const double kshift = wrec_k(gM) * PF_LN2;
         const double lg = log(gs1);
         s_g[0] = gM; s_g[1] = gs1; s_g[2] = gs2;
-        s_g[3] = gM + lg;                                                   // the normalisation shift
+        s_g[3] = kshift + lg;                                               // the normalisation shift = log sum exp(logw)
         s_g[4] = gs1 * gs1 / gs2;                                           // Neff
-        s_g[5] = (double)((T)gM - (T)(gM + lg));                            // the largest log-weight after the shift, as stored
+        s_g[5] = (double)((T)gM - (T)(kshift + lg));                        // the largest log-weight after the shift, as stored
         // (a failed step: outcome 2 = halt, with the error code in the control block; its statistics are not published)
         const int want = err ? 1 : (a.force >= 0 ? a.force : (s_g[4] < a.neff_frac * (double)a.n_global ? 1 : 0));
         s_i[1] = want ? ((a.lazy_ok && !err) ? 1 : 2) : 0;
@@ -1788,6 +1979,16 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void pf_auto_step_kern
     const int pcur = ctl->pcur, tside = ctl->tside, lwcur = ctl->lwcur;
     const double shift_next = ctl->shift_next;
     if (halted != 0 || ctl->error != 0) return;        // an earlier step waits for the host (which replays this one), or failed
+    if constexpr (SH) {
+        // a peer is destroying its handle: touch none of its memory (sweep_load, the inbox writes); the filter is dead
+        if (pf_peer_gone(a.inbox, a.world)) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                ctl->error = PF_ERR_PEER;
+                pf_publish(a.mir, 0.0, (long long)ctl->nresamples, ctl->resample_seq, PF_ERR_PEER, a.seq, a.seq);
+            }
+            return;
+        }
+    }
     PF_XS(1);
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->stamps[0] = wall_clock64();
     __shared__ T s_obs[2 * PF_AUTO_MAXOBS];          // the observations in the state dtype: converted once per workgroup
@@ -1819,22 +2020,22 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void pf_auto_step_kern
     plan_obs(l_pre, st_pre, m, s_l, s_st, s_ids, s_meta, s_first);
     PF_XS(2);
     if (PROPOSAL)
-        proposal_core<T, SH>(pose, (T*)a.lm0, (T*)a.lm1, tabs, logw, n, a.first, a.step, a.seed, (T)a.V, (T)a.G, (T)a.wheelbase, (T)a.a0,
+        proposal_core<T, SH>(pose, LmView<T>{a.lmtab}, tabs, logw, n, a.first, a.step, a.seed, (T)a.V, (T)a.G, (T)a.wheelbase, (T)a.a0,
                              (T)a.a1, (T)a.a2, (T)a.dt, s_obs, s_ids, s_meta, m, (T)a.R00, (T)a.R10, (T)a.R01, (T)a.R11, pend, p, valid, x,
                              y, phi, lw, sc);
     else
-        step_core<T, true, true, SH>(pose, (T*)a.lm0, (T*)a.lm1, tabs, logw, n, a.first, a.step, a.seed, (T)a.V, (T)a.G,
+        step_core<T, true, true, SH>(pose, LmView<T>{a.lmtab}, tabs, logw, n, a.first, a.step, a.seed, (T)a.V, (T)a.G,
                                      (T)a.wheelbase, (T)a.a0, (T)a.a1, (T)a.dt, s_obs, s_ids, s_meta, m, (T)a.R00, (T)a.R10, (T)a.R01,
                                      (T)a.R11, pend, p, valid, x, y, phi, lw, e1, e2, sc);
     PF_XS(4);
     PF_WG(1);
-    block_weight_stats<T, true, false>(lw, x, y, phi, valid, 1, a.part, a.seq);   // a tagged line, not waited for
+    wrec_block_line<T>(lw, valid, a.part, a.seq);          // the tree's 256-particle node as a tagged line, not waited for
     PF_XS(5);
     PF_WG(2);
     // the workgroup with the highest index collects the lines.  The wait cannot deadlock because NO other workgroup waits
     // for anything: each runs to its end on its own, whenever the dispatcher starts it (the dispatch order is not relied
     // on), and the collection ends on a time-out
-    if (blockIdx.x == gridDim.x - 1) pf_auto_tail<T>(a, s_l, s_st, s_first, pcur, tside, lwcur);
+    if (blockIdx.x == gridDim.x - 1) pf_auto_tail<T>(a, s_l, s_st, s_first, pcur, tside, lwcur, 1);
 }
 
 // ---- the same step with the OBSERVATIONS in parallel (small filters / shards) -----------------------------------------
@@ -1865,6 +2066,15 @@ __global__ __launch_bounds__(64 * PAR_WAVES) void pf_auto_step_par_kernel(PfAuto
     const int pcur = ctl->pcur, tside = ctl->tside, lwcur = ctl->lwcur;
     const double shift_next = ctl->shift_next;
     if (halted != 0 || ctl->error != 0) return;
+    if constexpr (SH) {
+        if (pf_peer_gone(a.inbox, a.world)) {              // (see pf_auto_step_kernel)
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                ctl->error = PF_ERR_PEER;
+                pf_publish(a.mir, 0.0, (long long)ctl->nresamples, ctl->resample_seq, PF_ERR_PEER, a.seq, a.seq);
+            }
+            return;
+        }
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->stamps[0] = wall_clock64();
     __shared__ T s_obs[2 * PF_AUTO_MAXOBS];
     __shared__ int32_t s_ids[PF_AUTO_MAXOBS], s_meta[PF_AUTO_MAXOBS], s_l[PF_AUTO_MAXOBS], s_st[PF_AUTO_MAXOBS], s_first[PF_AUTO_MAXOBS];
@@ -1904,19 +2114,18 @@ __global__ __launch_bounds__(64 * PAR_WAVES) void pf_auto_step_par_kernel(PfAuto
     plan_obs(l_pre, st_pre, m, s_l, s_st, s_ids, s_meta, s_first);       // (two barriers: the pose is in LDS behind them)
     if (wave != 0) { x = s_pose[0][lane]; y = s_pose[1][lane]; phi = s_pose[2][lane]; }
     const T R00 = (T)a.R00, R10 = (T)a.R10, R01 = (T)a.R01, R11 = (T)a.R11;
-    T* lm0 = (T*)a.lm0;
-    T* lm1 = (T*)a.lm1;
+    const LmView<T> lv{a.lmtab};
     for (int i = wave; i < m; i += PAR_WAVES) {          // F2 / F3: this wave's observations (uniform per wave)
         const int32_t code = __builtin_amdgcn_readfirstlane(s_ids[i]), meta = __builtin_amdgcn_readfirstlane(s_meta[i]);
         const int l = code & ID_MASK;
         const T r = s_obs[2 * i], b = s_obs[2 * i + 1];
-        const BufRow<T, decltype(lm_rsrc<T>(lm0, n))> row{lm_rsrc<T>(((meta & META_WBUF) ? lm1 : lm0) + (size_t)l * 5 * n, n),
+        const BufRow<T, decltype(lm_rsrc<T>((const T*)nullptr, n))> row{lm_rsrc<T>(lv.rows((meta & META_WBUF) ? 1 : 0, l, n), n),
                                                           (uint32_t)p * (uint32_t)sizeof(T), (uint32_t)n * (uint32_t)sizeof(T)};
         T term = 0;
         if (code & NEW_FLAG) {
             lm_init<T>(row, n, x, y, phi, r, b, R00, R10, R01, R11, valid);
         } else {
-            const LmRow<T> cur = sweep_load<T, 2, SH>(lm0, lm1, tabs, n, (uint32_t)p, code, meta, sc);
+            const LmRow<T> cur = sweep_load<T, 2, SH>(lv, tabs, n, (uint32_t)p, code, meta, sc);
             lm_update<T>(row, n, cur, x, y, phi, r, b, R00, R10, R01, R11, valid, term);      // term = 0 + (this observation's log-weight term)
         }
         s_term[i][lane] = term;
@@ -1928,10 +2137,13 @@ __global__ __launch_bounds__(64 * PAR_WAVES) void pf_auto_step_par_kernel(PfAuto
             if (!(__builtin_amdgcn_readfirstlane(s_ids[i]) & NEW_FLAG)) lw += s_term[i][lane];     // observation order
         if (valid) logw[p] = lw;
     }
-    block_weight_stats<T, true, false>(lw, x, y, phi, valid && wave == 0, 1, a.part, a.seq);
+    if (wave == 0) {                                       // the tree's leaf (this workgroup's 64 particles) as a tagged line
+        const WRec leaf = wrec_wave<T>(lw, valid);
+        if (lane == 0) wrec_store_line(a.part, (int)blockIdx.x, leaf, a.seq);
+    }
     if (blockIdx.x == gridDim.x - 1) {
         if (threadIdx.x >= 256) return;                  // the tail is written for four waves
-        pf_auto_tail<T>(a, s_l, s_st, s_first, pcur, tside, lwcur);
+        pf_auto_tail<T>(a, s_l, s_st, s_first, pcur, tside, lwcur, 0);
     }
 }
 
@@ -1952,9 +2164,16 @@ __global__ __launch_bounds__(64 * PAR_WAVES) void pf_auto_step_par_kernel(PfAuto
 //             step-s state reads buffers nobody writes.  Why no further hand-shake is needed: a rank writes those old
 //             sides again at its resampling s' > s at the earliest, which needs every rank's scalars of step s', which
 //             a rank publishes only after its own resampling s has completed (stream order).
+// one lane: "rank `rank` is going away" into every peer's inbox (slam_pf_destroy of a handle that is still attached)
+__global__ void pf_peer_gone_kernel(const PfPeers* __restrict__ peers, int rank, int world) {
+    const int r = threadIdx.x;
+    if (r < world && r != rank) __hip_atomic_store(&peers->inbox[r]->gone[rank][0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ __launch_bounds__(64) void pf_peer_gate_kernel(PfCtl* ctl, long long seq, const PfPeers* __restrict__ peers,
                                                           PfInbox* inbox, int rank, int world) {
     if (ctl->resample_seq != seq || ctl->error != 0) return;
+    if (pf_peer_gone(inbox, world)) { ctl->error = PF_ERR_PEER; return; }       // (the kernels behind this one return on ctl->error)
     const int r = threadIdx.x;
     if (r < world) {
         __hip_atomic_store(&peers->inbox[r]->ready[rank][0], (unsigned long long)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1969,6 +2188,7 @@ __global__ __launch_bounds__(64) void pf_peer_gate_kernel(PfCtl* ctl, long long 
 // A barrier among the ranks on their streams (materialise): every rank counts its calls, tells every peer, waits for all.
 __global__ __launch_bounds__(64) void pf_peer_barrier_kernel(int32_t* err, unsigned long long count, const PfPeers* __restrict__ peers,
                                                              PfInbox* inbox, int rank, int world, unsigned long long timeout_ticks) {
+    if (pf_peer_gone(inbox, world)) { *err = PF_ERR_PEER; return; }
     const int r = threadIdx.x;
     if (r < world) {
         __hip_atomic_store(&peers->inbox[r]->bar[rank][0], count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2150,11 +2370,24 @@ extern "C" int slam_pf_destroy(slam_pf_t h) {
     if (!h) return SLAM_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->d_peers && h->xchg_world > 1) {
+        // Destroyed while still attached (the orderly way is slam_pf_detach_peers on every rank first, then destroy): the peers
+        // may have kernels queued that read THIS rank's buffers.  Tell them before anything is freed -- every kernel of a sharded
+        // filter that touches peer memory first looks at its inbox's `gone` words and stops with PF_ERR_PEER -- and give
+        // kernels already in flight (a step is tens of microseconds) time to end.  Best effort: a peer's kernel that started
+        // between the word and the free can still fault; detach first.
+        hipLaunchKernelGGL(pf_peer_gone_kernel, dim3(1), dim3(64), 0, h->stream, (const PfPeers*)h->d_peers, h->xchg_rank, h->xchg_world);
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(h->stream);
+        usleep(5000);
+    }
+    pf_detach_peers_impl(h);                 // this rank's mappings of the peers' buffers are closed before anything is freed
     for (int b = 0; b < 2; ++b) {
         if (h->pose[b]) (void)hipFree(h->pose[b]);
-        if (h->lm[b]) (void)hipFree(h->lm[b]);
+        for (int k = 0; k < PF_LM_MAXC; ++k)
+            if (h->lmtab.c[b][k]) (void)hipFree(h->lmtab.c[b][k]);
     }
-    pf_detach_peers_impl(h);
+    if (h->d_lmtab) (void)hipFree(h->d_lmtab);
     void* devs[] = {h->logw2[0], h->logw2[1], h->d_part, h->d_out, h->d_cdf, h->d_bsum, h->d_src, h->d_anc, h->d_tab[0], h->d_tab[1],
                     h->d_lmeta, h->d_ctl, h->d_lmstate, h->inbox};
     if (h->xchg_host) (void)hipHostUnregister(h->xchg_host);
@@ -2176,21 +2409,42 @@ static int pf_create_impl(slam_pf* h) {
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     int rc;
     const size_t n = (size_t)h->n;
+    // the landmark records in chunks of 2^shift landmarks (PfLmTab): the largest power of two whose chunk stays within 1 GiB,
+    // doubled while the buffer would need more than PF_LM_MAXC chunks (a chunk above 2047 MiB cannot be exported to another
+    // process -- slam_pf_attach_peers refuses such a peer -- but works locally)
+    {
+        const size_t per_lm = h->esz * 5 * n;
+        int shift = 0;
+        while (shift < 20 && (per_lm << (shift + 1)) <= ((size_t)1 << 30)) ++shift;
+        while ((((size_t)h->nl + ((size_t)1 << shift) - 1) >> shift) > (size_t)PF_LM_MAXC) ++shift;
+        h->lmtab.shift = shift;
+        h->lmtab.nchunks = (int)(((size_t)h->nl + ((size_t)1 << shift) - 1) >> shift);
+        h->lm_chunk_bytes = per_lm << shift;
+    }
     for (int b = 0; b < 2; ++b) {
         if ((rc = pf_alloc(&h->pose[b], h->esz * 3 * n, h->stream))) return rc;
-        if ((rc = pf_alloc(&h->lm[b], h->esz * 5 * n * (size_t)h->nl, h->stream))) return rc;
+        for (int k = 0; k < h->lmtab.nchunks; ++k) {
+            // (the last chunk holds what is left of the nl landmarks)
+            const size_t lms = (size_t)h->nl - ((size_t)k << h->lmtab.shift) < ((size_t)1 << h->lmtab.shift)
+                                   ? (size_t)h->nl - ((size_t)k << h->lmtab.shift) : ((size_t)1 << h->lmtab.shift);
+            if ((rc = pf_alloc(&h->lmtab.c[b][k], h->esz * 5 * n * lms, h->stream))) return rc;
+        }
     }
+    HIP_TRY(hipMalloc((void**)&h->d_lmtab, sizeof(PfLmTab)));
+    HIP_TRY(hipMemcpy(h->d_lmtab, &h->lmtab, sizeof(PfLmTab), hipMemcpyHostToDevice));
     for (int b = 0; b < 2; ++b)
         if ((rc = pf_alloc(&h->logw2[b], h->esz * n, h->stream))) return rc;
     h->lwcur = 0;
     h->logw = h->logw2[0];
     // the inbox the peers of a sharded filter write into: fine-grained device memory (polled while a peer GPU writes it)
-    if (hipExtMallocWithFlags((void**)&h->inbox, sizeof(PfInbox), hipDeviceMallocFinegrained) != hipSuccess) {
+    // (header + the ranks' 1024-particle weight records of a step, two parities: 17 KB at 262144 particles)
+    h->inbox_bytes = pf_inbox_bytes(h->n_global);
+    if (hipExtMallocWithFlags((void**)&h->inbox, h->inbox_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
         (void)hipGetLastError();
         h->inbox = nullptr;
-        HIP_TRY(hipMalloc((void**)&h->inbox, sizeof(PfInbox)));
+        HIP_TRY(hipMalloc((void**)&h->inbox, h->inbox_bytes));
     }
-    HIP_TRY(hipMemsetAsync(h->inbox, 0, sizeof(PfInbox), h->stream));
+    HIP_TRY(hipMemsetAsync(h->inbox, 0, h->inbox_bytes, h->stream));
     h->ocap = PF_OCAP;
     h->red_blocks = grid_for(h->n);                  // one partial record per 256 particles
     // (room for one statistics line per 64 particles: the observation-parallel step kernel's workgroups)
@@ -2258,7 +2512,8 @@ extern "C" int slam_pf_create(slam_pf_t* out, int dtype, int64_t n_local, int64_
     h->prior.assign(max_landmarks, -1);
     h->d_tab[0] = h->d_tab[1] = nullptr; h->d_lmeta = nullptr; h->tside = 0; h->lazy_dirty = 0;
     h->lazy_off = getenv("SLAMHIP_PF_EAGER") && atoi(getenv("SLAMHIP_PF_EAGER")) ? 1 : 0;
-    h->pose[0] = h->pose[1] = h->lm[0] = h->lm[1] = h->logw = h->logw2[0] = h->logw2[1] = nullptr;
+    h->pose[0] = h->pose[1] = h->logw = h->logw2[0] = h->logw2[1] = nullptr;
+    memset(&h->lmtab, 0, sizeof(h->lmtab)); h->d_lmtab = nullptr; h->lm_chunk_bytes = 0;
     h->lwcur = 0; h->d_peers = nullptr; h->inbox = nullptr; h->bar_count = 0; h->halts = 0;
     h->par_max_n = slam_exp_env("SLAMHIP_PF_PAR_MAX", PF_PAR_MAX_N);      // (the knob is read by the experiments build only)
     memset(&h->peers, 0, sizeof(h->peers));
@@ -2324,15 +2579,15 @@ static int pf_materialise(slam_pf* h) {
         const dim3 grid(grid_for(h->n), (h->nl + MAT_LMS - 1) / MAT_LMS);
         if (sh)
             PF_DISPATCH(h,
-                        hipLaunchKernelGGL((pf_materialise_kernel<T, true>), grid, dim3(256), 0, h->stream, (T*)h->lm[0], (T*)h->lm[1],
+                        hipLaunchKernelGGL((pf_materialise_kernel<T, true>), grid, dim3(256), 0, h->stream, LmView<T>{h->d_lmtab},
                                            (const int32_t*)h->d_tab[h->tside], h->n, h->nl, (const int32_t*)h->d_lmeta, sc),
-                        hipLaunchKernelGGL((pf_materialise_kernel<T, true>), grid, dim3(256), 0, h->stream, (T*)h->lm[0], (T*)h->lm[1],
+                        hipLaunchKernelGGL((pf_materialise_kernel<T, true>), grid, dim3(256), 0, h->stream, LmView<T>{h->d_lmtab},
                                            (const int32_t*)h->d_tab[h->tside], h->n, h->nl, (const int32_t*)h->d_lmeta, sc));
         else
             PF_DISPATCH(h,
-                        hipLaunchKernelGGL((pf_materialise_kernel<T, false>), grid, dim3(256), 0, h->stream, (T*)h->lm[0], (T*)h->lm[1],
+                        hipLaunchKernelGGL((pf_materialise_kernel<T, false>), grid, dim3(256), 0, h->stream, LmView<T>{h->d_lmtab},
                                            (const int32_t*)h->d_tab[h->tside], h->n, h->nl, (const int32_t*)h->d_lmeta, sc),
-                        hipLaunchKernelGGL((pf_materialise_kernel<T, false>), grid, dim3(256), 0, h->stream, (T*)h->lm[0], (T*)h->lm[1],
+                        hipLaunchKernelGGL((pf_materialise_kernel<T, false>), grid, dim3(256), 0, h->stream, LmView<T>{h->d_lmtab},
                                            (const int32_t*)h->d_tab[h->tside], h->n, h->nl, (const int32_t*)h->d_lmeta, sc));
         HIP_TRY(hipGetLastError());
         for (int l = 0; l < h->nl; ++l)
@@ -2434,9 +2689,9 @@ extern "C" int slam_pf_init_landmarks(slam_pf_t h, const double* lm_xy, int nl, 
     HIP_TRY(hipMalloc((void**)&d_xy, sizeof(double) * 2 * nl));
     HIP_TRY(hipMemcpyAsync(d_xy, lm_xy, sizeof(double) * 2 * nl, hipMemcpyHostToDevice, h->stream));
     PF_DISPATCH(h,
-                hipLaunchKernelGGL(pf_init_lm_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->lm[h->cur],
+                hipLaunchKernelGGL(pf_init_lm_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, LmView<T>{h->d_lmtab}, h->cur,
                                    h->n, h->first, h->seed, d_xy, nl, (T)var, (T)jitter_sigma),
-                hipLaunchKernelGGL(pf_init_lm_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->lm[h->cur],
+                hipLaunchKernelGGL(pf_init_lm_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, LmView<T>{h->d_lmtab}, h->cur,
                                    h->n, h->first, h->seed, d_xy, nl, (T)var, (T)jitter_sigma));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -2553,10 +2808,10 @@ extern "C" int slam_pf_update_known(slam_pf_t h, const double* z, const int32_t*
     const double pend = pf_take_pending(h);              // a deferred normalisation shift is applied on the way
     PF_DISPATCH(h,
                 hipLaunchKernelGGL((pf_step_kernel<T, false, false>), dim3(grid_for(h->n)), dim3(256), (size_t)m * 24, h->stream,
-                                   (T*)h->pose[h->pcur], (T*)h->lm[0], (T*)h->lm[1], h->d_tab[h->tside], (T*)h->logw, h->n, h->first, 0u, h->seed, (T)0, (T)0,
+                                   (T*)h->pose[h->pcur], LmView<T>{h->d_lmtab}, h->d_tab[h->tside], (T*)h->logw, h->n, h->first, 0u, h->seed, (T)0, (T)0,
                                    (T)1, (T)0, (T)0, (T)0, dz, di, m, (T)R[0], (T)R[1], (T)R[2], (T)R[3], (double*)nullptr, (T)pend),
                 hipLaunchKernelGGL((pf_step_kernel<T, false, false>), dim3(grid_for(h->n)), dim3(256), (size_t)m * 24, h->stream,
-                                   (T*)h->pose[h->pcur], (T*)h->lm[0], (T*)h->lm[1], h->d_tab[h->tside], (T*)h->logw, h->n, h->first, 0u, h->seed, (T)0, (T)0,
+                                   (T*)h->pose[h->pcur], LmView<T>{h->d_lmtab}, h->d_tab[h->tside], (T*)h->logw, h->n, h->first, 0u, h->seed, (T)0, (T)0,
                                    (T)1, (T)0, (T)0, (T)0, dz, di, m, (T)R[0], (T)R[1], (T)R[2], (T)R[3], (double*)nullptr, (T)pend));
     HIP_TRY(hipGetLastError());
     return pf_stage_done(h);
@@ -2611,11 +2866,11 @@ extern "C" int slam_pf_step(slam_pf_t h, double V, double G, double wheelbase, c
     const double pend = pf_take_pending(h);
     PF_DISPATCH(h,
                 hipLaunchKernelGGL((pf_step_kernel<T, true, true>), dim3(grid_for(h->n)), dim3(256), (size_t)m * 24, h->stream,
-                                   (T*)h->pose[h->pcur], (T*)h->lm[0], (T*)h->lm[1], h->d_tab[h->tside], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
+                                   (T*)h->pose[h->pcur], LmView<T>{h->d_lmtab}, h->d_tab[h->tside], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
                                    (T)G, (T)wheelbase, (T)sV, (T)sG, (T)dt, dz, di, m, (T)Rz[0], (T)Rz[1], (T)Rz[2], (T)Rz[3],
                                    h->d_part, (T)pend),
                 hipLaunchKernelGGL((pf_step_kernel<T, true, true>), dim3(grid_for(h->n)), dim3(256), (size_t)m * 24, h->stream,
-                                   (T*)h->pose[h->pcur], (T*)h->lm[0], (T*)h->lm[1], h->d_tab[h->tside], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
+                                   (T*)h->pose[h->pcur], LmView<T>{h->d_lmtab}, h->d_tab[h->tside], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
                                    (T)G, (T)wheelbase, (T)sV, (T)sG, (T)dt, dz, di, m, (T)Rz[0], (T)Rz[1], (T)Rz[2], (T)Rz[3],
                                    h->d_part, (T)pend));
     HIP_TRY(hipGetLastError());
@@ -2651,11 +2906,11 @@ extern "C" int slam_pf_step_proposal(slam_pf_t h, double V, double G, double whe
     const double pend = pf_take_pending(h);
     PF_DISPATCH(h,
                 hipLaunchKernelGGL(pf_proposal_kernel<T>, dim3(grid_for(h->n)), dim3(256), (size_t)m * 24, h->stream,
-                                   (T*)h->pose[h->pcur], (T*)h->lm[0], (T*)h->lm[1], h->d_tab[h->tside], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
+                                   (T*)h->pose[h->pcur], LmView<T>{h->d_lmtab}, h->d_tab[h->tside], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
                                    (T)G, (T)wheelbase, (T)lq00, (T)lq10, (T)lq11, (T)dt, dz, di, m, (T)Rz[0], (T)Rz[1], (T)Rz[2],
                                    (T)Rz[3], h->d_part, (T)pend),
                 hipLaunchKernelGGL(pf_proposal_kernel<T>, dim3(grid_for(h->n)), dim3(256), (size_t)m * 24, h->stream,
-                                   (T*)h->pose[h->pcur], (T*)h->lm[0], (T*)h->lm[1], h->d_tab[h->tside], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
+                                   (T*)h->pose[h->pcur], LmView<T>{h->d_lmtab}, h->d_tab[h->tside], (T*)h->logw, h->n, h->first, h->step, h->seed, (T)V,
                                    (T)G, (T)wheelbase, (T)lq00, (T)lq10, (T)lq11, (T)dt, dz, di, m, (T)Rz[0], (T)Rz[1], (T)Rz[2],
                                    (T)Rz[3], h->d_part, (T)pend));
     HIP_TRY(hipGetLastError());
@@ -2673,8 +2928,8 @@ extern "C" int slam_pf_clear_landmarks(slam_pf_t h) {
     HIP_TRY(hipSetDevice(h->device));
     PF_LEGACY_ENTRY(h);
     PF_DISPATCH(h,
-                hipLaunchKernelGGL(pf_clear_lm_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->lm[h->cur], h->n, h->nl),
-                hipLaunchKernelGGL(pf_clear_lm_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, (T*)h->lm[h->cur], h->n, h->nl));
+                hipLaunchKernelGGL(pf_clear_lm_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, LmView<T>{h->d_lmtab}, h->cur, h->n, h->nl),
+                hipLaunchKernelGGL(pf_clear_lm_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream, LmView<T>{h->d_lmtab}, h->cur, h->n, h->nl));
     HIP_TRY(hipGetLastError());
     for (int l = 0; l < h->nl; ++l) {
         h->seen[l] = 0;
@@ -2706,10 +2961,10 @@ extern "C" int slam_pf_update_unknown(slam_pf_t h, const double* z, int m, const
     const double pend = pf_take_pending(h);
     PF_DISPATCH(h,
                 hipLaunchKernelGGL(pf_update_unknown_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream,
-                                   (const T*)h->pose[h->pcur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->nl, dz, m, (T)R[0], (T)R[1],
+                                   (const T*)h->pose[h->pcur], LmView<T>{h->d_lmtab}, h->cur, (T*)h->logw, h->n, h->nl, dz, m, (T)R[0], (T)R[1],
                                    (T)R[2], (T)R[3], (T)gate1, (T)gate2, (T)pend, d_assoc),
                 hipLaunchKernelGGL(pf_update_unknown_kernel<T>, dim3(grid_for(h->n)), dim3(256), 0, h->stream,
-                                   (const T*)h->pose[h->pcur], (T*)h->lm[h->cur], (T*)h->logw, h->n, h->nl, dz, m, (T)R[0], (T)R[1],
+                                   (const T*)h->pose[h->pcur], LmView<T>{h->d_lmtab}, h->cur, (T*)h->logw, h->n, h->nl, dz, m, (T)R[0], (T)R[1],
                                    (T)R[2], (T)R[3], (T)gate1, (T)gate2, (T)pend, d_assoc));
     HIP_TRY(hipGetLastError());
     return pf_stage_done(h);
@@ -2867,9 +3122,9 @@ extern "C" int slam_pf_pack(slam_pf_t h, const int32_t* d_local_idx, int cnt, vo
     const dim3 grid((cnt + 255) / 256, 3 + 5 * h->nl);
     PF_DISPATCH(h,
                 hipLaunchKernelGGL(pf_pack_kernel<T>, grid, dim3(256), 0, h->stream, (const T*)h->pose[h->pcur],
-                                   (const T*)h->lm[h->cur], h->n, d_local_idx, cnt, (T*)d_records),
+                                   LmView<T>{h->d_lmtab}, h->cur, h->n, d_local_idx, cnt, (T*)d_records),
                 hipLaunchKernelGGL(pf_pack_kernel<T>, grid, dim3(256), 0, h->stream, (const T*)h->pose[h->pcur],
-                                   (const T*)h->lm[h->cur], h->n, d_local_idx, cnt, (T*)d_records));
+                                   LmView<T>{h->d_lmtab}, h->cur, h->n, d_local_idx, cnt, (T*)d_records));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     return SLAM_OK;
@@ -2907,10 +3162,10 @@ extern "C" int slam_pf_resample_apply(slam_pf_t h, const int32_t* d_anc, const i
     const dim3 grid(grid_for(h->n), (nrows + GATHER_ROWS - 1) / GATHER_ROWS);
     PF_DISPATCH(h,
                 hipLaunchKernelGGL(pf_gather_kernel<T>, grid, dim3(256), 0, h->stream, (const T*)h->pose[h->pcur],
-                                   (const T*)h->lm[h->cur], (T*)h->pose[pnxt], (T*)h->lm[nxt], h->n, nrows, h->d_src,
+                                   LmView<T>{h->d_lmtab}, h->cur, (T*)h->pose[pnxt], nxt, h->n, nrows, h->d_src,
                                    (const T*)d_remote_records, nremote),
                 hipLaunchKernelGGL(pf_gather_kernel<T>, grid, dim3(256), 0, h->stream, (const T*)h->pose[h->pcur],
-                                   (const T*)h->lm[h->cur], (T*)h->pose[pnxt], (T*)h->lm[nxt], h->n, nrows, h->d_src,
+                                   LmView<T>{h->d_lmtab}, h->cur, (T*)h->pose[pnxt], nxt, h->n, nrows, h->d_src,
                                    (const T*)d_remote_records, nremote));
     (void)pf_take_pending(h);                          // logw is overwritten: a deferred shift is moot
     PF_DISPATCH(h,
@@ -2934,7 +3189,13 @@ extern "C" int slam_pf_download(slam_pf_t h, void* pose, void* logw, void* lm) {
     if (lm) { const int rcm = pf_materialise(h); if (rcm) return rcm; }
     if (pose) HIP_TRY(hipMemcpyAsync(pose, h->pose[h->pcur], h->esz * 3 * n, hipMemcpyDeviceToHost, h->stream));
     if (logw) HIP_TRY(hipMemcpyAsync(logw, h->logw, h->esz * n, hipMemcpyDeviceToHost, h->stream));
-    if (lm) HIP_TRY(hipMemcpyAsync(lm, h->lm[h->cur], h->esz * 5 * n * (size_t)h->nl, hipMemcpyDeviceToHost, h->stream));
+    if (lm)                          // chunk by chunk into the caller's contiguous [nl][5][n]
+        for (int k = 0; k < h->lmtab.nchunks; ++k) {
+            const size_t l0 = (size_t)k << h->lmtab.shift;
+            const size_t lms = (size_t)h->nl - l0 < ((size_t)1 << h->lmtab.shift) ? (size_t)h->nl - l0 : ((size_t)1 << h->lmtab.shift);
+            HIP_TRY(hipMemcpyAsync((char*)lm + h->esz * 5 * n * l0, h->lmtab.c[h->cur][k], h->esz * 5 * n * lms, hipMemcpyDeviceToHost,
+                                   h->stream));
+        }
     HIP_TRY(hipStreamSynchronize(h->stream));
     return SLAM_OK;
 }
@@ -3044,12 +3305,13 @@ static int pf_auto_enqueue(slam_pf* h, const PfStepRec& r) {
     PfAutoArgs a;
     memset(&a, 0, sizeof(a));
     for (int i = 0; i < r.m; ++i) { a.z[2 * i] = r.z[2 * i]; a.z[2 * i + 1] = r.z[2 * i + 1]; a.ids[i] = r.ids[i]; }
-    a.pose0 = h->pose[0]; a.pose1 = h->pose[1]; a.lm0 = h->lm[0]; a.lm1 = h->lm[1]; a.logw0 = h->logw2[0]; a.logw1 = h->logw2[1];
+    a.pose0 = h->pose[0]; a.pose1 = h->pose[1]; a.lmtab = h->d_lmtab; a.logw0 = h->logw2[0]; a.logw1 = h->logw2[1];
     a.tab0 = h->d_tab[0]; a.tab1 = h->d_tab[1];
     a.n = h->n; a.first = h->first; a.n_global = h->n_global; a.seq = r.seq;
     a.seed = h->seed; a.step = r.rng_step;
     a.m = r.m; a.nl = h->nl; a.force = r.force; a.lazy_ok = pf_auto_lazy_ok(h) ? 1 : 0;
     a.rank = h->xchg_rank; a.world = h->xchg_world;
+    a.rec_cap = (int)((h->n_global + 1023) / 1024) + PF_MAX_WORLD;
     a.publish = (r.seq % PF_PUBLISH_EVERY) == 0 ? 1 : 0;
     if (a.publish && r.seq > h->pub_seq) h->pub_seq = r.seq;
     a.V = r.V; a.G = r.G; a.wheelbase = r.wheelbase; a.dt = r.dt;
@@ -3347,16 +3609,37 @@ extern "C" int slam_pf_attach_exchange(slam_pf_t h, int rank, int world, void* p
  * inbox page, or -- same process, e.g. one host thread per GPU -- the raw device pointers), the caller moves the blobs
  * between the ranks by whatever it has (MPI, files, torch.distributed ...), and every rank attaches all of them in
  * rank order.  From then on slam_pf_step_auto resamples the sharded filter on the device (no SLAM_PF_HALTED). */
+constexpr int PF_BLOB_FIXED = 7;                                  // pose0, pose1, logw0, logw1, tab0, tab1, inbox
+constexpr int PF_BLOB_MAXH = PF_BLOB_FIXED + 2 * PF_LM_MAXC;      // ... then the landmark chunks: buffer 0's, buffer 1's
 struct PfPeerBlob {
     uint64_t magic;
     int64_t pid;
-    int32_t device, dtype, nl, reserved;
-    int64_t n;
-    void* raw[9];                     // pose0, pose1, lm0, lm1, logw0, logw1, tab0, tab1, inbox
-    hipIpcMemHandle_t ipc[9];
+    int32_t device, dtype, nl, lm_shift, lm_nchunks, reserved;
+    int64_t n, n_global;
+    uint64_t lm_chunk_bytes, inbox_bytes;
+    void* raw[PF_BLOB_MAXH];
+    hipIpcMemHandle_t ipc[PF_BLOB_MAXH];
 };
 static_assert(sizeof(PfPeerBlob) <= SLAM_PF_PEER_BLOB_BYTES, "peer blob");
-constexpr uint64_t PF_BLOB_MAGIC = 0x534c414d50465033ull;      // "SLAMPFP3"
+constexpr uint64_t PF_BLOB_MAGIC = 0x534c414d50465034ull;      // "SLAMPFP4"
+// What an IPC mapping may carry on this runtime (ROCm 7.2, dmabuf IPC; DESIGN section 7 has the records):
+//   * hipIpcOpenMemHandle of an allocation above 2 GiB never returns (1.91 GiB opens in milliseconds, 2.50 GiB hangs both
+//     processes): every exported buffer must stay below PF_IPC_MAX_BYTES -- the landmark records are chunked for that reason;
+//   * the import of a FINE-GRAINED (hipExtMallocWithFlags) allocation larger than one 2 MiB fragment was seen with only its
+//     first 2 MiB mapped (tools/ipc_probe.hip: page fault at import + 2 MiB in 3 of 7 runs; plain hipMalloc imports of the same
+//     size never): the only fine-grained export is the inbox, which must stay within PF_IPC_FINE_MAX_BYTES.
+// slam_pf_attach_peers checks both BEFORE opening anything and refuses with SLAM_E_CAPACITY (the caller keeps the halting flow).
+constexpr uint64_t PF_IPC_MAX_BYTES = 2047ull << 20;
+constexpr uint64_t PF_IPC_FINE_MAX_BYTES = 2ull << 20;
+
+static int pf_blob_handles(const slam_pf* h, void* ptrs[PF_BLOB_MAXH]) {
+    ptrs[0] = h->pose[0]; ptrs[1] = h->pose[1]; ptrs[2] = h->logw2[0]; ptrs[3] = h->logw2[1];
+    ptrs[4] = h->d_tab[0]; ptrs[5] = h->d_tab[1]; ptrs[6] = h->inbox;
+    int cnt = PF_BLOB_FIXED;
+    for (int b = 0; b < 2; ++b)
+        for (int k = 0; k < h->lmtab.nchunks; ++k) ptrs[cnt++] = h->lmtab.c[b][k];
+    return cnt;
+}
 
 extern "C" int slam_pf_export_peer(slam_pf_t h, void* blob) {
     ARG_CHECK(h != nullptr && blob != nullptr, "null argument");
@@ -3365,9 +3648,11 @@ extern "C" int slam_pf_export_peer(slam_pf_t h, void* blob) {
     memset(&b, 0, sizeof(b));
     b.magic = PF_BLOB_MAGIC;
     b.pid = (int64_t)getpid();
-    b.device = h->device; b.dtype = h->dtype; b.nl = h->nl; b.n = h->n;
-    void* ptrs[9] = {h->pose[0], h->pose[1], h->lm[0], h->lm[1], h->logw2[0], h->logw2[1], h->d_tab[0], h->d_tab[1], h->inbox};
-    for (int i = 0; i < 9; ++i) {
+    b.device = h->device; b.dtype = h->dtype; b.nl = h->nl; b.n = h->n; b.n_global = h->n_global;
+    b.lm_shift = h->lmtab.shift; b.lm_nchunks = h->lmtab.nchunks; b.lm_chunk_bytes = h->lm_chunk_bytes; b.inbox_bytes = h->inbox_bytes;
+    void* ptrs[PF_BLOB_MAXH];
+    const int cnt = pf_blob_handles(h, ptrs);
+    for (int i = 0; i < cnt; ++i) {
         b.raw[i] = ptrs[i];
         HIP_TRY(hipIpcGetMemHandle(&b.ipc[i], ptrs[i]));
     }
@@ -3379,7 +3664,7 @@ extern "C" int slam_pf_export_peer(slam_pf_t h, void* blob) {
 static void pf_detach_peers_impl(slam_pf* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int r = 0; r < PF_MAX_WORLD; ++r)
-        for (int i = 0; i < 9; ++i)
+        for (int i = 0; i < PF_BLOB_MAXH; ++i)
             if (h->peer_open[r][i]) {
                 (void)hipIpcCloseMemHandle(h->peer_open[r][i]);
                 h->peer_open[r][i] = nullptr;
@@ -3412,34 +3697,46 @@ extern "C" int slam_pf_attach_peers(slam_pf_t h, int rank, int world, const void
     const int64_t me = (int64_t)getpid();
     PfPeers t;
     memset(&t, 0, sizeof(t));
+    // pass 0 checks every blob (nothing is opened before all of them are acceptable), pass 1 opens
+    for (int pass = 0; pass < 2; ++pass)
     for (int r = 0; r < world; ++r) {
         PfPeerBlob b;
         memcpy(&b, (const char*)blobs + (size_t)r * SLAM_PF_PEER_BLOB_BYTES, sizeof(b));
-        ARG_CHECK(b.magic == PF_BLOB_MAGIC, "a peer blob is not one of slam_pf_export_peer's");
-        ARG_CHECK(b.n == h->n && b.nl == h->nl && b.dtype == h->dtype, "the peers' shards differ in size or type");
-        void* ptr[9];
-        if (r == rank) {
-            ARG_CHECK(b.pid == me && b.raw[0] == h->pose[0], "blob [rank] is not this handle's own export");
-            for (int i = 0; i < 9; ++i) ptr[i] = b.raw[i];
-        } else if (b.pid == me) {                           // a shard of this very process: plain pointers
-            if (b.device != h->device) {
+        const int cnt = PF_BLOB_FIXED + 2 * b.lm_nchunks;
+        if (pass == 0) {
+            ARG_CHECK(b.magic == PF_BLOB_MAGIC, "a peer blob is not one of slam_pf_export_peer's");
+            ARG_CHECK(b.n == h->n && b.nl == h->nl && b.dtype == h->dtype && b.n_global == h->n_global, "the peers' shards differ in size or type");
+            ARG_CHECK(b.lm_shift == h->lmtab.shift && b.lm_nchunks == h->lmtab.nchunks && b.lm_nchunks >= 1 && b.lm_nchunks <= PF_LM_MAXC,
+                      "the peers' landmark chunking differs");
+            if (r == rank) ARG_CHECK(b.pid == me && b.raw[0] == h->pose[0], "blob [rank] is not this handle's own export");
+            if (r != rank && b.pid != me) {
+                // the shapes this runtime's IPC mappings cannot carry (see PF_IPC_MAX_BYTES): refuse BEFORE opening anything
+                const uint64_t n64 = (uint64_t)b.n, esz = (uint64_t)h->esz;
+                const uint64_t largest = std::max<uint64_t>(std::max<uint64_t>(3 * n64 * esz, (uint64_t)PF_TAB_MAX * n64 * 4), b.lm_chunk_bytes);
+                if (largest > PF_IPC_MAX_BYTES) {
+                    slam_set_error("rank %d exports a buffer of %.2f GiB: above the 2 GiB an IPC mapping can carry on this runtime "
+                                   "(use more ranks, or the halting flow)", r, (double)largest / 1073741824.0);
+                    return SLAM_E_CAPACITY;
+                }
+                if (b.inbox_bytes > PF_IPC_FINE_MAX_BYTES) {
+                    slam_set_error("rank %d's inbox is %.2f MiB: a fine-grained allocation above 2 MiB is not exported (it was seen "
+                                   "half mapped on this runtime); use the halting flow for a filter of this size", r,
+                                   (double)b.inbox_bytes / 1048576.0);
+                    return SLAM_E_CAPACITY;
+                }
+            }
+            continue;
+        }
+        void* ptr[PF_BLOB_MAXH];
+        if (r == rank || b.pid == me) {                     // this handle, or a shard of this very process: plain pointers
+            if (r != rank && b.device != h->device) {
                 const hipError_t e = hipDeviceEnablePeerAccess(b.device, 0);
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(e);
                 (void)hipGetLastError();
             }
-            for (int i = 0; i < 9; ++i) ptr[i] = b.raw[i];
+            for (int i = 0; i < cnt; ++i) ptr[i] = b.raw[i];
         } else {
-            // hipIpcOpenMemHandle of an allocation above 2 GiB never returns on this runtime (ROCm 7.2, dmabuf IPC; measured
-            // with tools/ipc_gen_test.py: 1.91 GiB opens in milliseconds, 2.50 GiB hangs both processes): refuse BEFORE
-            // opening anything, the caller falls back to the halting flow.  The largest buffer is the landmark array.
-            const double lm_bytes = (double)b.n * 5.0 * (double)b.nl * (double)h->esz;
-            if (lm_bytes > 2047.0 * 1048576.0) {
-                slam_set_error("rank %d's landmark buffer is %.2f GiB: above the 2 GiB an IPC mapping can carry on this runtime "
-                               "(use more ranks, or the halting flow)", r, lm_bytes / 1073741824.0);
-                pf_detach_peers_impl(h);
-                return SLAM_E_CAPACITY;
-            }
-            for (int i = 0; i < 9; ++i) {
+            for (int i = 0; i < cnt; ++i) {
                 const hipError_t e = hipIpcOpenMemHandle(&ptr[i], b.ipc[i], hipIpcMemLazyEnablePeerAccess);
                 if (e != hipSuccess) {
                     slam_set_error("hipIpcOpenMemHandle of rank %d's buffer %d failed: %s", r, i, hipGetErrorString(e));
@@ -3449,9 +3746,12 @@ extern "C" int slam_pf_attach_peers(slam_pf_t h, int rank, int world, const void
                 h->peer_open[r][i] = ptr[i];
             }
         }
-        t.pose[r][0] = ptr[0]; t.pose[r][1] = ptr[1]; t.lm[r][0] = ptr[2]; t.lm[r][1] = ptr[3];
-        t.logw[r][0] = ptr[4]; t.logw[r][1] = ptr[5]; t.tab[r][0] = (int32_t*)ptr[6]; t.tab[r][1] = (int32_t*)ptr[7];
-        t.inbox[r] = (PfInbox*)ptr[8];
+        t.pose[r][0] = ptr[0]; t.pose[r][1] = ptr[1]; t.logw[r][0] = ptr[2]; t.logw[r][1] = ptr[3];
+        t.tab[r][0] = (int32_t*)ptr[4]; t.tab[r][1] = (int32_t*)ptr[5];
+        t.inbox[r] = (PfInbox*)ptr[6];
+        t.lm[r].shift = b.lm_shift; t.lm[r].nchunks = b.lm_nchunks;
+        for (int bb = 0; bb < 2; ++bb)
+            for (int k = 0; k < b.lm_nchunks; ++k) t.lm[r].c[bb][k] = ptr[PF_BLOB_FIXED + bb * b.lm_nchunks + k];
     }
     h->peers = t;
     HIP_TRY(hipMalloc((void**)&h->d_peers, sizeof(PfPeers)));
