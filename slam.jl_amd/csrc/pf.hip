@@ -206,6 +206,7 @@ struct slam_pf {
     size_t inbox_bytes;
     void* peer_open[PF_MAX_WORLD][7 + 2 * PF_LM_MAXC];   // what hipIpcOpenMemHandle returned (closed at detach); null for in-process peers
     int64_t par_max_n;           // filters / shards of at most this many particles take the observation-parallel step kernel
+    int64_t way4_max_n, way2_max_n;   // ... up to these: 4 / 2 observation ways on 256-particle workgroups
     long long bar_count;         // peer barriers enqueued so far (the same on every rank: the calls are collective)
     long long halts;             // SLAM_PF_HALTED returns so far
     double last_out[4];          // {Neff, resampled?, resamplings, step} of the last confirmed step
@@ -2050,6 +2051,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void pf_auto_step_kern
 // particles and weights bit for bit.  One statistics line per workgroup of 64 particles; the collecting tail runs on
 // the first four waves of the last workgroup (the others have ended: a barrier counts live waves only).
 constexpr int PAR_WAVES = 8;
+constexpr int PF_WAY4_MAX_N = 98304;         // (pf_auto_step_way_kernel; thresholds from the one-box sweep tools/gpu_r4c.sh)
+constexpr int PF_WAY2_MAX_N = 196608;
 constexpr int PF_PAR_MAX_N = 49152;          // one-box sweep (tools/gpu_r3m.sh): 16384: 26.4 -> 15.2 us, 32768: 27.2 -> 17.1, 65536: 28.4 -> 29.2, 98304: 31.9 -> 43.5
 template <typename T, bool SH>
 __global__ __launch_bounds__(64 * PAR_WAVES) void pf_auto_step_par_kernel(PfAutoArgs a) {
@@ -2144,6 +2147,147 @@ __global__ __launch_bounds__(64 * PAR_WAVES) void pf_auto_step_par_kernel(PfAuto
     if (blockIdx.x == gridDim.x - 1) {
         if (threadIdx.x >= 256) return;                  // the tail is written for four waves
         pf_auto_tail<T>(a, s_l, s_st, s_first, pcur, tside, lwcur, 0);
+    }
+}
+
+
+// ---- the step with W-way observation parallelism on 256-particle workgroups (round 4; shards of 2 and 4 ranks) -------------
+// The 8-way kernel above wins up to ~49 k particles and loses beyond (four times the workgroups, the plan and the pose
+// hand-over per 64 particles); the sequential sweep needs ~262 k particles to hide its sixteen-update chain.  Between them --
+// the shards of BASELINE.json's filter on two and four GPUs, 131 072 and 65 536 particles -- a workgroup keeps the sweep's 256
+// particles and takes W = 2 or 4 WAYS: 256 W threads, wave w serves the particles 64 (w & 3) .. + 63 and the observations
+// (w >> 2), (w >> 2) + W, ... with the sweep's record ring (PF_DEPTH requests in flight per way).  Way 0 runs the motion model
+// and leaves the pose in LDS; every way leaves its log-weight terms in LDS and way 0 adds them IN OBSERVATION ORDER: particles
+// and weights are the sequential kernel's bit for bit.  The first four waves hold the 256 particles' weights, so the workgroup
+// stores the same 256-particle statistics line as the sequential sweep.  Needs: no landmark twice in the call (host-checked),
+// m <= WAY_MAXOBS<T>.
+template <typename T>
+constexpr int WAY_MAXOBS = sizeof(T) == 4 ? 32 : 16;     // the term array [m][256] stays within 32 KB of LDS
+template <typename T, bool SH, int W>
+__global__ __launch_bounds__(256 * W) void pf_auto_step_way_kernel(PfAutoArgs a) {
+    PfCtl* ctl = a.ctl;
+    typedef const __attribute__((address_space(4))) PfAutoArgs* KargPtr;
+    const KargPtr ka = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    int l_pre = 0;
+    int32_t st_pre = 0;
+    if ((int)threadIdx.x < a.m) {
+        l_pre = ka->ids[threadIdx.x] - 1;
+        st_pre = a.lmstate[l_pre];
+    }
+    const long long halted = ctl->halt_seq;
+    const int pcur = ctl->pcur, tside = ctl->tside, lwcur = ctl->lwcur;
+    const double shift_next = ctl->shift_next;
+    if (halted != 0 || ctl->error != 0) return;
+    if constexpr (SH) {
+        if (pf_peer_gone(a.inbox, a.world)) {              // (see pf_auto_step_kernel)
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                ctl->error = PF_ERR_PEER;
+                pf_publish(a.mir, 0.0, (long long)ctl->nresamples, ctl->resample_seq, PF_ERR_PEER, a.seq, a.seq);
+            }
+            return;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->stamps[0] = wall_clock64();
+    __shared__ T s_obs[2 * PF_AUTO_MAXOBS];
+    __shared__ int32_t s_ids[PF_AUTO_MAXOBS], s_meta[PF_AUTO_MAXOBS], s_l[PF_AUTO_MAXOBS], s_st[PF_AUTO_MAXOBS], s_first[PF_AUTO_MAXOBS];
+    __shared__ T s_pose[3][256];
+    __shared__ T s_term[WAY_MAXOBS<T>][256];
+    const int m = a.m;
+    for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) s_obs[i] = (T)ka->z[i];
+    const T pend = (T)shift_next;
+    T* pose = (T*)(pcur ? a.pose1 : a.pose0);
+    T* logw = (T*)(lwcur ? a.logw1 : a.logw0);
+    const int32_t* tabs = tside ? a.tab1 : a.tab0;
+    const int64_t n = a.n;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int way = wave >> 2;                               // 0 .. W-1 (wave-uniform)
+    const int pl = (wave & 3) * 64 + lane;                   // the particle's place in the workgroup
+    const int64_t pi = (int64_t)blockIdx.x * 256 + pl;
+    const bool valid = pi < n;
+    const int64_t p = valid ? pi : n - 1;
+    PfShardCtx sc{};
+    if constexpr (SH) sc = PfShardCtx{a.peers, (uint32_t)a.first, (uint32_t)a.n, a.rank, a.world};
+    T x = 0, y = 0, phi = 0, lw = 0;
+    if (way == 0) {                                          // F1: the motion model, once per particle
+        x = pose[p]; y = pose[n + p]; phi = pose[2 * n + p];
+        lw = logw[p];
+        T e1, e2;
+        normals2<T>((uint64_t)(a.first + p), a.step, STREAM_PREDICT, a.seed, e1, e2);
+        const T Vn = (T)a.V + (T)a.a0 * e1;                  // sim/sim-utils.jl:36
+        const T Gn = (T)a.G + (T)a.a1 * e2;                  // :37
+        T sgp, cgp, sg, cg;
+        m_sincos<T>(Gn + phi, sgp, cgp);
+        m_sincos<T>(Gn, sg, cg);
+        const T xn = x + Vn * (T)a.dt * cgp;                 // src/ekf.jl:39-41
+        const T yn = y + Vn * (T)a.dt * sgp;
+        const T pn = wrap_pi<T>(phi + Vn * (T)a.dt * sg / (T)a.wheelbase);
+        x = xn; y = yn; phi = pn;
+        if (valid) { pose[p] = x; pose[n + p] = y; pose[2 * n + p] = phi; }
+        s_pose[0][pl] = x; s_pose[1][pl] = y; s_pose[2][pl] = phi;
+    }
+    plan_obs(l_pre, st_pre, m, s_l, s_st, s_ids, s_meta, s_first);       // (two barriers: the pose is in LDS behind them)
+    if (way != 0) { x = s_pose[0][pl]; y = s_pose[1][pl]; phi = s_pose[2][pl]; }
+    const T R00 = (T)a.R00, R10 = (T)a.R10, R01 = (T)a.R01, R11 = (T)a.R11;
+    const LmView<T> lv{a.lmtab};
+    auto uni = [](int32_t v) { return __builtin_amdgcn_readfirstlane(v); };
+    // this way's observations i = way + W j, j = 0 .. cnt-1, with the sweep's ring: the records of the next PF_DEPTH of them in
+    // flight (no landmark occurs twice in the call, so every record may be requested ahead)
+    const int cnt = m > way ? (m - way + W - 1) / W : 0;
+    LmRow<T> ring[PF_DEPTH];
+    bool have[PF_DEPTH];
+#pragma unroll
+    for (int u = 0; u < PF_DEPTH; ++u) {
+        have[u] = false;
+        ring[u] = LmRow<T>{0, 0, 0, 0, 0};
+        const int i = way + W * u;
+        if (u < cnt && !(uni(s_ids[i]) & NEW_FLAG)) {
+            ring[u] = sweep_load<T, 2, SH>(lv, tabs, n, (uint32_t)p, uni(s_ids[i]), uni(s_meta[i]), sc);
+            have[u] = true;
+        }
+    }
+    for (int j0 = 0; j0 < cnt; j0 += PF_DEPTH) {
+#pragma unroll
+        for (int u = 0; u < PF_DEPTH; ++u) {
+            const int j = j0 + u;
+            if (j >= cnt) break;                             // uniform
+            const int i = way + W * j;
+            const int32_t code = uni(s_ids[i]), meta = uni(s_meta[i]);
+            const int l = code & ID_MASK;
+            const T r = s_obs[2 * i], b = s_obs[2 * i + 1];
+            const BufRow<T, decltype(lm_rsrc<T>((const T*)nullptr, n))> row{lm_rsrc<T>(lv.rows((meta & META_WBUF) ? 1 : 0, l, n), n),
+                                                              (uint32_t)p * (uint32_t)sizeof(T), (uint32_t)n * (uint32_t)sizeof(T)};
+            LmRow<T> cur = ring[u];
+            const bool have_cur = have[u];
+            have[u] = false;
+            const int jn = j + PF_DEPTH;
+            if (jn < cnt) {
+                const int in = way + W * jn;
+                if (!(uni(s_ids[in]) & NEW_FLAG)) {
+                    ring[u] = sweep_load<T, 2, SH>(lv, tabs, n, (uint32_t)p, uni(s_ids[in]), uni(s_meta[in]), sc);
+                    have[u] = true;
+                }
+            }
+            T term = 0;
+            if (code & NEW_FLAG) {                           // F3: first sighting
+                lm_init<T>(row, n, x, y, phi, r, b, R00, R10, R01, R11, valid);
+            } else {
+                if (!have_cur) cur = sweep_load<T, 2, SH>(lv, tabs, n, (uint32_t)p, code, meta, sc);
+                lm_update<T>(row, n, cur, x, y, phi, r, b, R00, R10, R01, R11, valid, term);      // term = 0 + (this observation's log-weight term)
+            }
+            s_term[i][pl] = term;
+        }
+    }
+    __syncthreads();
+    if (way == 0) {
+        lw -= pend;
+        for (int i = 0; i < m; ++i)
+            if (!(uni(s_ids[i]) & NEW_FLAG)) lw += s_term[i][pl];                                 // observation order
+        if (valid) logw[p] = lw;
+    }
+    wrec_block_line<T>(lw, valid, a.part, a.seq);            // (the first four waves = way 0 hold the 256 weights)
+    if (blockIdx.x == gridDim.x - 1) {
+        if (threadIdx.x >= 256) return;                      // the tail is written for four waves
+        pf_auto_tail<T>(a, s_l, s_st, s_first, pcur, tside, lwcur, 1);
     }
 }
 
@@ -2515,7 +2659,9 @@ extern "C" int slam_pf_create(slam_pf_t* out, int dtype, int64_t n_local, int64_
     h->pose[0] = h->pose[1] = h->logw = h->logw2[0] = h->logw2[1] = nullptr;
     memset(&h->lmtab, 0, sizeof(h->lmtab)); h->d_lmtab = nullptr; h->lm_chunk_bytes = 0;
     h->lwcur = 0; h->d_peers = nullptr; h->inbox = nullptr; h->bar_count = 0; h->halts = 0;
-    h->par_max_n = slam_exp_env("SLAMHIP_PF_PAR_MAX", PF_PAR_MAX_N);      // (the knob is read by the experiments build only)
+    h->par_max_n = slam_exp_env("SLAMHIP_PF_PAR_MAX", PF_PAR_MAX_N);      // (the knobs are read by the experiments build only)
+    h->way4_max_n = slam_exp_env("SLAMHIP_PF_WAY4_MAX", PF_WAY4_MAX_N);
+    h->way2_max_n = slam_exp_env("SLAMHIP_PF_WAY2_MAX", PF_WAY2_MAX_N);
     memset(&h->peers, 0, sizeof(h->peers));
     memset(h->peer_open, 0, sizeof(h->peer_open));
     h->h_ids = nullptr; h->h_obs = nullptr; h->ocap = 0;
@@ -3330,11 +3476,32 @@ static int pf_auto_enqueue(slam_pf* h, const PfStepRec& r) {
     const dim3 grid(grid_for(h->n));
     // small filter / shard: the observations in parallel (pf_auto_step_par_kernel) -- FastSLAM-1.0 step, no landmark twice
     // in the call; above PF_PAR_MAX_N particles the sequential sweep already fills the chip
-    bool par = !r.proposal && r.m >= 2 && h->n <= h->par_max_n;
-    for (int i = 1; i < r.m && par; ++i)
+    bool distinct = !r.proposal && r.m >= 2;
+    for (int i = 1; i < r.m && distinct; ++i)
         for (int j = 0; j < i; ++j)
-            if (r.ids[i] == r.ids[j]) { par = false; break; }
-    if (par) {
+            if (r.ids[i] == r.ids[j]) { distinct = false; break; }
+    const bool par = distinct && h->n <= h->par_max_n;
+    // between the 8-way kernel's range and the size at which the sequential sweep fills the chip: 4 and 2 ways on
+    // 256-particle workgroups (pf_auto_step_way_kernel).  fp64 keeps to 2 ways (170 registers: no 1024-thread workgroup).
+    int ways = 0;
+    if (distinct && !par) {
+        const int mo = h->dtype == SLAM_F32 ? WAY_MAXOBS<float> : WAY_MAXOBS<double>;
+        if (r.m <= mo && r.m >= 4) {
+            if (h->n <= h->way4_max_n) ways = h->dtype == SLAM_F32 ? 4 : 2;
+            else if (h->n <= h->way2_max_n) ways = 2;
+        }
+    }
+    if (ways) {
+        const dim3 wgrid((unsigned)((h->n + 255) / 256));
+#define PF_WAY_LAUNCH(TT, WW)                                                                                                \
+    do {                                                                                                                     \
+        if (sh) hipLaunchKernelGGL((pf_auto_step_way_kernel<TT, true, WW>), wgrid, dim3(256 * WW), 0, h->stream, a);         \
+        else hipLaunchKernelGGL((pf_auto_step_way_kernel<TT, false, WW>), wgrid, dim3(256 * WW), 0, h->stream, a);           \
+    } while (0)
+        if (h->dtype == SLAM_F32) { if (ways == 4) PF_WAY_LAUNCH(float, 4); else PF_WAY_LAUNCH(float, 2); }
+        else PF_WAY_LAUNCH(double, 2);
+#undef PF_WAY_LAUNCH
+    } else if (par) {
         const dim3 pgrid((unsigned)((h->n + 63) / 64));
         if (h->dtype == SLAM_F32) {
             if (sh) hipLaunchKernelGGL((pf_auto_step_par_kernel<float, true>), pgrid, dim3(64 * PAR_WAVES), 0, h->stream, a);

@@ -700,6 +700,46 @@ def test_auto_mode_observation_parallel_kernel(pkg, dtype, m):
         g.shard.close()
 
 
+@pytest.mark.parametrize("dtype,n,m", [("f32", 65536 + 77, 16), ("f32", 131072, 16), ("f32", 70000, 5), ("f32", 60000, 31),
+                                       ("f64", 65536, 16), ("f64", 150001, 7)])
+def test_auto_mode_observation_ways_on_256_particle_workgroups(pkg, dtype, n, m):
+    """Round 4: between the 8-way observation-parallel kernel (up to 49152 particles) and the size at which the sequential sweep
+    fills the chip, a step takes pf_auto_step_way_kernel -- a workgroup keeps the sweep's 256 particles and splits the call's
+    observations over 4 ways (up to 98304 particles, fp32) or 2 ways (up to 196608; fp64 always 2), each way with the sweep's
+    record ring; the log-weight terms are added in observation order.  Against the synchronous driver (FastSLAM.step, which
+    only has the sequential kernel): the same particles bit for bit, log-weights within 4 ulp, the same resampling steps -- ragged particle counts,
+    first sightings, m below / at / above the ring depth, a step with a repeated landmark (sequential kernel) in between."""
+    nl, seed = 40, 58
+    lm = scene(nl, 29)
+    f = {}
+    for name in ("auto", "sync"):
+        sh = pkg.PFShard(n, nl, seed, dtype=dtype)
+        sh.set_pose([0.5, 1.5, -0.2])
+        sh.init_landmarks(lm[:30], 0.01, 0.1)                 # 31..40 are first seen later
+        f[name] = pkg.FastSLAM(sh, None, neff_frac=0.75)
+    rng = np.random.default_rng(160 + m)
+    pose = np.array([0.5, 1.5, -0.2])
+    hist = []
+    for t in range(14):
+        pose = np.array([pose[0] + 0.6 * math.cos(pose[2]), pose[1] + 0.6 * math.sin(pose[2]), pose[2]])
+        ids = rng.choice(np.arange(1, nl + 1), size=m, replace=False)
+        if t == 7:
+            ids[-1] = ids[0]                                  # a repeat: this step takes the sequential kernel
+        z = observe(lm, pose, ids, rng)
+        force = True if t % 6 == 2 else (False if t % 6 == 4 else None)
+        f["auto"].step_async(6.0, 0.01 * (t % 5), 4.0, Q, 0.1, z, ids, R, force_resample=force)
+        hist.append(f["sync"].step(6.0, 0.01 * (t % 5), 4.0, Q, 0.1, z, ids, R, force_resample=force))
+        if t in (3, 8, 13):
+            neff, did = f["auto"].flush()
+            assert did == hist[-1][1], f"step {t}"
+            assert neff == pytest.approx(hist[-1][0], rel=1e-12 if dtype == "f64" else 1e-6)
+            assert f["auto"].resamples == f["sync"].resamples
+            _compare(f["auto"].shard, f["sync"].shard, f"n {n} m {m} step {t}", exact_logw=False)
+    assert f["sync"].resamples >= 2
+    for g in f.values():
+        g.shard.close()
+
+
 @pytest.mark.parametrize("n", [200, 1024 * 256 + 700])
 def test_auto_mode_grid_sizes_of_the_statistics_hand_over(pkg, n):
     """The step kernel's last workgroup collects one tagged statistics line per workgroup, 1024 lines per pass: a grid of ONE
@@ -893,14 +933,15 @@ def test_sharded_filter_resamples_on_the_device(pkg, dtype, world, proposal):
         sh.close()
 
 
-@pytest.mark.parametrize("dtype,world,per", [("f32", 4, 16384), ("f64", 2, 2048), ("f32", 2, 3 * 1024)])
+@pytest.mark.parametrize("dtype,world,per", [("f32", 4, 16384), ("f64", 2, 2048), ("f32", 2, 3 * 1024), ("f32", 2, 65536), ("f32", 3, 66 * 1024)])
 def test_sharded_normalisation_is_invariant_in_the_number_of_ranks(pkg, dtype, world, per):
     """identical results for any number of ranks -- INCLUDING the normalisation (round 4).  The weight statistics
     are the root of ONE fixed radix-4 tree over the global particle index (csrc/pf.hip: WRec): every rank writes its
     1024-particle records into every rank's inbox and all ranks reduce the same sequence, so a sharded filter whose slices
     are multiples of 1024 particles has the ONE-RANK auto filter's log-weights BIT FOR BIT, not within ulps -- also where
-    the two use different step kernels (65536 particles: the one-rank filter takes the sequential sweep and its 256-particle
-    lines, the four 16384-particle shards the observation-parallel kernel and 64-particle leaves)."""
+    the two use different step kernels (65536 particles: the one-rank filter takes the 4-way kernel and its 256-particle lines, the
+    four 16384-particle shards the 8-way kernel and 64-particle leaves; 131072: 2 ways against 4; 202752: the sequential sweep
+    against three 2-way shards)."""
     import threading
     nl, seed = 14, 91
     n = per * world
