@@ -518,6 +518,12 @@ typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void request_chunk_p(const DdCtx& c, int2 t, int chunk, u32x4b (&g)[3]) {
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(c.img), (short)0, 0x7fffffff, 0x00020000);
     const int tid = threadIdx.x;
+#ifdef SLAMHIP_EXPERIMENTS
+    // experiment (SLAMHIP_DEBUG bit 65536, round 4): EVERY tile reads the image of tile (0, 0) -- 192 KB that never leave the
+    // L2s: what the panels' fabric traffic (every XCD fetches every column band's image once: 0.12 GB of the 0.2 GB the launch
+    // moves beyond P itself) costs in time.  Wrong numbers.
+    if (c.xflags & 256) t = make_int2(0, 0);
+#endif
     const int sx = (t.x * c.img_nch + chunk) * IMG_CHUNK, sy = (t.y * c.img_nch + chunk) * IMG_CHUNK;
     // pieces tid, tid + 512, tid + 1024 of the 1536 sixteen-byte pieces [X image | Y image]
     g[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, sx, 0);
@@ -1133,7 +1139,7 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
             if (wgs > L) wgs = L;
             hipLaunchKernelGGL((downdate_f32_mfma<true, 4, 3, true>), dim3(8 * wgs), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,
                                (const float*)X, (const float*)Y, pitch, kp_total, lst, L,
-                               h->d_status, h->debug_flags & 0xdf, (unsigned long long*)nullptr, dcount, joseph, IMGARGS);
+                               h->d_status, h->debug_flags & ~32, (unsigned long long*)nullptr, dcount, joseph, IMGARGS);
         }
         else if (h->debug_flags)      // timing experiments only (SLAMHIP_DEBUG): parts of the kernel switched off
             hipLaunchKernelGGL(downdate_f32_mfma<true>, dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,

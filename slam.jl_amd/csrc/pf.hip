@@ -2051,8 +2051,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : 2) void pf_auto_step_kern
 // particles and weights bit for bit.  One statistics line per workgroup of 64 particles; the collecting tail runs on
 // the first four waves of the last workgroup (the others have ended: a barrier counts live waves only).
 constexpr int PAR_WAVES = 8;
-constexpr int PF_WAY4_MAX_N = 98304;         // (pf_auto_step_way_kernel; thresholds from the one-box sweep tools/gpu_r4c.sh)
-constexpr int PF_WAY2_MAX_N = 196608;
+constexpr int PF_WAY4_MAX_N = 81920;         // one-box sweep (tools/gpu_r4c.sh, no resampling): 65536: seq 29.7, 2 ways 22.4, 4 ways 20.4 us; 98304: 32.4 / 27.1 / 31.3;
+constexpr int PF_WAY2_MAX_N = 196608;        // 131072: 34.0 / 29.0 / 35.9; 196608: 38.4 / 36.1 / 47.9 (262144: the sequential sweep, 43.9)
 constexpr int PF_PAR_MAX_N = 49152;          // one-box sweep (tools/gpu_r3m.sh): 16384: 26.4 -> 15.2 us, 32768: 27.2 -> 17.1, 65536: 28.4 -> 29.2, 98304: 31.9 -> 43.5
 template <typename T, bool SH>
 __global__ __launch_bounds__(64 * PAR_WAVES) void pf_auto_step_par_kernel(PfAutoArgs a) {
