@@ -304,7 +304,7 @@ int slam_pf_ancestors_all(slam_pf_t h, const void* d_logw_all, double gmax, doub
 /* Resampling of a filter that lives WHOLLY on this shard (n_local == n_global) as one call: cdf of the weights,
  * systematic-resampling ancestors (offset u0, gmax = the maximum log-weight), then the LAZY step: poses are permuted
  * and small ancestor tables composed, the particles' maps stay where they are and move landmark by landmark when
- * next updated (csrc/pf.hip, "lazy resampling"; SLAMHIP_PF_EAGER=1 or an exhausted table pool: the eager gather of
+ * next updated (csrc/pf_legacy.hip, "lazy resampling"; SLAMHIP_PF_EAGER=1 or an exhausted table pool: the eager gather of
  * whole records).  Same particles, bit for bit, as slam_pf_copy_logw + slam_pf_ancestors + slam_pf_resample_apply.
  * Enqueued. */
 int slam_pf_resample_local(slam_pf_t h, double gmax, double u0);

@@ -506,7 +506,7 @@ def test_proposal_driver_against_oracle_and_neff_gain(pkg):
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_lazy_resampling_equals_the_eager_gather(pkg, monkeypatch, dtype):
     """A filter that lives on one shard resamples lazily: poses are permuted, the maps stay where they are behind
-    composed ancestor tables and move landmark by landmark when next updated (csrc/pf.hip, "lazy resampling").
+    composed ancestor tables and move landmark by landmark when next updated (csrc/pf_legacy.hip, "lazy resampling").
     SLAMHIP_PF_EAGER=1 keeps the eager gather of whole particle records.  Both must give the SAME bits, whatever
     comes in between: landmarks untouched across many resamplings, repeats and first sightings in a call, the
     FastSLAM-2.0 step, the unknown-correspondence sweep and a record pack (which materialise the maps), and more live
@@ -936,7 +936,7 @@ def test_sharded_filter_resamples_on_the_device(pkg, dtype, world, proposal):
 @pytest.mark.parametrize("dtype,world,per", [("f32", 4, 16384), ("f64", 2, 2048), ("f32", 2, 3 * 1024), ("f32", 2, 65536), ("f32", 3, 66 * 1024)])
 def test_sharded_normalisation_is_invariant_in_the_number_of_ranks(pkg, dtype, world, per):
     """identical results for any number of ranks -- INCLUDING the normalisation (round 4).  The weight statistics
-    are the root of ONE fixed radix-4 tree over the global particle index (csrc/pf.hip: WRec): every rank writes its
+    are the root of ONE fixed radix-4 tree over the global particle index (csrc/pf_device.h: WRec): every rank writes its
     1024-particle records into every rank's inbox and all ranks reduce the same sequence, so a sharded filter whose slices
     are multiples of 1024 particles has the ONE-RANK auto filter's log-weights BIT FOR BIT, not within ulps -- also where
     the two use different step kernels (65536 particles: the one-rank filter takes the 4-way kernel and its 256-particle lines, the
@@ -1081,7 +1081,7 @@ def test_auto_mode_two_ranks_without_peers_halts_and_resumes(pkg, tmp_path):
 
 
 def test_sharded_filter_generations_and_the_weak_scaling_shape_attach_their_peers(pkg):
-    """The IPC mappings of the sharded filter (csrc/pf.hip: PF_IPC_MAX_BYTES), two processes on one card (tools/ipc_gen_test.py):
+    """The IPC mappings of the sharded filter (csrc/pf_peers.hip: PF_IPC_MAX_BYTES), two processes on one card (tools/ipc_gen_test.py):
     `gen`  attach -> steps with resamplings -> detach -> close, three GENERATIONS of filters of changing buffer sizes in the
            same pair of processes (every generation re-exports and re-imports every buffer);
     `big`  BASELINE config 4 PER GPU, the weak-scaling shape: 262144 particles x 512 landmarks per rank = 2.5 GiB per landmark
