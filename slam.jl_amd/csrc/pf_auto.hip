@@ -751,7 +751,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void pf_auto_scan1_kernel(const T* __re
                                                                     double* __restrict__ bsum, const PfPeers* __restrict__ peers,
                                                                     int rank, int world) {
     if (ctl->resample_seq != seq || ctl->error != 0) return;
-    __shared__ double sh[SCAN_BLOCK];
+    __shared__ double sh16[16];
     const int64_t i = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
     const T pend = (T)ctl->shift_scan;
     const double gmax = ctl->gmax_norm;
@@ -762,16 +762,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void pf_auto_scan1_kernel(const T* __re
         if (world > 1 && owner != (uint32_t)rank) v = ld_sys((const T*)peers->logw[owner][old] + (i - (int64_t)owner * n_local));
         else v = (old ? logw1 : logw0)[i - (int64_t)owner * n_local];
     }
-    sh[threadIdx.x] = i < n_global ? exp((double)(T)(v - pend) - gmax) : 0.0;
-    __syncthreads();
-    for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
-        const double u = threadIdx.x >= off ? sh[threadIdx.x - off] : 0.0;
-        __syncthreads();
-        sh[threadIdx.x] += u;
-        __syncthreads();
-    }
-    if (i < n_global) cdf[i] = sh[threadIdx.x];
-    if (threadIdx.x == SCAN_BLOCK - 1) bsum[blockIdx.x] = sh[threadIdx.x];
+    const double c = block_scan1024(i < n_global ? exp((double)(T)(v - pend) - gmax) : 0.0, sh16);
+    if (i < n_global) cdf[i] = c;
+    if (threadIdx.x == SCAN_BLOCK - 1) bsum[blockIdx.x] = c;
 }
 
 // Block offsets (pf_scan2_kernel's serial order, redone by every workgroup out of LDS), ancestors (pf_ancestor_kernel)

@@ -266,19 +266,12 @@ __global__ __launch_bounds__(256) void pf_shift_kernel(T* __restrict__ logw, int
 template <typename T>
 __global__ __launch_bounds__(SCAN_BLOCK) void pf_scan1_kernel(const T* __restrict__ logw_all, int64_t n, double gmax,
                                                                double* __restrict__ cdf, double* __restrict__ bsum, T pend) {
-    __shared__ double sh[SCAN_BLOCK];
+    __shared__ double sh16[16];
     const int64_t i = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
     // `pend`: a normalisation shift not yet applied to the stored values (rounded as pf_shift_kernel would store it)
-    sh[threadIdx.x] = i < n ? exp((double)(T)(logw_all[i] - pend) - gmax) : 0.0;
-    __syncthreads();
-    for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
-        const double v = threadIdx.x >= off ? sh[threadIdx.x - off] : 0.0;
-        __syncthreads();
-        sh[threadIdx.x] += v;
-        __syncthreads();
-    }
-    if (i < n) cdf[i] = sh[threadIdx.x];
-    if (threadIdx.x == SCAN_BLOCK - 1) bsum[blockIdx.x] = sh[threadIdx.x];
+    const double c = block_scan1024(i < n ? exp((double)(T)(logw_all[i] - pend) - gmax) : 0.0, sh16);
+    if (i < n) cdf[i] = c;
+    if (threadIdx.x == SCAN_BLOCK - 1) bsum[blockIdx.x] = c;
 }
 
 // exclusive scan of the block totals, in place.  The additions run in index order on ONE thread (the oracle's
