@@ -214,14 +214,16 @@ int slam_ekf_sync(slam_ekf_t h);
  * totals and returns total milliseconds and launch count for kernel id `kid`. */
 int slam_ekf_timing(slam_ekf_t h, int enable);
 int slam_ekf_timing_read(slam_ekf_t h, int kid, double* total_ms, int64_t* launches);
+/* The fastest bracketed launch of kernel `kid` since the last reset, in milliseconds (0: none).  Synchronises. */
+int slam_ekf_timing_min(slam_ekf_t h, int kid, double* min_ms);
 int slam_ekf_timing_reset(slam_ekf_t h);
 /* Diagnostics: when enabled the factorisation kernel records 100 MHz wall-clock stamps at its
  * phase boundaries; out8 (may be NULL) receives the stamps of the last update. */
 int slam_ekf_debug_stamps(slam_ekf_t h, int enable, uint64_t* out8);
 /* Measurement hook (bench.py: roofline.copy_floor_ms): the bare memory side of the covariance down-date (src/ekf.jl:75) on
  * THIS handle's matrix -- every stored tile the down-date touches read once and written back unchanged (bit-exact), in
- * the down-date's own band-major order, no panels, no matrix-core work; `reps` timed passes of each of two launch forms.
- * out = {milliseconds per pass of the faster form, its index (0: one workgroup per tile, 1: persistent grid)}.  The
+ * the down-date's own band-major order, no panels, no matrix-core work; `reps` individually timed passes of each of two launch
+ * forms.  out = {milliseconds of the FASTEST pass, its form's index (0: one workgroup per tile, 1: persistent grid)}.  The
  * down-date's launch time over this figure compares across the boxes of a pool whose memory systems differ by a few
  * per cent.  Synchronises; the state is unchanged. */
 int slam_ekf_copy_floor(slam_ekf_t h, int reps, double out[2]);

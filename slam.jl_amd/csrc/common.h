@@ -170,6 +170,7 @@ struct slam_ekf {
     std::vector<TimingPair> pairs;
     std::vector<TimingPair> free_pairs;
     double t_ms[SLAM_K_COUNT];
+    double t_min[SLAM_K_COUNT];   // fastest bracketed launch since the last reset (0: none)
     int64_t t_n[SLAM_K_COUNT];
 };
 

@@ -98,6 +98,7 @@ static int fold_timing(slam_ekf* h) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             h->t_ms[p.kid] += ms;
+            if (h->t_min[p.kid] == 0.0 || ms < h->t_min[p.kid]) h->t_min[p.kid] = ms;
             h->t_n[p.kid] += 1;
         }
         h->free_pairs.push_back(p);
@@ -314,7 +315,7 @@ extern "C" int slam_ekf_create(slam_ekf_t* out, int dtype, int max_landmarks, in
     h->factor_blocked = !(getenv("SLAMHIP_FACTOR") && !strcmp(getenv("SLAMHIP_FACTOR"), "scalar"));
 #endif
     h->timing = 0;
-    for (int i = 0; i < SLAM_K_COUNT; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
+    for (int i = 0; i < SLAM_K_COUNT; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; h->t_min[i] = 0; }
     const int rc = create_impl(h);
     if (rc != SLAM_OK) {
         slam_ekf_destroy(h);
@@ -845,11 +846,21 @@ extern "C" int slam_ekf_timing_read(slam_ekf_t h, int kid, double* total_ms, int
     return SLAM_OK;
 }
 
+extern "C" int slam_ekf_timing_min(slam_ekf_t h, int kid, double* min_ms) {
+    ARG_CHECK(h != nullptr && min_ms != nullptr, "null argument");
+    ARG_CHECK(kid >= 0 && kid < SLAM_K_COUNT, "kernel id out of range");
+    HIP_TRY(hipSetDevice(h->device));
+    const int rc = fold_timing(h);
+    if (rc) return rc;
+    *min_ms = h->t_min[kid];
+    return SLAM_OK;
+}
+
 extern "C" int slam_ekf_timing_reset(slam_ekf_t h) {
     ARG_CHECK(h != nullptr, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     const int rc = fold_timing(h);
     if (rc) return rc;
-    for (int i = 0; i < SLAM_K_COUNT; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; }
+    for (int i = 0; i < SLAM_K_COUNT; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; h->t_min[i] = 0; }
     return SLAM_OK;
 }

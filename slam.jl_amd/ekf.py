@@ -414,6 +414,12 @@ class EKFSlamState(SlamState):
             out[name] = (ms.value, cnt.value)
         return out
 
+    def timing_min(self, kernel):
+        """Milliseconds of the fastest bracketed launch of `kernel` since the last reset (0.0: none)."""
+        ms = C.c_double()
+        check(lib.slam_ekf_timing_min(self._h, _lib.KERNEL_IDS[kernel], C.byref(ms)))
+        return ms.value
+
 
 # ---- the reference's function surface ---------------------------------------------------
 
