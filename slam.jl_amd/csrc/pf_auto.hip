@@ -148,6 +148,15 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
     // partials -- is issued up front: the memory system is still draining the sweep's stores and a load takes microseconds
     // to come back, so the tail pays that latency once, not once per phase.
     const int my_tref = tid < PF_TAB_MAX ? ctl->tref[tid] : 0;
+    // (round 4) this thread's share of the per-landmark state words, for the resampling's "landmarks without a table take the
+    // fresh one" pass: requested NOW, with the rest -- loaded where they are used they were a dependent global round trip at
+    // the very end of every resampling step.  Maps of up to 1024 landmarks; larger ones take the loop below.
+    constexpr int LS_PRE = 4;
+    const bool ls_pre = a.nl <= 256 * LS_PRE;
+    int32_t my_ls[LS_PRE];
+#pragma unroll
+    for (int j = 0; j < LS_PRE; ++j) my_ls[j] = (ls_pre && tid + 256 * j < a.nl) ? a.lmstate[tid + 256 * j] : 0;
+    __shared__ unsigned s_obsbit[256 * LS_PRE / 32];         // the landmarks this step observes (their words change below)
     const int identity0 = ctl->identity;                      // landmarks without a table before this step
     const int nres0 = ctl->nresamples;                        // (requested here, with the rest: used by the bookkeeping only)
     const long long res0 = ctl->resample_seq;
@@ -159,6 +168,7 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
     if (tid == 0) s_perr = 0;
     if (tid < PF_TAB_MAX) s_tref[tid] = my_tref;
     if (tid == 0) s_i[0] = identity0;
+    if (tid < 256 * LS_PRE / 32) s_obsbit[tid] = 0u;
     __syncthreads();
     // Four consecutive records {m, s1, s2, tag} starting at `first` (64 bytes apart in `src`), polled until their tags fit
     // (see part_key: a line that is stale, half written or torn does not fit; nothing else orders the stores).  Records from
@@ -247,6 +257,7 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
             atomicAdd(&s_i[0], 1);                            // released its table: a landmark without one ("identity")
         }
         a.lmstate[s_l[tid]] = LS_SEEN | ((tab ? (rb ^ 1) : rb) ? LS_BUF : 0);
+        if (ls_pre) atomicOr(&s_obsbit[s_l[tid] >> 5], 1u << (s_l[tid] & 31));
     }
     if (xpeers) {
         // ---- every rank's records, as they arrive in THIS rank's inbox (local memory, written by the peers over xGMI): the
@@ -330,27 +341,50 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
     }
     __syncthreads();
     if (tid == 0) ctl->stamps[3] = wall_clock64();
-    if (tid == 0 && s_i[1] == 1) {
-        // lazy resampling: landmarks without a table share a fresh one (= the ancestor vector); live tables are composed
-        int count = 0, free_idx = -1;
-        for (int t = 0; t < PF_TAB_MAX; ++t) {
-            if (s_tref[t] > 0) ctl->tl_idx[count++] = t;
-            else if (free_idx < 0) free_idx = t;
-        }
-        if (s_i[0] > 0 && free_idx < 0) s_i[1] = 2;                         // no table left: the host resamples eagerly
-        else {
-            ctl->tl_count = count;
-            ctl->tl_fresh = s_i[0] > 0 ? free_idx : -1;
-            s_i[2] = s_i[0] > 0 ? free_idx : -1;
-            if (s_i[0] > 0) s_tref[free_idx] = s_i[0];
+    static_assert(PF_TAB_MAX == 64, "the table list is formed by one wave, a lane per table");
+    if (tid < 64 && s_i[1] == 1) {
+        // lazy resampling: landmarks without a table share a fresh one (= the ancestor vector); live tables are composed.
+        // One lane per table (round 4: thread 0 used to walk the 64 tables, an LDS read and a global store each: 3 us of every
+        // resampling step): the list position of a live table = the live tables before it, the fresh one = the first free.
+        const int identity = s_i[0];
+        const bool live = s_tref[tid] > 0;
+        const unsigned long long mask = __ballot(live);
+        const int free_idx = ~mask ? __ffsll((unsigned long long)~mask) - 1 : -1;
+        const bool halt = identity > 0 && free_idx < 0;                      // no table left: the host resamples eagerly
+        if (live && !halt) ctl->tl_idx[__popcll(mask & ((1ull << tid) - 1ull))] = tid;
+        if (tid == 0) {
+            if (halt) s_i[1] = 2;
+            else {
+                ctl->tl_count = __popcll(mask);
+                ctl->tl_fresh = identity > 0 ? free_idx : -1;
+                s_i[2] = identity > 0 ? free_idx : -1;
+                if (identity > 0) s_tref[free_idx] = identity;
+            }
         }
     }
     __syncthreads();
-    if (s_i[1] == 1 && s_i[2] >= 0)
-        for (int l = tid; l < a.nl; l += 256) {
-            const int32_t st = a.lmstate[l];
-            if ((st & LS_TAB) == 0) a.lmstate[l] = st | (s_i[2] + 1);
+    if (s_i[1] == 1 && s_i[2] >= 0) {
+        const int32_t fresh = s_i[2] + 1;
+        if (ls_pre) {
+            // the words requested at the tail's start; a landmark observed in THIS step has a new word (no table: it takes the
+            // fresh one), written by its observation's thread above -- that thread adds the table to it
+#pragma unroll
+            for (int j = 0; j < LS_PRE; ++j) {
+                const int l = tid + 256 * j;
+                if (l < a.nl && !((s_obsbit[l >> 5] >> (l & 31)) & 1u) && (my_ls[j] & LS_TAB) == 0) a.lmstate[l] = my_ls[j] | fresh;
+            }
+            if (tid < a.m && s_first[tid]) {
+                const int32_t st = s_st[tid];
+                const int tab = st & LS_TAB, rb = (st & LS_BUF) ? 1 : 0;
+                a.lmstate[s_l[tid]] = (LS_SEEN | ((tab ? (rb ^ 1) : rb) ? LS_BUF : 0)) | fresh;
+            }
+        } else {
+            for (int l = tid; l < a.nl; l += 256) {
+                const int32_t st = a.lmstate[l];
+                if ((st & LS_TAB) == 0) a.lmstate[l] = st | fresh;
+            }
         }
+    }
     for (int t = tid; t < PF_TAB_MAX; t += 256) ctl->tref[t] = s_tref[t];
     if (tid == 0) {
         ctl->stamps[4] = wall_clock64();
