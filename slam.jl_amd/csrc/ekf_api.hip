@@ -313,6 +313,7 @@ extern "C" int slam_ekf_create(slam_ekf_t* out, int dtype, int max_landmarks, in
     h->factor_blocked = 1;
 #ifdef SLAMHIP_EXPERIMENTS
     h->factor_blocked = !(getenv("SLAMHIP_FACTOR") && !strcmp(getenv("SLAMHIP_FACTOR"), "scalar"));
+    if (getenv("SLAMHIP_FACTOR") && !strcmp(getenv("SLAMHIP_FACTOR"), "pivot1")) h->factor_blocked = 2;     // round 3's one pivot per MFMA
 #endif
     h->timing = 0;
     for (int i = 0; i < SLAM_K_COUNT; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; h->t_min[i] = 0; }

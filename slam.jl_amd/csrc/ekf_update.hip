@@ -323,6 +323,65 @@ __device__ __forceinline__ double bpermute_f64(double v, int srclane) {
 // Row j reaches every lane with one bpermute; the multipliers use a_ji for a_ij (the active part is symmetric);
 // column j gets -mu_i exactly (its C entries are zeroed and its row entry is 1).  Leaves the CLEAN unit-lower
 // inv(L_JJ) in M (ones on the diagonal, zeros above), D in dvec, 1/D in dinv.  False on a non-positive pivot.
+//
+// Round 4: FOUR pivots per matrix-core instruction.  The sixteen sequential steps above each wait for a cross-lane row
+// broadcast, a reciprocal and a dependent MFMA (~460 cycles measured per pivot; the chain is what the factorisation costs).
+// The four rows of a pivot GROUP s (rows 4s .. 4s+3) are register s of the four quarter-waves, so
+//   * inside the group the four pivots are eliminated with VALU work only (row t reaches the other quarter-waves with one
+//     bpermute, the group's multipliers a_{j, 4s+q} with a second one issued beside it; no MFMA, no hazard wait);
+//   * the rows BELOW the group then take all four pivots in ONE v_mfma_f64_16x16x4_f64 -- and need no data movement at all:
+//     with R_kk the finished group row kk, the B operand B[kk][c] = R_kk[c] is register s of lane c + 16 kk AS IT STANDS
+//     (diagonal replaced by 1; the group's own columns right of the diagonal by 0: those entries of the rows below are
+//     overwritten by later pivots of the group), and the A operand A[i][kk] = -R_kk[i] / d_kk (the multiplier of row i at
+//     pivot kk, by the symmetry of the active part) is the same register of the same lane, scaled.
+// Same contract as the one-pivot form; worked out and checked against it in NumPy first (the emulation is in the round's log).
+__device__ __forceinline__ bool factor_diag_block4(double* M, int mp, int J, double* dvec, double* dinv) {
+    const int lane = threadIdx.x & 63;
+    const int c = lane & 15, q = lane >> 4;
+    double* blk = M + (16 * J) * mp + 16 * J;
+    f64x4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = blk[(4 * r + q) * mp + c];
+    bool bad = false;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int j0 = 4 * s;
+        double rp[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = j0 + t;
+            const double piv = readlane_f64(acc[s], j + 16 * t);
+            bad = bad || !(piv > 0.0) || piv == __builtin_inf();
+            rp[t] = pivot_rcp(piv);
+            if (t < 3) {
+                const double rowv = bpermute_f64(acc[s], c + 16 * t);             // a_{j, c} on every lane
+                const double muv = bpermute_f64(acc[s], (j0 + q) + 16 * t);       // a_{j, 4s+q}: row q of the group at the pivot's column
+                const double mu = muv * rp[t];
+                if (q > t) acc[s] = (c == j) ? -mu : acc[s] - mu * rowv;
+            }
+        }
+        if (s < 3) {
+            const double rpq = q == 0 ? rp[0] : (q == 1 ? rp[1] : (q == 2 ? rp[2] : rp[3]));
+            const double aval = (c > j0 + 3) ? -(acc[s] * rpq) : 0.0;              // A[i = c][kk = q]: rows below the group only
+            const double bval = (c == j0 + q) ? 1.0 : ((c > j0 + q && c <= j0 + 3) ? 0.0 : acc[s]);      // B[kk = q][c]
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r > s) acc[r] = (c >= j0 && c <= j0 + 3) ? 0.0 : acc[r];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aval, bval, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * r + q;
+        blk[row * mp + c] = (c < row) ? acc[r] : (c == row ? 1.0 : 0.0);
+        if (c == row) {
+            dvec[16 * J + row] = acc[r];
+            dinv[16 * J + row] = pivot_rcp(acc[r]);
+        }
+    }
+    return !bad;
+}
+
 __device__ __forceinline__ bool factor_diag_block(double* M, int mp, int J, double* dvec, double* dinv) {
     const int lane = threadIdx.x & 63;
     const int c = lane & 15, q = lane >> 4;
@@ -357,7 +416,8 @@ __device__ __forceinline__ bool factor_diag_block(double* M, int mp, int J, doub
     return !bad;
 }
 
-__device__ __forceinline__ bool eliminate_blocked(double* M, int mp, int k, int kp, double* dvec, double* dinv, double* flag) {
+__device__ __forceinline__ bool eliminate_blocked(double* M, int mp, int k, int kp, double* dvec, double* dinv, double* flag,
+                                                  bool four = true) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
     const int li = lane & 15, kk = lane >> 4;
@@ -432,7 +492,8 @@ __device__ __forceinline__ bool eliminate_blocked(double* M, int mp, int k, int 
         const int tp = nbk - J;                       // trailing block rows of step J-1
         if (wave == 0) {
             if (J > 0) trailing(J - 1, 0, 1, 1);
-            if (!factor_diag_block(M, mp, J, dvec, dinv) && lane == 0) flag[0] = 1.0;
+            const bool okb = four ? factor_diag_block4(M, mp, J, dvec, dinv) : factor_diag_block(M, mp, J, dvec, dinv);
+            if (!okb && lane == 0) flag[0] = 1.0;
         } else {
             if (J > 0) trailing(J - 1, wave, nwaves - 1, tp * (tp + 1) / 2);
             if (C < J) {
@@ -634,7 +695,7 @@ __device__ __forceinline__ void factor_body(
     STAMP(3);
     bool ok;
     if constexpr (!INLDS) ok = eliminate_in_memory(M, mp, k, mvec);
-    else if (blocked) ok = eliminate_blocked(M, mp, k, kp, rowbuf, rowbuf + kp, colbuf);
+    else if (blocked) ok = eliminate_blocked(M, mp, k, kp, rowbuf, rowbuf + kp, colbuf, blocked != 2);      // (2: one pivot per MFMA, experiments build)
     else if (kp == 32) ok = eliminate_in_registers<2>(M, mp, k, kp, rowbuf, colbuf);
     else if (kp == 64) ok = eliminate_in_registers<4>(M, mp, k, kp, rowbuf, colbuf);
     else if (kp == 96) ok = eliminate_in_registers<6>(M, mp, k, kp, rowbuf, colbuf);

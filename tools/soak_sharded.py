@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Soak of the sharded device-side resampling: random configurations (ranks, particles per rank, landmarks, observations per
 step, dtype, FastSLAM-1.0 / 2.0, resampling schedule), the shards driven by one host thread each on ONE card, against the
-one-rank synchronous filter: particles bit-identical, log-weights within 8 ulp, zero halts.  usage: soak_sharded.py [configs]"""
+one-rank synchronous filter: particles bit-identical, log-weights within 8 ulp, zero halts; and, where the ranks' slices are
+multiples of 1024 particles, against the one-rank AUTO filter: log-weights EQUAL.  usage: soak_sharded.py [configs]"""
 import math
 import os
 import sys
@@ -29,7 +30,9 @@ class Rank:
 def one(cfg_seed):
     rng = np.random.default_rng(cfg_seed)
     world = int(rng.choice([2, 3, 4]))
-    per = int(rng.choice([257, 1000, 4096, 20000, 50000, 70000]))      # below and above the observation-parallel threshold
+    # below and above the step kernels' thresholds; multiples of 1024 (the statistics tree is then the one-rank filter's:
+    # log-weights must be EQUAL to the one-rank AUTO filter's) and ragged sizes (a few ulp)
+    per = int(rng.choice([257, 1000, 4096, 20 * 1024, 20000, 49 * 1024, 70000, 69 * 1024]))
     nl = int(rng.choice([6, 20, 70]))
     m = int(rng.integers(1, min(nl, 20) + 1))
     dtype = str(rng.choice(["f32", "f64"]))
@@ -65,6 +68,17 @@ def one(cfg_seed):
             ref_hist.append((p_.copy(), w_.copy(), info))
     want = ref_sh.download()
     ref_resamples = ref.resamples
+    want_auto = None
+    if per % 1024 == 0:                     # the one-rank AUTO filter: the sharded one must equal it bit for bit, weights included
+        a_sh = pkg.PFShard(n, nl, cfg_seed, dtype=dtype)
+        a_sh.set_pose([0.5, 1.5, -0.2])
+        a_sh.init_landmarks(lm[:known], 0.01, 0.1)
+        fa = pkg.FastSLAM(a_sh, None, neff_frac=0.75)
+        for g, z, ids, force in plan:
+            fa.step_async(6.0, g, 4.0, Q, 0.1, z, ids, R, force_resample=force, proposal=proposal)
+        fa.flush()
+        want_auto = a_sh.download()
+        a_sh.close()
     if os.environ.get("SOAK_KEEP_REF") != "1":
         ref_sh.close()                      # (its stream goes before the shards' kernels start waiting for each other)
     got, errs = [None] * world, []
@@ -112,6 +126,9 @@ def one(cfg_seed):
         tol = 8 * np.finfo(wa.dtype).eps * max(1.0, float(np.abs(want[1]).max()))
         checks = dict(halts=halts == [0] * world, poses=bool(np.array_equal(pa, want[0])), landmarks=bool(np.array_equal(la, want[2])),
                       logw=bool(np.allclose(wa, want[1], rtol=0, atol=tol)))
+        if want_auto is not None:           # aligned slices: EQUAL to the one-rank auto filter (round 4: the canonical statistics tree)
+            checks["logw_equal_to_one_rank_auto"] = bool(np.array_equal(wa, want_auto[1]))
+            checks["poses_equal_to_one_rank_auto"] = bool(np.array_equal(pa, want_auto[0]))
         ok = all(checks.values())
         if not ok:
             print(f"   checks {checks} halts {halts}; particles with different poses {int((pa != want[0]).any(axis=0).sum())}, "
