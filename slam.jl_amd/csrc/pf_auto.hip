@@ -819,11 +819,19 @@ __global__ __launch_bounds__(256) void pf_auto_resample_kernel(T* pose0, T* pose
     if (threadIdx.x < PF_TAB_MAX) s_tl[threadIdx.x] = ctl->tl_idx[threadIdx.x];
     __syncthreads();
     if (threadIdx.x == 0) {
+        // the same additions in the same (index) order as pf_scan2_kernel -- s_off[b + 1] == s_off[b] + bsum[b] exactly, which the
+        // two-level search below relies on -- sixteen entries at a time out of registers: written as load / store / add per entry
+        // the loop waited for an LDS round trip per block total
         double run = 0.0;
-        for (int i = 0; i < nb; ++i) {
-            const double v = s_off[i];
-            s_off[i] = run;
-            run += v;
+        for (int i0 = 0; i0 < nb; i0 += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = i0 + u < nb ? s_off[i0 + u] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (i0 + u < nb) s_off[i0 + u] = run;
+                run += v[u];                               // (+ 0.0 beyond nb: exact)
+            }
         }
         s_off[nb] = run;
     }
