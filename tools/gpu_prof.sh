@@ -7,5 +7,6 @@ timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT
 echo "rocprof exit $?"
 f=$(find $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -name '*kernel_stats.csv' | head -1)
 cp "$f" $GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_stats.csv
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_$tag          # (the raw trace: gpurun copies back at most 64 MiB)
 cut -c1-150 $GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_stats.csv | head -30
 tail -c 3000 $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log | grep -o '"regimes".*"weak_scaling"' | head -3

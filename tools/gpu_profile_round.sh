@@ -10,6 +10,7 @@ rm -rf gpurun_out/pmc
 bash tools/gpu_pmc.sh > gpurun_out/pmc_$tag.log 2>&1
 python tools/pmc_summary.py gpurun_out/pmc > gpurun_out/pmc_${tag}_summary.txt 2>&1
 cut -c1-230 gpurun_out/pmc_${tag}_summary.txt | grep -E "downdate|pf_auto_step" 
+rm -rf gpurun_out/pmc                                   # (the raw counter files: gpurun copies back at most 64 MiB)
 # the other configurations' bench lines (C2: 1k landmarks, 16 obs; C5: 50k landmarks, fp64, Joseph form, 8 obs)
 timeout -k 10 300 python bench.py --landmarks 1000 --obs 16 --steps 200 --warmup 20 --no-fastslam > gpurun_out/bench_${tag}_c2.json 2>/dev/null
 timeout -k 10 400 python bench.py --landmarks 50000 --obs 8 --dtype f64 --form joseph --steps 20 --warmup 3 --no-fastslam > gpurun_out/bench_${tag}_c5.json 2>/dev/null
