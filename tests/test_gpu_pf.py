@@ -933,7 +933,8 @@ def test_sharded_filter_resamples_on_the_device(pkg, dtype, world, proposal):
         sh.close()
 
 
-@pytest.mark.parametrize("dtype,world,per", [("f32", 4, 16384), ("f64", 2, 2048), ("f32", 2, 3 * 1024), ("f32", 2, 65536), ("f32", 3, 66 * 1024)])
+@pytest.mark.parametrize("dtype,world,per", [("f32", 4, 16384), ("f64", 2, 2048), ("f32", 2, 3 * 1024), ("f32", 2, 65536), ("f32", 3, 66 * 1024),
+                                             ("f32", 4, 320 * 1024)])
 def test_sharded_normalisation_is_invariant_in_the_number_of_ranks(pkg, dtype, world, per):
     """identical results for any number of ranks -- INCLUDING the normalisation (round 4).  The weight statistics
     are the root of ONE fixed radix-4 tree over the global particle index (csrc/pf_device.h: WRec): every rank writes its
@@ -941,7 +942,8 @@ def test_sharded_normalisation_is_invariant_in_the_number_of_ranks(pkg, dtype, w
     are multiples of 1024 particles has the ONE-RANK auto filter's log-weights BIT FOR BIT, not within ulps -- also where
     the two use different step kernels (65536 particles: the one-rank filter takes the 4-way kernel and its 256-particle lines, the
     four 16384-particle shards the 8-way kernel and 64-particle leaves; 131072: 2 ways against 4; 202752: the sequential sweep
-    against three 2-way shards)."""
+    against three 2-way shards; 1 310 720 particles: more than 1024 statistics lines per rank AND more than 1024 records in the
+    inbox -- the tail's second pass on both sides, the shape of the weak-scaling filter on 5+ GPUs)."""
     import threading
     nl, seed = 14, 91
     n = per * world

@@ -3,7 +3,7 @@ tag=${1:-r02}
 shift
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-pmc "$@" > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-pmc --no-configs "$@" > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log 2>&1
 echo "rocprof exit $?"
 f=$(find $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -name '*kernel_stats.csv' | head -1)
 cp "$f" $GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_stats.csv
