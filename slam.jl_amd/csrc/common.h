@@ -127,6 +127,7 @@ struct slam_ekf {
     int2* tiles;         // two orders in one buffer: the super-row order (8 lists of tiles_len), then the band-major
     int tiles_T, tiles_len, tiles_cap;     // order of the split-bf16 path (8 lists of tilesB_len, at offset tilesB_off)
     int tilesB_off, tilesB_len;
+    int tilesH_off, tilesH_len;            // (experiments build: the half-tile experiment's lists)
     unsigned* dd_claim;  // [8][16] per-XCD tile counters of the claiming down-date launch (zeroed before every launch)
     int tiles_xlen[8];   // valid entries of each XCD's list
     int diag_off, diag_len, diag_xlen[8];   // fp32: the diagonal tiles, listed after the main lists

@@ -194,6 +194,29 @@ extern "C" int slam_ekf_destroy(slam_ekf_t h) {
     if (!h) return SLAM_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+#ifdef SLAMHIP_EXPERIMENTS
+    if (h->dd_prof && slam_exp_env("SLAMHIP_STAMPS", 0)) {       // dd_stream_dma's phase sums of the LAST down-date
+        const size_t cnt = (size_t)4096 * 16;
+        std::vector<unsigned long long> v(cnt);
+        if (hipMemcpy(v.data(), h->dd_prof, cnt * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            double s[16] = {0};
+            size_t waves = 0;
+            for (size_t w = 0; w < 4096; ++w) {
+                if (!v[16 * w]) continue;
+                ++waves;
+                for (int i = 0; i < 14; ++i) s[i] += (double)v[16 * w + i];
+            }
+            if (waves) {
+                fprintf(stderr, "[slamhip] dma down-date, mean per wave of %zu waves: steps %.1f  clk per step: reads %.0f  mfma-issue %.0f  barrier %.0f  dma-issue %.0f  stores(per tile) %.0f  chunk-wait by step:",
+                        waves, s[0] / waves, s[1] / s[0], s[2] / s[0], s[3] / s[0], s[4] / s[0], s[5] / s[0] * 8);
+                for (int i = 0; i < 8; ++i) fprintf(stderr, " %.0f", s[6 + i] / s[0] * 8);
+                fprintf(stderr, "\n");
+            }
+        }
+        dev_free(h->dd_prof);
+        h->dd_prof = nullptr;
+    }
+#endif
     if (h->dd_prof) {                // experiment output: mean per-wave phase clocks of the LAST down-date
         const size_t cnt = (size_t)4096 * 4 * 4;
         std::vector<unsigned long long> v(cnt);
@@ -257,6 +280,9 @@ static int create_impl(slam_ekf* h) {
     h->h_flag[0] = 0;
     HIP_TRY(hipHostGetDevicePointer((void**)&h->h_flag_dev, h->h_flag, 0));
     if ((h->debug_flags & 8) && (rc = dev_alloc_zero(&h->dd_prof, (size_t)4096 * 4 * 4 * 8, h->stream))) return rc;
+#ifdef SLAMHIP_EXPERIMENTS
+    if (!h->dd_prof && slam_exp_env("SLAMHIP_STAMPS", 0) && (rc = dev_alloc_zero(&h->dd_prof, (size_t)4096 * 16 * 8, h->stream))) return rc;
+#endif
     if ((rc = dev_alloc_zero(&h->d_status, sizeof(int32_t) * 4, h->stream))) return rc;
     HIP_TRY(hipHostMalloc((void**)&h->h_small, sizeof(double) * 64, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&h->h_status, sizeof(int32_t) * 4, hipHostMallocDefault));

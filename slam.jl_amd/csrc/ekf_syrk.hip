@@ -46,6 +46,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <type_traits>
 #include "device_math.h"
 
 namespace {
@@ -598,8 +599,19 @@ __device__ __forceinline__ void mfma_chunk_p(const DdCtx& c, const char* sm, int
 // that is waited for anyway), stores the position to an LDS word before chunk 1's barrier, and every wave reads it
 // after that barrier -- wave-uniform, so the list entry comes through the SCALAR cache, outside the in-order queue.
 constexpr int CLAIM_OFF = 2 * 2 * IMG_CHUNK;        // the LDS word behind the two image buffers
+// The claim word goes through these two: a VOLATILE access through a generic pointer is not rewritten to the LDS address
+// space by the compiler and comes out as flat_store / flat_load followed by s_waitcnt vmcnt(0) -- which, in the middle of a
+// tile, waited for the whole P tile just requested and for the previous tile's stores (found in round 4 in the ISA; the
+// kernel's phases "adding instead of overlapping" was largely this wait).  With the address space spelled out they are
+// ds_write_b32 / ds_read_b32 and touch lgkmcnt only.
+typedef __attribute__((address_space(3))) unsigned lds_u32_t;
+__device__ __forceinline__ void lds_store_u32(char* p, unsigned v) { *(volatile lds_u32_t*)p = v; }
+__device__ __forceinline__ unsigned lds_load_u32(const char* p) { return *(const volatile lds_u32_t*)p; }
 #ifndef DD_PCH0
 #define DD_PCH0 0
+#endif
+#ifndef DD_POFF8          // (build-time A/B at eight chunks per tile: the P tile is requested at chunk 8 - DD_POFF8)
+#define DD_POFF8 (7 + DD_PCH0)
 #endif
 
 template <bool DBG, int NCH, int POFF, bool WRAP = false, bool DYN = false>
@@ -632,14 +644,14 @@ __device__ __forceinline__ void dd_stream_p(DdCtx& c, const int2* __restrict__ l
             const int pb = (base + ch) & 1;
             if (ch == PCH && !(DBG && (c.dbg & 4))) load_p_mfma(c, tile.x * TILE, tile.y * TILE, pold);
             mfma_chunk_p<DBG>(c, sm, pb, acc, WRAP && ch >= 8);
-            if (DYN && ch == 1 && threadIdx.x == 0) *reinterpret_cast<volatile unsigned*>(sm + CLAIM_OFF) = claimed;
+            if (DYN && ch == 1 && threadIdx.x == 0) lds_store_u32(sm + CLAIM_OFF, claimed);
             if (ch < NCH - 1) {
                 fill_lds_p(sm, pb ^ 1, g);
                 __syncthreads();
                 if (DYN && ch == 0 && threadIdx.x == 0)
                     claimed = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (DYN && ch == 1) {
-                    next_slot = nper + __builtin_amdgcn_readfirstlane((int)*reinterpret_cast<volatile unsigned*>(sm + CLAIM_OFF));
+                    next_slot = nper + __builtin_amdgcn_readfirstlane((int)lds_load_u32(sm + CLAIM_OFF));
                     next = fetch(next_slot);
                     next_off = next.x >= 0 && next.x != next.y;
                 }
@@ -658,6 +670,187 @@ __device__ __forceinline__ void dd_stream_p(DdCtx& c, const int2* __restrict__ l
         if (!DYN) next = fetch(slot + nper);
         base = (base + NCH) & 1;
     }
+}
+
+
+// ---- the image path with the panel chunks moved by LDS-DMA, two chunks ahead (round 4) ------------------------------------------
+// dd_stream_p gives a chunk ONE step to come from the L2 (requested after step c's barrier, written to LDS at the end of step
+// c + 1) and pays three ds_write_b128 plus their wait per wave and chunk.  Here the chunks go global -> LDS directly
+// (buffer_load_dwordx4 ... lds: the image IS the LDS layout, one wave instruction = 1 KB of it) into THREE buffers of 24 KB --
+// the 72 KB this kernel's LDS array has anyway --, requested TWO steps ahead: after step c's barrier buffer c % 3 is free and
+// receives chunk c + 3, chunk c + 1 has landed (waited for before that barrier), chunk c + 2 is on its way.  No staging
+// registers, no LDS stores, and what sits between two chunks in a wave's in-order memory queue -- the P tile's 32 loads,
+// its 32 stores -- has two steps to get out of the way instead of one.
+//   The waits are COUNTED by hand (inline s_waitcnt; the barrier is a bare s_barrier: __syncthreads() would drain the queue):
+// at the end of step c everything up to chunk c + 1's three pieces must be back, i.e. at most what was issued after them may
+// be outstanding: chunk c + 2's three pieces, plus the P tile's 32 loads where they were issued in between (PCH = c - 1 or c),
+// plus the previous tile's 32 stores (c = 0, 1).  The count has to be a LOWER bound of what was issued behind the chunk (a
+// larger one lets the wait pass while the chunk is still on its way): it drops to what is really there on a workgroup's first
+// tile (no stores yet) and last one (no chunks of a next tile).  Operations the count does not know -- wave 0's claim atomic,
+// the one side-array store -- only make a wave wait for one operation more than it has to.
+constexpr int DMA_BUF = 2 * IMG_CHUNK;          // [X image chunk | Y image chunk]
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+// The DMA itself is the compiler's builtin -- so that its own counted waits (the P tile's loads before the stores, the claim
+// atomic) include these operations --, but every LDS READ of this path is inline assembly: the compiler puts s_waitcnt vmcnt(0)
+// in front of any LDS access it can see while an LDS-DMA is in flight (it cannot tell the buffers apart), which would be the
+// pipeline gone.
+__device__ __forceinline__ void dma_chunk(const DdCtx& c, int2 t, int chunk, char* sm, int buf, int wave) {
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(c.img), (short)0, 0x7fffffff, 0x00020000);
+    const int sx = (t.x * c.img_nch + chunk) * IMG_CHUNK + wave * 1024, sy = (t.y * c.img_nch + chunk) * IMG_CHUNK + wave * 1024;
+    const int lane16 = (threadIdx.x & 63) * 16;
+    char* dst = sm + buf * DMA_BUF + wave * 1024;
+    // the 1536 sixteen-byte pieces [X image | Y image] of a chunk: wave w moves pieces 64 w .. 64 w + 63 of each third
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)dst, 16, lane16, sx, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(dst + 8192), 16, lane16, wave < 4 ? sx + 8192 : sy - 4096, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(dst + 16384), 16, lane16, sy + 4096, 0, 0);
+}
+__device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(unsigned long long)(const lds_void_t*)p; }
+__device__ __forceinline__ void asm_lds_store_u32(char* p, unsigned v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(lds_addr(p)), "v"(v) : "memory");
+}
+__device__ __forceinline__ unsigned asm_lds_load_u32(const char* p) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_addr(p)) : "memory");
+    return v;
+}
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {          // f(integral_constant<int, I>) for I = I .. N - 1, unrolled at compile time
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void bare_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct DdFrags { bf16x8 a[3], b[3], b1[3]; };
+__device__ __forceinline__ void read_frags_d(const DdCtx& c, const char* sm, int buf, DdFrags& f) {
+    const unsigned base = lds_addr(sm) + buf * DMA_BUF + c.l31 * 32 + ((c.lh ^ (c.l31 >> 3)) & 1) * 16;
+    const unsigned ya = base + IMG_CHUNK + (32 * c.wc) * 32, xa = base + (64 * c.wr) * 32;
+    asm volatile(
+        "ds_read_b128 %0, %9\n\tds_read_b128 %1, %9 offset:4096\n\tds_read_b128 %2, %9 offset:8192\n\t"
+        "ds_read_b128 %3, %10\n\tds_read_b128 %4, %10 offset:4096\n\tds_read_b128 %5, %10 offset:8192\n\t"
+        "ds_read_b128 %6, %10 offset:1024\n\tds_read_b128 %7, %10 offset:5120\n\tds_read_b128 %8, %10 offset:9216\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(f.a[0]), "=&v"(f.a[1]), "=&v"(f.a[2]), "=&v"(f.b[0]), "=&v"(f.b[1]), "=&v"(f.b[2]), "=&v"(f.b1[0]), "=&v"(f.b1[1]), "=&v"(f.b1[2])
+        : "v"(ya), "v"(xa)
+        : "memory");
+}
+__device__ __forceinline__ void mfma_frags_d(const DdFrags& f, f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        __builtin_amdgcn_s_setprio(3);
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1], rb ? f.b1[1] : f.b[1], acc[rb], 0, 0, 0);      // (m, m)
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], rb ? f.b1[2] : f.b[2], acc[rb], 0, 0, 0);      // (h, l)
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[2], rb ? f.b1[0] : f.b[0], acc[rb], 0, 0, 0);      // (l, h)
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], rb ? f.b1[1] : f.b[1], acc[rb], 0, 0, 0);      // (h, m)
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1], rb ? f.b1[0] : f.b[0], acc[rb], 0, 0, 0);      // (m, h)
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], rb ? f.b1[0] : f.b[0], acc[rb], 0, 0, 0);      // (h, h)
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+// PCH (2 <= PCH <= NCH - 2): the step at whose start the P tile is requested
+// ORD2: the step's barrier sits between the fragment reads and the MFMAs (reads -> wait for the next chunk -> barrier -> MFMAs ->
+// request): after the barrier every wave goes into its MFMAs, and the DMA requests and the next step's fragment reads follow as
+// the waves leave the matrix pipe one after the other, instead of eight waves reading 72 KB of fragments at once.
+template <bool DBG, int NCH, int PCH, bool ORD2 = false>
+__device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__ list, int L, int nper, int& slot, char* sm,
+                                              unsigned* __restrict__ ctr, int wave, char* cw, unsigned long long* prof = nullptr) {
+    static_assert(NCH >= 5 && PCH >= 2 && PCH <= NCH - 2, "");
+#ifdef SLAMHIP_EXPERIMENTS
+    // (SLAMHIP_STAMPS=1: where a wave's cycles go -- shader-clock sums over all its steps: fragment reads, MFMA issue, the wait
+    //  for the chunk per step of the tile, barrier, DMA issue, stores)
+    unsigned long long ph_lds = 0, ph_mfma = 0, ph_bar = 0, ph_issue = 0, ph_store = 0, ph_vm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_steps = 0;
+#define STAMP(var) do { if (prof) { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define STAMP(var) do { } while (0)
+#endif
+    constexpr int RD = NCH - 3;        // the step at whose end the next tile's first chunk is requested
+    auto fetch = [&](int sl) { return sl < L ? list[sl] : make_int2(-1, -1); };
+    int2 tile = fetch(slot);
+    int2 next = make_int2(-1, -1);
+    int next_slot = slot + nper;
+    unsigned claimed = 0;
+    f32x16 acc[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
+    float pold[2][16];
+    dma_chunk(c, tile, 0, sm, 0, wave);
+    dma_chunk(c, tile, 1, sm, 1, wave);
+    dma_chunk(c, tile, 2, sm, 2, wave);
+    wait_vm<6>();
+    bare_barrier();
+    int base = 0;                      // the buffer that holds chunk 0 of the current tile
+    bool first = true;
+    for (;;) {
+        bool next_off = false;
+        static_for<0, NCH>([&](auto CH) {
+            constexpr int ch = decltype(CH)::value;
+            const int buf = (base + ch) % 3;
+            unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+            STAMP(t0);
+            if (ch == PCH && !(DBG && (c.dbg & 4))) load_p_mfma(c, tile.x * TILE, tile.y * TILE, pold);
+            DdFrags fr;
+            read_frags_d(c, sm, buf, fr);
+            STAMP(t1);
+            if (!ORD2) mfma_frags_d(fr, acc);
+            STAMP(t2);
+            if (ch == RD && threadIdx.x == 0) asm_lds_store_u32(cw, claimed);
+            // chunk ch + 1 (this tile's, or the next tile's first) has landed when at most these remain outstanding
+            constexpr int PL = (ch == PCH || ch == PCH + 1) ? 32 : 0;           // the P tile's loads sit behind it
+            if (ch <= 1) {                                                      // ... the previous tile's stores and chunk ch + 2
+                if (first) wait_vm<3>();
+                else wait_vm<35>();
+            } else if (ch + 2 < NCH) wait_vm<3 + PL>();
+            else if (next_off) wait_vm<3 + PL>();                               // (chunk ch + 2 is the next tile's)
+            else wait_vm<PL>();
+            STAMP(t3);
+            bare_barrier();
+            STAMP(t4);
+            if (ch == 0 && threadIdx.x == 0) claimed = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ch == RD) {          // (the claim of step 0 is read as late as the next tile's first chunk allows: its return
+                                     //  comes behind the previous tile's stores in wave 0's queue)
+                next_slot = nper + __builtin_amdgcn_readfirstlane((int)asm_lds_load_u32(cw));
+                next = fetch(next_slot);
+                next_off = next.x >= 0 && next.x != next.y;
+            }
+            unsigned long long t4b = t4;
+            if (ORD2) {
+                mfma_frags_d(fr, acc);
+                STAMP(t4b);
+            }
+            if (ch + 3 < NCH) dma_chunk(c, tile, ch + 3, sm, buf, wave);
+            else if (next_off) dma_chunk(c, next, ch + 3 - NCH, sm, buf, wave);
+            STAMP(t5);
+            if (ch == NCH - 1 && !(DBG && (c.dbg & 1))) store_p_mfma(c, tile.x * TILE, tile.y * TILE, pold, acc);
+            STAMP(t6);
+#ifdef SLAMHIP_EXPERIMENTS
+            if (prof) {
+                ph_lds += t1 - t0; ph_mfma += (t2 - t1) + (t4b - t4); ph_vm[ch < 8 ? ch : 7] += t3 - t2; ph_bar += t4 - t3; ph_issue += t5 - t4b; ph_store += t6 - t5;
+                ++ph_steps;
+            }
+#endif
+        });
+        slot = next_slot;
+        if (!next_off) break;
+        tile = next;
+        base = (base + NCH) % 3;
+        first = false;
+    }
+    wait_vm<0>();                      // (nothing of this path is in flight when the diagonal tiles take the LDS array over)
+#ifdef SLAMHIP_EXPERIMENTS
+    if (prof && (threadIdx.x & 63) == 0) {
+        unsigned long long* o = prof + ((size_t)blockIdx.x * NWAVE + wave) * 16;
+        o[0] = ph_steps; o[1] = ph_lds; o[2] = ph_mfma; o[3] = ph_bar; o[4] = ph_issue; o[5] = ph_store;
+        for (int i = 0; i < 8; ++i) o[6 + i] = ph_vm[i];
+    }
+#endif
+#undef STAMP
 }
 
 // As dd_stream: processes list[slot], list[slot + nper], ... while they are off-diagonal; NCH = kp / 16 (>= 2).  On
@@ -732,6 +925,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
         if (kp == 0) return;
     }
     __shared__ __attribute__((aligned(16))) float smem[2][2][TILE][LDSP];   // [buffer][X|Y][row][k]  73,728 B
+    __shared__ unsigned dma_claim_word[4];                                   // (dd_stream_dma's claim word: its three buffers fill smem)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // provably wave-uniform
@@ -768,10 +962,29 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
         // the product's launch at 80 <= k <= 128: a persistent grid that CLAIMS its tiles (dd_stream_p<DYN>)
         char* sm = reinterpret_cast<char*>(&smem[0][0][0][0]);
         unsigned* ctr = claim + 16 * xcd;                     // one counter per XCD list, 64 bytes apart
+        if (tile.x != tile.y && (c.xflags & 1024)) {         // SLAMHIP_X bit 1024: the LDS-DMA pipeline with the barrier between reads and MFMAs
+            char* cw = reinterpret_cast<char*>(&dma_claim_word[0]);
+            switch (kp / KB) {
+                case 8: dd_stream_dma<DBG, 8, 2, true>(c, list, L, nper, slot, sm, ctr, wave, cw, prof); break;
+                case 7: dd_stream_dma<DBG, 7, 2, true>(c, list, L, nper, slot, sm, ctr, wave, cw, prof); break;
+                case 6: dd_stream_dma<DBG, 6, 2, true>(c, list, L, nper, slot, sm, ctr, wave, cw, prof); break;
+                default: dd_stream_dma<DBG, 5, 2, true>(c, list, L, nper, slot, sm, ctr, wave, cw, prof); break;
+            }
+        } else
+        if (tile.x != tile.y && (c.xflags & 512)) {          // SLAMHIP_X bit 512: the LDS-DMA pipeline, chunks two steps ahead
+            static_assert(sizeof(smem) == 3 * DMA_BUF, "three 24 KB chunk buffers");
+            char* cw = reinterpret_cast<char*>(&dma_claim_word[0]);
+            switch (kp / KB) {
+                case 8: dd_stream_dma<DBG, 8, 2>(c, list, L, nper, slot, sm, ctr, wave, cw, prof); break;
+                case 7: dd_stream_dma<DBG, 7, 2>(c, list, L, nper, slot, sm, ctr, wave, cw, prof); break;
+                case 6: dd_stream_dma<DBG, 6, 2>(c, list, L, nper, slot, sm, ctr, wave, cw, prof); break;
+                default: dd_stream_dma<DBG, 5, 2>(c, list, L, nper, slot, sm, ctr, wave, cw, prof); break;
+            }
+        } else
         if (tile.x != tile.y) {
             switch (kp / KB) {
                 // (DD_PCH0 = 1, build-time A/B: the P tile requested at the tile's FIRST chunk instead of its second)
-                case 8: dd_stream_p<DBG, 8, 7 + DD_PCH0, false, true>(c, list, L, nper, slot, sm, ctr); break;
+                case 8: dd_stream_p<DBG, 8, DD_POFF8, false, true>(c, list, L, nper, slot, sm, ctr); break;
                 case 7: dd_stream_p<DBG, 7, 6 + DD_PCH0, false, true>(c, list, L, nper, slot, sm, ctr); break;
                 case 6: dd_stream_p<DBG, 6, 5 + DD_PCH0, false, true>(c, list, L, nper, slot, sm, ctr); break;
                 default: dd_stream_p<DBG, 5, 4 + DD_PCH0, false, true>(c, list, L, nper, slot, sm, ctr); break;
@@ -786,9 +999,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
             if (tile.x != tile.y) dd_tile<false, DBG>(c, tile, make_int2(-1, -1), smem, sD, sV, gx, gy);
             else dd_tile<true, DBG>(c, tile, make_int2(-1, -1), smem, sD, sV, gx, gy);
             if (tid == 0)
-                *reinterpret_cast<volatile unsigned*>(sm + CLAIM_OFF) = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lds_store_u32(sm + CLAIM_OFF, __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             __syncthreads();
-            slot = nper + __builtin_amdgcn_readfirstlane((int)*reinterpret_cast<volatile unsigned*>(sm + CLAIM_OFF));
+            slot = nper + __builtin_amdgcn_readfirstlane((int)lds_load_u32(sm + CLAIM_OFF));
         }
         return;
     }
@@ -855,6 +1068,197 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
         o[3] = __builtin_amdgcn_s_memtime() - mt0;
     }
 }
+
+
+#ifdef SLAMHIP_EXPERIMENTS
+// ---- EXPERIMENT (round 4, experiments build only, SLAMHIP_HALF=1; OFF-DIAGONAL TILES ONLY: wrong results) --------------------
+// The switch-off runs of this round say the split-bf16 down-date's phases ADD (panel pipeline 0.166 ms + MFMAs 0.128 + P loads
+// 0.043 + stores 0.08) instead of overlapping: the eight waves of a workgroup move in lockstep from barrier to barrier, and only
+// two workgroups fit a CU.  Here a workgroup is FOUR waves on a 64 x 128 half tile (wave w = column quarter w, both row blocks
+// of the half) -- NOW: a 128 x 64 half, 32 contiguous KB of the column-major tile, wave = (row half, column quarter); the
+// 64 x 128 split measured 0.298 ms without stores but 0.388 with them, against 0.344 / 0.357 of the product kernel --, 36 KB of LDS, so FOUR workgroups with barriers of their own share a CU: twice the phases to interleave, at the
+// price of re-reading the column panel per 64 rows (L2 -> LDS traffic x 1.5).  Timing experiment: what would that buy?
+constexpr int HX = 3 * 64 * 32;             // X part of a chunk: three split arrays of 64 rows x 32 bytes
+constexpr int HCH = HX + IMG_CHUNK;         // one chunk buffer: X (6144 B) then Y (12288 B)
+constexpr int HCLAIM = 2 * HCH;
+
+__device__ __forceinline__ void request_chunk_h(const char* img, int img_nch, int I, int half, int J, int chunk, const int (&voff)[5],
+                                                u32x4b (&g)[5]) {
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(img), (short)0, 0x7fffffff, 0x00020000);
+    // (the HALVED panel is the column panel: a workgroup's 128 x 64 half of a column-major tile is 32 contiguous KB)
+    const int sx = (J * img_nch + chunk) * IMG_CHUNK + half * 2048, sy = (I * img_nch + chunk) * IMG_CHUNK;
+    const int tid = threadIdx.x;
+    // pieces tid + 256 j of the 1152 sixteen-byte pieces [X: 3 x 128 | Y: 768]; voff[j] >= 0: offset inside the X image of the
+    // row block (split array * 4096 + piece), else -(offset inside the Y image) - 1
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        if (j == 4 && tid >= 128) break;
+        const int p = tid + 256 * j;
+        (void)voff;
+        g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, p < 384 ? sx + (p >> 7) * IMG_ARR + (p & 127) * 16 : sy + (p - 384) * 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void fill_lds_h(char* sm, int buf, const u32x4b (&g)[5]) {
+    char* base = sm + buf * HCH + threadIdx.x * 16;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        if (j == 4 && threadIdx.x >= 128) break;
+        *reinterpret_cast<u32x4b*>(base + j * 4096) = g[j];
+    }
+}
+
+__device__ __forceinline__ void mfma_chunk_h(const DdCtx& c, const char* sm, int buf, f32x16 (&acc)[2]) {
+    const char* base = sm + buf * HCH + c.l31 * 32 + ((c.lh ^ (c.l31 >> 3)) & 1) * 16;
+    bf16x8 a[3];
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp) a[sp] = *reinterpret_cast<const bf16x8*>(base + sp * 2048 + (32 * (c.wc & 1)) * 32);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        bf16x8 b[3];
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) b[sp] = *reinterpret_cast<const bf16x8*>(base + HX + sp * IMG_ARR + (64 * c.wr + 32 * rb) * 32);
+        __builtin_amdgcn_s_setprio(3);
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[rb], 0, 0, 0);      // (m, m)
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[rb], 0, 0, 0);      // (h, l)
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[rb], 0, 0, 0);      // (l, h)
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[rb], 0, 0, 0);      // (h, m)
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[rb], 0, 0, 0);      // (m, h)
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[rb], 0, 0, 0);      // (h, h)
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+// list entries: {I, 2 J + half}, I > J
+// one row block (32 rows x the wave's 32 columns) of the P tile in the MFMA layout: 16 dword loads / stores of two 128-byte lines
+__device__ __forceinline__ void load_p_rb(const DdCtx& c, int R0, int C0, int rb, float (&po)[16]) {
+    const auto rs = tile_rsrc(c, R0, C0);
+    const int voff = (4 * c.lh * TILE + c.l31) * 4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        po[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, ((32 * c.wc + 8 * (r >> 2) + (r & 3)) * TILE + 64 * c.wr + 32 * rb) * 4, 2));
+}
+__device__ __forceinline__ void store_p_rb(const DdCtx& c, int R0, int C0, int rb, const float (&po)[16], f32x16& acc) {
+    const auto rs = tile_rsrc(c, R0, C0);
+    const int voff = (4 * c.lh * TILE + c.l31) * 4;
+    const bool adj = R0 == C0 + TILE;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float v = po[r] - acc[r];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, ((32 * c.wc + 8 * (r >> 2) + (r & 3)) * TILE + 64 * c.wr + 32 * rb) * 4, 2);
+        if (rb == 0 && r == 15 && adj && c.wr == 0 && c.wc == 3 && c.lh == 1 && c.l31 == 0) c.side[(size_t)c.side_n + ((C0 + TILE - 4) >> 1)] = v;
+        acc[r] = 0.0f;
+    }
+}
+
+// SPLITP: the P tile's second row block is requested only after the tile's last LDS fill, into the registers the panel pieces
+// have just left (the pieces of the next tile's second chunk are then requested after the stores): 16 registers less at the peak
+template <int NCH, bool NOSTORE, bool SPLITP>
+__device__ __forceinline__ void dd_stream_h(DdCtx& c, const int2* __restrict__ list, int L, int nper, int slot, char* sm,
+                                            unsigned* __restrict__ ctr, const int (&voff)[5]) {
+    auto fetch = [&](int sl) { return sl < L ? list[sl] : make_int2(-1, -1); };
+    constexpr int PCH = 1;
+    int2 tile = fetch(slot);
+    if (tile.x < 0) return;
+    const int wq = c.wc;
+    int2 next = make_int2(-1, -1);
+    unsigned claimed = 0;
+    f32x16 acc[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
+    float pold[2][16];
+    u32x4b g[5];
+    request_chunk_h(c.img, c.img_nch, tile.x, tile.y & 1, tile.y >> 1, 0, voff, g);
+    fill_lds_h(sm, 0, g);
+    __syncthreads();
+    request_chunk_h(c.img, c.img_nch, tile.x, tile.y & 1, tile.y >> 1, 1, voff, g);
+    int base = 0;
+    for (;;) {
+        bool next_ok = next.x >= 0;
+        c.wc = 2 * (tile.y & 1) + wq;                       // (uniform: the wave's column quarter of the 128-column tile)
+        const int R0 = tile.x * TILE, C0 = (tile.y >> 1) * TILE;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int pb = (base + ch) & 1;
+            if (ch == PCH) {
+                if (SPLITP) load_p_rb(c, R0, C0, 0, pold[0]);
+                else load_p_mfma(c, R0, C0, pold);
+            }
+            mfma_chunk_h(c, sm, pb, acc);
+            if (ch == 1 && threadIdx.x == 0) lds_store_u32(sm + HCLAIM, claimed);
+            if (ch < NCH - 1) {
+                fill_lds_h(sm, pb ^ 1, g);
+                __syncthreads();
+                if (ch == 0 && threadIdx.x == 0) claimed = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ch == 1) {
+                    next = fetch(nper + __builtin_amdgcn_readfirstlane((int)lds_load_u32(sm + HCLAIM)));
+                    next_ok = next.x >= 0;
+                }
+                if (ch + 2 < NCH) request_chunk_h(c.img, c.img_nch, tile.x, tile.y & 1, tile.y >> 1, ch + 2, voff, g);
+                else if (next_ok) request_chunk_h(c.img, c.img_nch, next.x, next.y & 1, next.y >> 1, 0, voff, g);
+            } else {
+                if (next_ok) fill_lds_h(sm, pb ^ 1, g);
+                if (SPLITP) load_p_rb(c, R0, C0, 1, pold[1]);
+                __syncthreads();
+                if (!SPLITP && next_ok) request_chunk_h(c.img, c.img_nch, next.x, next.y & 1, next.y >> 1, 1, voff, g);
+                if (!NOSTORE && SPLITP) {
+                    store_p_rb(c, R0, C0, 0, pold[0], acc[0]);
+                    store_p_rb(c, R0, C0, 1, pold[1], acc[1]);
+                } else
+                if (!NOSTORE) store_p_mfma(c, R0, C0, pold, acc);   // (a RUN-time switch here costs 0.09 ms: the two paths' different
+                                                                    //  store counts make the next panel wait a vmcnt(0))
+                else {
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { asm volatile("" ::"v"(pold[rb][r] - acc[rb][r])); acc[rb][r] = 0.0f; }
+                }
+                if (SPLITP && next_ok) request_chunk_h(c.img, c.img_nch, next.x, next.y & 1, next.y >> 1, 1, voff, g);
+            }
+        }
+        if (!next_ok) return;
+        tile = next;
+        base = (base + NCH) & 1;
+    }
+}
+
+template <bool NOSTORE, bool SPLITP, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void downdate_f32_half(
+    float* __restrict__ P, int ld, const int2* __restrict__ tiles, int L, const int32_t* __restrict__ status,
+    const int32_t* __restrict__ dcount, int kp, const char* __restrict__ img, int img_nch, unsigned* __restrict__ claim,
+    float* __restrict__ side, int side_n) {
+    if (status[0] != 0) return;
+    if (dcount) {
+        const int k = 2 * dcount[0];
+        kp = (k + 15) / 16 * 16;
+        if (kp == 0) return;
+    }
+    __shared__ __attribute__((aligned(16))) char sm[HCLAIM + 16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    DdCtx c;
+    c.side = side; c.side_n = side_n; c.P = P; c.ld = ld; c.img = img; c.img_nch = img_nch; c.kp = kp; c.dbg = 0; c.xflags = 0;
+    c.wr = __builtin_amdgcn_readfirstlane(tid >> 6) & 1; c.wc = __builtin_amdgcn_readfirstlane(tid >> 6) >> 1;   // wave = (row half, column quarter of the half tile)
+    c.l31 = lane & 31; c.lh = lane >> 5;
+    int voff[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int p = tid + 256 * j;
+        voff[j] = p < 384 ? (p >> 7) * IMG_ARR + (p & 127) * 16 : -((p - 384) * 16) - 1;
+    }
+    const int xcd = blockIdx.x & 7, rk = blockIdx.x >> 3, nper = gridDim.x >> 3;
+    const int2* list = tiles + (size_t)xcd * L;
+    unsigned* ctr = claim + 16 * xcd;
+    switch (kp / KB) {
+        case 8: dd_stream_h<8, NOSTORE, SPLITP>(c, list, L, nper, rk, sm, ctr, voff); break;
+        case 7: dd_stream_h<7, NOSTORE, SPLITP>(c, list, L, nper, rk, sm, ctr, voff); break;
+        case 6: dd_stream_h<6, NOSTORE, SPLITP>(c, list, L, nper, rk, sm, ctr, voff); break;
+        case 5: dd_stream_h<5, NOSTORE, SPLITP>(c, list, L, nper, rk, sm, ctr, voff); break;
+        default: break;
+    }
+}
+#endif
 
 // ---- fp64 down-date on the fp64 matrix cores ------------------------------------------
 // 64 x 64 tile per 256-thread workgroup, wave (wr, wc) owns rows 32 wr.., columns 32 wc.. as 2 x 2 blocks of
@@ -1017,10 +1421,27 @@ void build_tile_order(int T, std::vector<int2>& out, int order) {
 
 int ensure_tile_order(slam_ekf* h, int T) {
     if (h->tiles && h->tiles_T == T) return SLAM_OK;
-    std::vector<int2> order, orderB;
+    std::vector<int2> order, orderB, orderH;
     build_tile_order(T, order, 0);
     build_tile_order(T, orderB, 2);
-    const size_t total = order.size() + orderB.size();
+#ifdef SLAMHIP_EXPERIMENTS
+    {   // the half-tile experiment's lists: the band-major order with every off-diagonal tile as its two 64-row halves
+        std::vector<std::vector<int2>> lists(8);
+        for (int J = 0; J < T; ++J)
+            for (int I = J + 1; I < T; ++I) {
+                const int r = I % 16;
+                auto& l = lists[r < 8 ? r : 15 - r];
+                l.push_back(make_int2(I, 2 * J));
+                l.push_back(make_int2(I, 2 * J + 1));
+            }
+        size_t LH = 1;
+        for (auto& l : lists) LH = std::max(LH, l.size());
+        orderH.assign(LH * 8, make_int2(-1, -1));
+        for (int x = 0; x < 8; ++x)
+            for (size_t i = 0; i < lists[x].size(); ++i) orderH[x * LH + i] = lists[x][i];
+    }
+#endif
+    const size_t total = order.size() + orderB.size() + orderH.size();
     HIP_TRY(hipStreamSynchronize(h->stream));          // earlier down-dates may still read the old list
     if ((int)total > h->tiles_cap) {
         if (h->tiles) (void)hipFree(h->tiles);
@@ -1031,6 +1452,10 @@ int ensure_tile_order(slam_ekf* h, int T) {
     }
     HIP_TRY(hipMemcpy(h->tiles, order.data(), sizeof(int2) * order.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->tiles + order.size(), orderB.data(), sizeof(int2) * orderB.size(), hipMemcpyHostToDevice));
+    if (!orderH.empty())
+        HIP_TRY(hipMemcpy(h->tiles + order.size() + orderB.size(), orderH.data(), sizeof(int2) * orderH.size(), hipMemcpyHostToDevice));
+    h->tilesH_off = (int)(order.size() + orderB.size());
+    h->tilesH_len = (int)orderH.size() / 8;
     h->tiles_T = T;
     h->tiles_len = (int)order.size() / 8;          // L: entries per XCD list
     h->tilesB_off = (int)order.size();
@@ -1067,6 +1492,36 @@ __global__ __launch_bounds__(512) void tile_copy_floor_kernel(T* __restrict__ P,
 }  // namespace
 
 // out = {milliseconds of the fastest pass, its launch form: 0 = one workgroup per tile / 1 = persistent}.  Synchronises.
+#ifdef SLAMHIP_EXPERIMENTS
+// EXPERIMENT (round 4, SLAMHIP_COPY_LAG=1): the same copy with the WRITE of a unit one iteration behind its read (the next unit
+// is requested before this one is stored), as the down-date writes a tile some 10 us after it read it -- does the memory
+// system care how far a tile's write trails its read?
+template <typename T>
+__global__ __launch_bounds__(512) void tile_copy_lag_kernel(T* __restrict__ P, long long total_bytes, T one) {
+    typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
+    const long long nunits = total_bytes >> 16;                       // (whole units only)
+    long long t = blockIdx.x;
+    if (t >= nunits) return;
+    vec_t v[8], w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<vec_t*>(reinterpret_cast<char*>(P) + (t << 16)) + u * 512 + threadIdx.x);
+    for (;;) {
+        const long long tn = t + gridDim.x;
+        const bool more = tn < nunits;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<vec_t*>(reinterpret_cast<char*>(P) + (tn << 16)) + u * 512 + threadIdx.x);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) __builtin_nontemporal_store(v[u] * one, reinterpret_cast<vec_t*>(reinterpret_cast<char*>(P) + (t << 16)) + u * 512 + threadIdx.x);
+        if (!more) return;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = w[u];
+        t = tn;
+    }
+}
+#endif
+
 int launch_copy_floor(slam_ekf* h, int reps, double out[2]) {
     const int n = 3 + 2 * h->N;
     const int tlog = h->dtype == SLAM_F32 ? 7 : 6, E = 1 << tlog;
@@ -1080,6 +1535,12 @@ int launch_copy_floor(slam_ekf* h, int reps, double out[2]) {
     const long long bytes = ntiles * (long long)E * E * (long long)h->esz, units = (bytes + 65535) >> 16;
     auto one_pass = [&](int form) {
         const long long grid = form == 0 ? units : std::min<long long>(units, 2 * h->num_cus);
+#ifdef SLAMHIP_EXPERIMENTS
+        if (h->dtype == SLAM_F32 && slam_exp_env("SLAMHIP_COPY_LAG", 0)) {
+            hipLaunchKernelGGL(tile_copy_lag_kernel<float>, dim3((unsigned)std::min<long long>(units, 2 * h->num_cus)), dim3(512), 0, h->stream, (float*)h->P, bytes, 1.0f);
+            return;
+        }
+#endif
         if (h->dtype == SLAM_F32)
             hipLaunchKernelGGL(tile_copy_floor_kernel<float>, dim3((unsigned)grid), dim3(512), 0, h->stream, (float*)h->P, bytes, 1.0f);
         else
@@ -1183,10 +1644,29 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
                 int wgs = dyn ? per_xcd : (wgs_env > 0 ? wgs_env : L);
                 if (wgs > L) wgs = L;
                 if (wgs < 1) wgs = 1;
+#ifdef SLAMHIP_EXPERIMENTS
+                if (dyn && slam_exp_env("SLAMHIP_HALF", 0)) {      // the half-tile experiment (off-diagonal tiles only: WRONG results)
+                    // SLAMHIP_HALF: 1 = as written (spills 6 registers), 2 = without stores, 3 = the P tile's second row block late
+                    // (SPLITP), 4 = three workgroups per CU (170 registers)
+                    const int hv = slam_exp_env("SLAMHIP_HALF", 0);
+                    const int per = (hv == 4 ? 3 : 4) * h->num_cus / 8;
+                    auto kern = hv == 2 ? downdate_f32_half<true, false, 4> : hv == 3 ? downdate_f32_half<false, true, 4>
+                              : hv == 4 ? downdate_f32_half<false, false, 3> : downdate_f32_half<false, false, 4>;
+                    hipLaunchKernelGGL(kern, dim3(8 * per), dim3(256), 0, h->stream, (float*)h->P, h->ld,
+                                       (const int2*)h->tiles + h->tilesH_off, h->tilesH_len, h->d_status, dcount, kp_total, (const char*)img,
+                                       h->kcap / 16, h->dd_claim, (float*)h->Pside, h->npad / 2);
+                } else
+#endif
                 if (dyn) {                 // (the counters were zeroed by the W1 kernel that wrote the image: ekf_update.hip)
                     hipLaunchKernelGGL((downdate_f32_mfma<false, 4, 3, true>), dim3(8 * wgs), dim3(NTHREADS), 0, h->stream,
                                        (float*)h->P, h->ld, n, (const float*)X, (const float*)Y, pitch, kp_total, lst, L,
-                                       h->d_status, h->xflags << 8, (unsigned long long*)nullptr, dcount, joseph, IMGARGS_CLAIM);
+                                       h->d_status, h->xflags << 8,
+#ifdef SLAMHIP_EXPERIMENTS
+                                       (unsigned long long*)h->dd_prof,
+#else
+                                       (unsigned long long*)nullptr,
+#endif
+                                       dcount, joseph, IMGARGS_CLAIM);
                 } else
                 hipLaunchKernelGGL((downdate_f32_mfma<false, 4, 3, true>), dim3(8 * wgs), dim3(NTHREADS), 0, h->stream,
                                    (float*)h->P, h->ld, n, (const float*)X, (const float*)Y, pitch, kp_total, lst, L,
