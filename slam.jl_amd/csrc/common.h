@@ -59,8 +59,8 @@ static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 // A/B knobs of the measurement tooling (tile order, workgroups per list, super-row height, the scalar factorisation ...):
 // read from the environment ONLY in the experiments build (`make exp`, libslamhip_exp.so); the product library always
 // takes the default, so no untested code path can be switched on from outside.  What the product library does read:
-// SLAMHIP_X bits 8 / 32 / 64 (fp32 matrix cores instead of the split-bf16 down-date; pre-gate never / always) and
-// SLAMHIP_PF_EAGER -- each has a test of its own.
+// SLAMHIP_X bits 8 / 32 / 64 / 512 (fp32 matrix cores instead of the split-bf16 down-date; pre-gate never / always; round 3's
+// register-staged chunk pipeline instead of the LDS-DMA one) and SLAMHIP_PF_EAGER -- each has a test of its own.
 #ifdef SLAMHIP_EXPERIMENTS
 #include <stdlib.h>
 static inline int slam_exp_env(const char* name, int dflt) {
@@ -70,7 +70,7 @@ static inline int slam_exp_env(const char* name, int dflt) {
 constexpr int SLAM_XFLAGS_MASK = ~0;
 #else
 static inline int slam_exp_env(const char*, int dflt) { return dflt; }
-constexpr int SLAM_XFLAGS_MASK = 8 | 32 | 64;
+constexpr int SLAM_XFLAGS_MASK = 8 | 32 | 64 | 512;
 #endif
 
 struct TimingPair {

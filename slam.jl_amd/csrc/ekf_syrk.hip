@@ -753,10 +753,10 @@ __device__ __forceinline__ void mfma_frags_d(const DdFrags& f, f32x16 (&acc)[2])
 }
 
 // PCH (2 <= PCH <= NCH - 2): the step at whose start the P tile is requested
-// ORD2: the step's barrier sits between the fragment reads and the MFMAs (reads -> wait for the next chunk -> barrier -> MFMAs ->
-// request): after the barrier every wave goes into its MFMAs, and the DMA requests and the next step's fragment reads follow as
-// the waves leave the matrix pipe one after the other, instead of eight waves reading 72 KB of fragments at once.
-template <bool DBG, int NCH, int PCH, bool ORD2 = false>
+// Measured and dropped (round 4, one box each, profiles/r04_downdate_dma_experiments.txt): the barrier between the fragment reads
+// and the MFMAs; the second row block's fragment reads behind the first one's MFMAs; a tile's stores behind the next tile's first
+// MFMAs instead of one burst -- all within 1 % of this form.
+template <bool DBG, int NCH, int PCH>
 __device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__ list, int L, int nper, int& slot, char* sm,
                                               unsigned* __restrict__ ctr, int wave, char* cw, unsigned long long* prof = nullptr) {
     static_assert(NCH >= 5 && PCH >= 2 && PCH <= NCH - 2, "");
@@ -792,13 +792,13 @@ __device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__
         static_for<0, NCH>([&](auto CH) {
             constexpr int ch = decltype(CH)::value;
             const int buf = (base + ch) % 3;
-            unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+            [[maybe_unused]] unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
             STAMP(t0);
             if (ch == PCH && !(DBG && (c.dbg & 4))) load_p_mfma(c, tile.x * TILE, tile.y * TILE, pold);
             DdFrags fr;
             read_frags_d(c, sm, buf, fr);
             STAMP(t1);
-            if (!ORD2) mfma_frags_d(fr, acc);
+            mfma_frags_d(fr, acc);
             STAMP(t2);
             if (ch == RD && threadIdx.x == 0) asm_lds_store_u32(cw, claimed);
             // chunk ch + 1 (this tile's, or the next tile's first) has landed when at most these remain outstanding
@@ -819,11 +819,6 @@ __device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__
                 next = fetch(next_slot);
                 next_off = next.x >= 0 && next.x != next.y;
             }
-            unsigned long long t4b = t4;
-            if (ORD2) {
-                mfma_frags_d(fr, acc);
-                STAMP(t4b);
-            }
             if (ch + 3 < NCH) dma_chunk(c, tile, ch + 3, sm, buf, wave);
             else if (next_off) dma_chunk(c, next, ch + 3 - NCH, sm, buf, wave);
             STAMP(t5);
@@ -831,7 +826,7 @@ __device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__
             STAMP(t6);
 #ifdef SLAMHIP_EXPERIMENTS
             if (prof) {
-                ph_lds += t1 - t0; ph_mfma += (t2 - t1) + (t4b - t4); ph_vm[ch < 8 ? ch : 7] += t3 - t2; ph_bar += t4 - t3; ph_issue += t5 - t4b; ph_store += t6 - t5;
+                ph_lds += t1 - t0; ph_mfma += t2 - t1; ph_vm[ch < 8 ? ch : 7] += t3 - t2; ph_bar += t4 - t3; ph_issue += t5 - t4; ph_store += t6 - t5;
                 ++ph_steps;
             }
 #endif
@@ -962,23 +957,19 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
         // the product's launch at 80 <= k <= 128: a persistent grid that CLAIMS its tiles (dd_stream_p<DYN>)
         char* sm = reinterpret_cast<char*>(&smem[0][0][0][0]);
         unsigned* ctr = claim + 16 * xcd;                     // one counter per XCD list, 64 bytes apart
-        if (tile.x != tile.y && (c.xflags & 1024)) {         // SLAMHIP_X bit 1024: the LDS-DMA pipeline with the barrier between reads and MFMAs
-            char* cw = reinterpret_cast<char*>(&dma_claim_word[0]);
-            switch (kp / KB) {
-                case 8: dd_stream_dma<DBG, 8, 2, true>(c, list, L, nper, slot, sm, ctr, wave, cw, prof); break;
-                case 7: dd_stream_dma<DBG, 7, 2, true>(c, list, L, nper, slot, sm, ctr, wave, cw, prof); break;
-                case 6: dd_stream_dma<DBG, 6, 2, true>(c, list, L, nper, slot, sm, ctr, wave, cw, prof); break;
-                default: dd_stream_dma<DBG, 5, 2, true>(c, list, L, nper, slot, sm, ctr, wave, cw, prof); break;
-            }
-        } else
-        if (tile.x != tile.y && (c.xflags & 512)) {          // SLAMHIP_X bit 512: the LDS-DMA pipeline, chunks two steps ahead
+        if (tile.x != tile.y && !(c.xflags & 512)) {         // the LDS-DMA pipeline, chunks two steps ahead (SLAMHIP_X bit 512: round 3's register-staged pipeline below)
             static_assert(sizeof(smem) == 3 * DMA_BUF, "three 24 KB chunk buffers");
+#ifdef SLAMHIP_EXPERIMENTS
+#define DMA_PROF prof
+#else
+#define DMA_PROF nullptr
+#endif
             char* cw = reinterpret_cast<char*>(&dma_claim_word[0]);
             switch (kp / KB) {
-                case 8: dd_stream_dma<DBG, 8, 2>(c, list, L, nper, slot, sm, ctr, wave, cw, prof); break;
-                case 7: dd_stream_dma<DBG, 7, 2>(c, list, L, nper, slot, sm, ctr, wave, cw, prof); break;
-                case 6: dd_stream_dma<DBG, 6, 2>(c, list, L, nper, slot, sm, ctr, wave, cw, prof); break;
-                default: dd_stream_dma<DBG, 5, 2>(c, list, L, nper, slot, sm, ctr, wave, cw, prof); break;
+                case 8: dd_stream_dma<DBG, 8, 2>(c, list, L, nper, slot, sm, ctr, wave, cw, DMA_PROF); break;
+                case 7: dd_stream_dma<DBG, 7, 2>(c, list, L, nper, slot, sm, ctr, wave, cw, DMA_PROF); break;
+                case 6: dd_stream_dma<DBG, 6, 2>(c, list, L, nper, slot, sm, ctr, wave, cw, DMA_PROF); break;
+                default: dd_stream_dma<DBG, 5, 2>(c, list, L, nper, slot, sm, ctr, wave, cw, DMA_PROF); break;
             }
         } else
         if (tile.x != tile.y) {
@@ -1522,6 +1513,35 @@ __global__ __launch_bounds__(512) void tile_copy_lag_kernel(T* __restrict__ P, l
 }
 #endif
 
+#ifdef SLAMHIP_EXPERIMENTS
+// EXPERIMENT (round 4, SLAMHIP_COPY_LAG=2): the copy with the DOWN-DATE'S OWN memory instructions -- every off-diagonal tile read
+// with load_p_mfma (32 dword loads per wave: two 128-byte lines each, the accumulator layout of the 32 x 32 MFMA) and written
+// back with store_p_mfma, by the down-date's grid (512 workgroups of 8 waves walking its per-XCD lists), no panels, no matrix
+// cores: is it the access pattern that keeps the down-date above the plain copy?
+__global__ __launch_bounds__(NTHREADS) void tile_copy_mfma_kernel(float* __restrict__ P, int ld, const int2* __restrict__ tiles, int L,
+                                                                 float* __restrict__ side, int side_n) {
+    DdCtx c;
+    c.P = P; c.ld = ld; c.side = side; c.side_n = side_n;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    c.wr = wave & 1; c.wc = wave >> 1; c.l31 = lane & 31; c.lh = lane >> 5;
+    const int xcd = blockIdx.x & 7, nper = gridDim.x >> 3;
+    const int2* list = tiles + (size_t)xcd * L;
+    for (int sl = blockIdx.x >> 3; sl < L; sl += nper) {
+        const int2 t = list[sl];
+        if (t.x < 0) break;
+        if (t.x == t.y) continue;
+        float pold[2][16];
+        f32x16 acc[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
+        load_p_mfma(c, t.x * TILE, t.y * TILE, pold);
+        store_p_mfma(c, t.x * TILE, t.y * TILE, pold, acc);
+    }
+}
+#endif
+
 int launch_copy_floor(slam_ekf* h, int reps, double out[2]) {
     const int n = 3 + 2 * h->N;
     const int tlog = h->dtype == SLAM_F32 ? 7 : 6, E = 1 << tlog;
@@ -1536,6 +1556,12 @@ int launch_copy_floor(slam_ekf* h, int reps, double out[2]) {
     auto one_pass = [&](int form) {
         const long long grid = form == 0 ? units : std::min<long long>(units, 2 * h->num_cus);
 #ifdef SLAMHIP_EXPERIMENTS
+        if (h->dtype == SLAM_F32 && slam_exp_env("SLAMHIP_COPY_LAG", 0) == 2) {
+            if (ensure_tile_order(h, (int)T) == SLAM_OK)
+                hipLaunchKernelGGL(tile_copy_mfma_kernel, dim3(8 * (2 * h->num_cus / 8)), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld,
+                                   (const int2*)h->tiles + h->tilesB_off, h->tilesB_len, (float*)h->Pside, h->npad / 2);
+            return;
+        }
         if (h->dtype == SLAM_F32 && slam_exp_env("SLAMHIP_COPY_LAG", 0)) {
             hipLaunchKernelGGL(tile_copy_lag_kernel<float>, dim3((unsigned)std::min<long long>(units, 2 * h->num_cus)), dim3(512), 0, h->stream, (float*)h->P, bytes, 1.0f);
             return;

@@ -921,6 +921,35 @@ def test_split_bf16_downdate_against_the_fp32_matrix_cores(pkg, monkeypatch, m):
         assert err["split"][0] <= 1.5 * err["fp32"][0], err                   # max error
 
 
+@pytest.mark.parametrize("m", [40, 48, 56, 64])
+def test_lds_dma_chunk_pipeline_against_the_register_staged_one(pkg, monkeypatch, m):
+    """Round 4: the split-bf16 down-date moves its panel chunks global -> LDS by LDS-DMA, two chunks ahead, with hand-counted
+    waits (csrc/ekf_syrk.hip: dd_stream_dma); SLAMHIP_X=512 keeps round 3's register-staged pipeline (dd_stream_p).  Same
+    fragments, same MFMA order: the two must agree bit for bit, at every chunk count (k = 80, 96, 112, 128), over several steps
+    (a chunk read before it landed would show up as a wrong P)."""
+    rng = np.random.default_rng(300 + m)
+    N = 1500                                             # n = 3003: 24 tile rows, 276 off-diagonal tiles: several per workgroup list
+    x, P = random_state(rng, N, spread=900.0)
+    got = {}
+    for name, flag in (("dma", None), ("staged", "512")):
+        if flag is None:
+            monkeypatch.delenv("SLAMHIP_X", raising=False)
+        else:
+            monkeypatch.setenv("SLAMHIP_X", flag)
+        st = pkg.EKFSlamState(x, P, dtype="f32", max_landmarks=N)
+        r2 = np.random.default_rng(11)
+        for step in range(3):
+            xo, Po = rounded(st)
+            ids = r2.permutation(N)[:m] + 1
+            st.update(noisy_obs(r2, xo, ids), R, ids)
+        got[name] = st.download()
+        st.close()
+    monkeypatch.delenv("SLAMHIP_X", raising=False)
+    assert np.array_equal(got["dma"][0], got["staged"][0])
+    assert np.array_equal(got["dma"][1], got["staged"][1])
+    assert np.array_equal(got["dma"][1], got["dma"][1].T)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_telemetry_ellipses_and_monitor_schema(pkg, dtype):
     """Row N3: feature / vehicle ellipses computed on the device from the 2 x 2 blocks (no download of P) against
