@@ -610,6 +610,9 @@ __device__ __forceinline__ unsigned lds_load_u32(const char* p) { return *(const
 #ifndef DD_PCH0
 #define DD_PCH0 0
 #endif
+#ifndef DD_DMA_PCH8       // (build-time A/B at eight chunks per tile: the LDS-DMA pipeline requests the P tile at the start of this step)
+#define DD_DMA_PCH8 2
+#endif
 #ifndef DD_POFF8          // (build-time A/B at eight chunks per tile: the P tile is requested at chunk 8 - DD_POFF8)
 #define DD_POFF8 (7 + DD_PCH0)
 #endif
@@ -966,7 +969,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
 #endif
             char* cw = reinterpret_cast<char*>(&dma_claim_word[0]);
             switch (kp / KB) {
-                case 8: dd_stream_dma<DBG, 8, 2>(c, list, L, nper, slot, sm, ctr, wave, cw, DMA_PROF); break;
+                case 8: dd_stream_dma<DBG, 8, DD_DMA_PCH8>(c, list, L, nper, slot, sm, ctr, wave, cw, DMA_PROF); break;
                 case 7: dd_stream_dma<DBG, 7, 2>(c, list, L, nper, slot, sm, ctr, wave, cw, DMA_PROF); break;
                 case 6: dd_stream_dma<DBG, 6, 2>(c, list, L, nper, slot, sm, ctr, wave, cw, DMA_PROF); break;
                 default: dd_stream_dma<DBG, 5, 2>(c, list, L, nper, slot, sm, ctr, wave, cw, DMA_PROF); break;
