@@ -797,11 +797,23 @@ __device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__
             const int buf = (base + ch) % 3;
             [[maybe_unused]] unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
             STAMP(t0);
-            if (ch == PCH && !(DBG && (c.dbg & 4))) load_p_mfma(c, tile.x * TILE, tile.y * TILE, pold);
+#ifdef SLAMHIP_EXPERIMENTS
+            // switch-off experiments on THIS pipeline (SLAMHIP_X bits, wrong results except where P stays what it was):
+            // 1024 no MFMAs, 2048 no stores, 4096 no P loads (with 2048 only), 8192 no fragment reads, 16384 no chunk requests
+            const int xo = c.xflags;
+#else
+            constexpr int xo = 0;
+#endif
+            if (ch == PCH && !(DBG && (c.dbg & 4)) && !(xo & 4096)) load_p_mfma(c, tile.x * TILE, tile.y * TILE, pold);
             DdFrags fr;
-            read_frags_d(c, sm, buf, fr);
+            if (!(xo & 8192)) read_frags_d(c, sm, buf, fr);
+            else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { fr.a[i] = fr.b[i] = fr.b1[i] = bf16x8{}; }
+            }
             STAMP(t1);
-            mfma_frags_d(fr, acc);
+            if (!(xo & 1024)) mfma_frags_d(fr, acc);
+            else asm volatile("" ::"v"(fr.a[0]), "v"(fr.a[1]), "v"(fr.a[2]), "v"(fr.b[0]), "v"(fr.b[1]), "v"(fr.b[2]), "v"(fr.b1[0]), "v"(fr.b1[1]), "v"(fr.b1[2]));
             STAMP(t2);
             if (ch == RD && threadIdx.x == 0) asm_lds_store_u32(cw, claimed);
             // chunk ch + 1 (this tile's, or the next tile's first) has landed when at most these remain outstanding
@@ -822,9 +834,21 @@ __device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__
                 next = fetch(next_slot);
                 next_off = next.x >= 0 && next.x != next.y;
             }
-            if (ch + 3 < NCH) dma_chunk(c, tile, ch + 3, sm, buf, wave);
-            else if (next_off) dma_chunk(c, next, ch + 3 - NCH, sm, buf, wave);
+            if (!(xo & 16384)) {
+                if (ch + 3 < NCH) dma_chunk(c, tile, ch + 3, sm, buf, wave);
+                else if (next_off) dma_chunk(c, next, ch + 3 - NCH, sm, buf, wave);
+            }
             STAMP(t5);
+            if (ch == NCH - 1 && (xo & 2048)) {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (!(xo & 4096)) asm volatile("" ::"v"(pold[rb][r] - acc[rb][r]));
+                        else asm volatile("" ::"v"(acc[rb][r]));
+                        acc[rb][r] = 0.0f;
+                    }
+            } else
             if (ch == NCH - 1 && !(DBG && (c.dbg & 1))) store_p_mfma(c, tile.x * TILE, tile.y * TILE, pold, acc);
             STAMP(t6);
 #ifdef SLAMHIP_EXPERIMENTS
@@ -850,6 +874,99 @@ __device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__
 #endif
 #undef STAMP
 }
+
+
+#ifdef SLAMHIP_EXPERIMENTS
+// ---- EXPERIMENT: the same pipeline WITHOUT a barrier per step (round 4; 74 EKF tests green, 0.3409-0.3442 against 0.3392-0.3396 ms) ---------------------------------------------------------------------
+// The switch-off runs on dd_stream_dma (profiles/r04_downdate_dma_experiments.txt) say a workgroup's step is [requests + fragment
+// reads + barrier: ~1250 cycles of latency] + [its MFMAs: 768 cycles per SIMD], one after the other, and the MFMAs' time adds in
+// full.  Part of it is the barrier's place: behind the MFMAs, where the wave of a SIMD that got the matrix pipe first waits 384
+// cycles for its neighbour.  Here the two things the barrier stands for are counted in LDS instead, and a wave ARRIVES before
+// its MFMAs and WAITS after them:
+//   R: "my fragment reads of this step's chunk are done"   -> 8 arrivals free the chunk's buffer for the request three chunks on
+//   L: "my pieces of the NEXT chunk have landed"           -> 8 arrivals make that chunk readable
+// reads(c) -> arrive R -> wait for my pieces of chunk c + 1 -> arrive L -> MFMAs(c) -> wait L, wait R -> request chunk c + 3.
+// By the time a wave has issued its MFMAs the other seven have arrived long ago: the waits cost one LDS read each.
+// The claimed list position travels the same way (written before an arrival, read after the wait).
+__device__ __forceinline__ void lds_arrive(unsigned addr) {
+    if ((threadIdx.x & 63) == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
+}
+__device__ __forceinline__ void lds_wait_ge(unsigned addr, unsigned target) {
+    unsigned v;
+    do {
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    } while ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)v) - target) < 0);
+}
+
+template <bool DBG, int NCH, int PCH>
+__device__ __forceinline__ void dd_stream_dma2(DdCtx& c, const int2* __restrict__ list, int L, int nper, int& slot, char* sm,
+                                               unsigned* __restrict__ ctr, int wave, char* cw) {
+    static_assert(NCH >= 5 && PCH >= 2 && PCH <= NCH - 2, "");
+    constexpr int RD = NCH - 3;        // the step at whose end the next tile's first chunk is requested
+    auto fetch = [&](int sl) { return sl < L ? list[sl] : make_int2(-1, -1); };
+    const unsigned aR = lds_addr(cw) + 4, aL = lds_addr(cw) + 8;
+    int2 tile = fetch(slot);
+    int2 next = make_int2(-1, -1);
+    int next_slot = slot + nper;
+    unsigned claimed = 0;
+    f32x16 acc[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
+    float pold[2][16];
+    dma_chunk(c, tile, 0, sm, 0, wave);
+    dma_chunk(c, tile, 1, sm, 1, wave);
+    dma_chunk(c, tile, 2, sm, 2, wave);
+    if (threadIdx.x == 0) { asm_lds_store_u32(cw + 4, 0u); asm_lds_store_u32(cw + 8, 0u); }
+    wait_vm<6>();
+    bare_barrier();
+    int base = 0;                      // the buffer that holds chunk 0 of the current tile
+    bool first = true;
+    unsigned goal = 0;                 // arrivals expected at the end of the current step: 8 per step
+    for (;;) {
+        bool next_off = false;
+        static_for<0, NCH>([&](auto CH) {
+            constexpr int ch = decltype(CH)::value;
+            const int buf = (base + ch) % 3;
+            goal += NWAVE;
+            if (ch == PCH) load_p_mfma(c, tile.x * TILE, tile.y * TILE, pold);
+            DdFrags fr;
+            read_frags_d(c, sm, buf, fr);
+            lds_arrive(aR);
+            if (ch == RD && threadIdx.x == 0) asm_lds_store_u32(cw, claimed);
+            // my pieces of chunk ch + 1 have landed when at most these remain outstanding (dd_stream_dma's counts)
+            constexpr int PL = (ch == PCH || ch == PCH + 1) ? 32 : 0;
+            if (ch <= 1) {
+                if (first) wait_vm<3>();
+                else wait_vm<35>();
+            } else if (ch + 2 < NCH) wait_vm<3 + PL>();
+            else if (next_off) wait_vm<3 + PL>();
+            else wait_vm<PL>();
+            lds_arrive(aL);
+            mfma_frags_d(fr, acc);
+            if (ch == 0 && threadIdx.x == 0) claimed = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lds_wait_ge(aL, goal);                     // chunk ch + 1 is readable (and, at step RD, the claim word is there)
+            if (ch == RD) {
+                next_slot = nper + __builtin_amdgcn_readfirstlane((int)asm_lds_load_u32(cw));
+                next = fetch(next_slot);
+                next_off = next.x >= 0 && next.x != next.y;
+            }
+            lds_wait_ge(aR, goal);                     // chunk ch's buffer is free
+            if (ch + 3 < NCH) dma_chunk(c, tile, ch + 3, sm, buf, wave);
+            else if (next_off) dma_chunk(c, next, ch + 3 - NCH, sm, buf, wave);
+            if (ch == NCH - 1) store_p_mfma(c, tile.x * TILE, tile.y * TILE, pold, acc);
+        });
+        slot = next_slot;
+        if (!next_off) break;
+        tile = next;
+        base = (base + NCH) % 3;
+        first = false;
+    }
+    wait_vm<0>();
+    bare_barrier();                    // (every wave is out of the counted hand-overs before the LDS array changes hands)
+}
+#endif
 
 // As dd_stream: processes list[slot], list[slot + nper], ... while they are off-diagonal; NCH = kp / 16 (>= 2).  On
 // entry gx/gy hold the request for chunk 0 of the first tile.  On return `slot` is the first unprocessed position;
@@ -960,6 +1077,17 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
         // the product's launch at 80 <= k <= 128: a persistent grid that CLAIMS its tiles (dd_stream_p<DYN>)
         char* sm = reinterpret_cast<char*>(&smem[0][0][0][0]);
         unsigned* ctr = claim + 16 * xcd;                     // one counter per XCD list, 64 bytes apart
+#ifdef SLAMHIP_EXPERIMENTS
+        if (tile.x != tile.y && (c.xflags & 32768)) {        // SLAMHIP_X bit 32768 (experiments build): the LDS-DMA pipeline without a barrier per step
+            char* cw = reinterpret_cast<char*>(&dma_claim_word[0]);
+            switch (kp / KB) {
+                case 8: dd_stream_dma2<DBG, 8, 2>(c, list, L, nper, slot, sm, ctr, wave, cw); break;
+                case 7: dd_stream_dma2<DBG, 7, 2>(c, list, L, nper, slot, sm, ctr, wave, cw); break;
+                case 6: dd_stream_dma2<DBG, 6, 2>(c, list, L, nper, slot, sm, ctr, wave, cw); break;
+                default: dd_stream_dma2<DBG, 5, 2>(c, list, L, nper, slot, sm, ctr, wave, cw); break;
+            }
+        } else
+#endif
         if (tile.x != tile.y && !(c.xflags & 512)) {         // the LDS-DMA pipeline, chunks two steps ahead (SLAMHIP_X bit 512: round 3's register-staged pipeline below)
             static_assert(sizeof(smem) == 3 * DMA_BUF, "three 24 KB chunk buffers");
 #ifdef SLAMHIP_EXPERIMENTS
@@ -985,6 +1113,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
             }
         }
         // what is left for this workgroup: the list's diagonal tiles (fp32 pipeline, 1.3 % of the tiles), claimed one at a time
+#ifdef SLAMHIP_EXPERIMENTS
+        if (c.xflags & (1024 | 2048)) return;                  // (switch-off experiments: P stays what it was, diagonal tiles included)
+#endif
         while (slot < L) {
             tile = list[slot];
             if (tile.x < 0) break;
