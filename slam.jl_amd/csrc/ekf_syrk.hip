@@ -804,6 +804,10 @@ __device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__
 #else
             constexpr int xo = 0;
 #endif
+#ifdef SLAMHIP_EXPERIMENTS
+            if (ch == PCH && (xo & 524288)) load_p_mfma<0>(c, tile.x * TILE, tile.y * TILE, pold);                  // (cache policy of the P loads: default)
+            else
+#endif
             if (ch == PCH && !(DBG && (c.dbg & 4)) && !(xo & 4096)) load_p_mfma(c, tile.x * TILE, tile.y * TILE, pold);
             DdFrags fr;
             if (!(xo & 8192)) read_frags_d(c, sm, buf, fr);
@@ -849,6 +853,12 @@ __device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__
                         acc[rb][r] = 0.0f;
                     }
             } else
+#ifdef SLAMHIP_EXPERIMENTS
+            if (ch == NCH - 1 && (xo & 65536)) store_p_mfma<0>(c, tile.x * TILE, tile.y * TILE, pold, acc);          // (cache policy of the P stores: default)
+            else if (ch == NCH - 1 && (xo & 131072)) store_p_mfma<1>(c, tile.x * TILE, tile.y * TILE, pold, acc);   // (sc0)
+            else if (ch == NCH - 1 && (xo & 262144)) store_p_mfma<3>(c, tile.x * TILE, tile.y * TILE, pold, acc);   // (sc0 nt)
+            else
+#endif
             if (ch == NCH - 1 && !(DBG && (c.dbg & 1))) store_p_mfma(c, tile.x * TILE, tile.y * TILE, pold, acc);
             STAMP(t6);
 #ifdef SLAMHIP_EXPERIMENTS
