@@ -811,10 +811,8 @@ __device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__
             if (ch == PCH && !(DBG && (c.dbg & 4)) && !(xo & 4096)) load_p_mfma(c, tile.x * TILE, tile.y * TILE, pold);
             DdFrags fr;
             if (!(xo & 8192)) read_frags_d(c, sm, buf, fr);
-            else {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) { fr.a[i] = fr.b[i] = fr.b1[i] = bf16x8{}; }
-            }
+            else     // (the registers are taken as they are: no instruction stands in for the reads)
+                asm volatile("" : "=v"(fr.a[0]), "=v"(fr.a[1]), "=v"(fr.a[2]), "=v"(fr.b[0]), "=v"(fr.b[1]), "=v"(fr.b[2]), "=v"(fr.b1[0]), "=v"(fr.b1[1]), "=v"(fr.b1[2]));
             STAMP(t1);
             if (!(xo & 1024)) mfma_frags_d(fr, acc);
             else asm volatile("" ::"v"(fr.a[0]), "v"(fr.a[1]), "v"(fr.a[2]), "v"(fr.b[0]), "v"(fr.b[1]), "v"(fr.b[2]), "v"(fr.b1[0]), "v"(fr.b1[1]), "v"(fr.b1[2]));
