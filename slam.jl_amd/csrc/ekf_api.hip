@@ -204,13 +204,14 @@ extern "C" int slam_ekf_destroy(slam_ekf_t h) {
             for (size_t w = 0; w < 4096; ++w) {
                 if (!v[16 * w]) continue;
                 ++waves;
-                for (int i = 0; i < 14; ++i) s[i] += (double)v[16 * w + i];
+                for (int i = 0; i < 16; ++i) s[i] += (double)v[16 * w + i];
             }
             if (waves) {
                 fprintf(stderr, "[slamhip] dma down-date, mean per wave of %zu waves: steps %.1f  clk per step: reads %.0f  mfma-issue %.0f  barrier %.0f  dma-issue %.0f  stores(per tile) %.0f  chunk-wait by step:",
                         waves, s[0] / waves, s[1] / s[0], s[2] / s[0], s[3] / s[0], s[4] / s[0], s[5] / s[0] * 8);
                 for (int i = 0; i < 8; ++i) fprintf(stderr, " %.0f", s[6 + i] / s[0] * 8);
-                fprintf(stderr, "\n");
+                fprintf(stderr, "  | stream: %.0f shader clocks in %.2f us per wave = %.3f GHz in-kernel clock\n", s[14] / waves, s[15] / waves / 100.0,
+                        s[15] > 0 ? s[14] / s[15] * 0.1 : 0.0);
             }
         }
         dev_free(h->dd_prof);

@@ -767,6 +767,8 @@ __device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__
     // (SLAMHIP_STAMPS=1: where a wave's cycles go -- shader-clock sums over all its steps: fragment reads, MFMA issue, the wait
     //  for the chunk per step of the tile, barrier, DMA issue, stores)
     unsigned long long ph_lds = 0, ph_mfma = 0, ph_bar = 0, ph_issue = 0, ph_store = 0, ph_vm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_steps = 0;
+    // (the in-kernel clock: shader-clock ticks over 100 MHz ticks around the whole stream, MI355X_MICROARCH.md 'DVFS give-back' item 6)
+    const unsigned long long clk0 = prof ? __builtin_amdgcn_s_memtime() : 0, rt0 = prof ? __builtin_amdgcn_s_memrealtime() : 0;
 #define STAMP(var) do { if (prof) { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define STAMP(var) do { } while (0)
@@ -878,6 +880,7 @@ __device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__
         unsigned long long* o = prof + ((size_t)blockIdx.x * NWAVE + wave) * 16;
         o[0] = ph_steps; o[1] = ph_lds; o[2] = ph_mfma; o[3] = ph_bar; o[4] = ph_issue; o[5] = ph_store;
         for (int i = 0; i < 8; ++i) o[6 + i] = ph_vm[i];
+        o[14] = __builtin_amdgcn_s_memtime() - clk0; o[15] = __builtin_amdgcn_s_memrealtime() - rt0;
     }
 #endif
 #undef STAMP
@@ -1760,7 +1763,7 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
     if (h->dtype == SLAM_F32) {
         // persistent: two workgroups per CU (VGPR- and LDS-limited residency), never more than there are tiles
         // persistent: two workgroups per CU (VGPR- and LDS-limited residency), never more than there are tiles
-        int per_xcd = 2 * h->num_cus / 8;
+        int per_xcd = slam_exp_env("SLAMHIP_PER_CU", 2) * h->num_cus / 8;      // (experiments build: 1 = one workgroup per CU)
         if (per_xcd > h->tiles_len) per_xcd = h->tiles_len;
         if (per_xcd < 1) per_xcd = 1;
 #ifdef SLAMHIP_EXPERIMENTS
