@@ -921,15 +921,16 @@ def test_split_bf16_downdate_against_the_fp32_matrix_cores(pkg, monkeypatch, m):
         assert err["split"][0] <= 1.5 * err["fp32"][0], err                   # max error
 
 
-@pytest.mark.parametrize("m", [40, 48, 56, 64])
-def test_lds_dma_chunk_pipeline_against_the_register_staged_one(pkg, monkeypatch, m):
+@pytest.mark.parametrize("m,N", [(40, 1500), (48, 1500), (56, 1500), (64, 1500), (64, 6000), (56, 6000)])
+def test_lds_dma_chunk_pipeline_against_the_register_staged_one(pkg, monkeypatch, m, N):
     """Round 4: the split-bf16 down-date moves its panel chunks global -> LDS by LDS-DMA, two chunks ahead, with hand-counted
     waits (csrc/ekf_syrk.hip: dd_stream_dma); SLAMHIP_X=512 keeps round 3's register-staged pipeline (dd_stream_p).  Same
     fragments, same MFMA order: the two must agree bit for bit, at every chunk count (k = 80, 96, 112, 128), over several steps
     (a chunk read before it landed would show up as a wrong P)."""
     rng = np.random.default_rng(300 + m)
-    N = 1500                                             # n = 3003: 24 tile rows, 276 off-diagonal tiles: several per workgroup list
-    x, P = random_state(rng, N, spread=900.0)
+    # N = 1500: n = 3003, 276 off-diagonal tiles (a workgroup's FIRST tile: the waits' first-tile counts); N = 6000: n = 12003,
+    # 4371 tiles = eight or nine per workgroup (the steady-state counts, with the previous tile's stores in the queue)
+    x, P = random_state(rng, N, spread=900.0 if N < 3000 else 2500.0)
     got = {}
     for name, flag in (("dma", None), ("staged", "512")):
         if flag is None:
@@ -939,7 +940,7 @@ def test_lds_dma_chunk_pipeline_against_the_register_staged_one(pkg, monkeypatch
         st = pkg.EKFSlamState(x, P, dtype="f32", max_landmarks=N)
         r2 = np.random.default_rng(11)
         for step in range(3):
-            xo, Po = rounded(st)
+            xo = st.download("x").astype(np.float64) if N > 3000 else rounded(st)[0]      # (the mean alone at the large size)
             ids = r2.permutation(N)[:m] + 1
             st.update(noisy_obs(r2, xo, ids), R, ids)
         got[name] = st.download()
