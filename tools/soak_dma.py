@@ -6,8 +6,8 @@ bit for bit every time.  A chunk read before it had landed would show up as a di
 import os, sys, math
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import importlib
-pkg = importlib.import_module("slam.jl_amd")
+from __graft_entry__ import load_package  # noqa: E402
+pkg = load_package()
 from oracle import ekf_ref as O        # (test infrastructure: only the observation model, to make plausible observations)
 
 R = np.diag([0.1 ** 2, (math.pi / 180) ** 2])
