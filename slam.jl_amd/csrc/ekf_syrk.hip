@@ -729,6 +729,33 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 __device__ __forceinline__ void bare_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct DdFrags { bf16x8 a[3], b[3], b1[3]; };
+#ifdef SLAMHIP_EXPERIMENTS
+// EXPERIMENT (SLAMHIP_X bit 1048576, timing only, WRONG numbers): the step's matrix work as 24 v_mfma_f32_16x16x32_bf16 on the
+// same fragment registers instead of 12 v_mfma_f32_32x32x16_bf16 -- the same pipe cycles per FLOP; MI355X_MICROARCH.md ('DVFS
+// give-back' item 7) reports a higher clock held on the 16x16x32 shape.  Run with the stores off.
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mfma_frags_16(const DdFrags& f, f32x16 (&acc)[2]) {
+    __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        f32x4m c[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[q] = f32x4m{acc[rb][4 * q], acc[rb][4 * q + 1], acc[rb][4 * q + 2], acc[rb][4 * q + 3]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bf16x8 bb = rb ? f.b1[q % 3] : f.b[q % 3];
+            c[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[0], bb, c[q], 0, 0, 0);
+            c[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[1], bb, c[q], 0, 0, 0);
+            c[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[2], bb, c[q], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[rb][4 * q + r] = c[q][r];
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+#endif
 __device__ __forceinline__ void read_frags_d(const DdCtx& c, const char* sm, int buf, DdFrags& f) {
     const unsigned base = lds_addr(sm) + buf * DMA_BUF + c.l31 * 32 + ((c.lh ^ (c.l31 >> 3)) & 1) * 16;
     const unsigned ya = base + IMG_CHUNK + (32 * c.wc) * 32, xa = base + (64 * c.wr) * 32;
@@ -742,6 +769,23 @@ __device__ __forceinline__ void read_frags_d(const DdCtx& c, const char* sm, int
         : "memory");
 }
 __device__ __forceinline__ void mfma_frags_d(const DdFrags& f, f32x16 (&acc)[2]) {
+#ifdef DD_MFMA_INTERLEAVE     // (build-time A/B: the two row blocks' chains interleaved, no MFMA directly behind the one it depends on)
+    __builtin_amdgcn_s_setprio(3);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1], f.b[1], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1], f.b1[1], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], f.b[2], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], f.b1[2], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[2], f.b[0], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[2], f.b1[0], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], f.b[1], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], f.b1[1], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1], f.b[0], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1], f.b1[0], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], f.b[0], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], f.b1[0], acc[1], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    return;
+#endif
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         __builtin_amdgcn_s_setprio(3);
@@ -816,6 +860,10 @@ __device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__
             else     // (the registers are taken as they are: no instruction stands in for the reads)
                 asm volatile("" : "=v"(fr.a[0]), "=v"(fr.a[1]), "=v"(fr.a[2]), "=v"(fr.b[0]), "=v"(fr.b[1]), "=v"(fr.b[2]), "=v"(fr.b1[0]), "=v"(fr.b1[1]), "=v"(fr.b1[2]));
             STAMP(t1);
+#ifdef SLAMHIP_EXPERIMENTS
+            if (xo & 1048576) mfma_frags_16(fr, acc);
+            else
+#endif
             if (!(xo & 1024)) mfma_frags_d(fr, acc);
             else asm volatile("" ::"v"(fr.a[0]), "v"(fr.a[1]), "v"(fr.a[2]), "v"(fr.b[0]), "v"(fr.b[1]), "v"(fr.b[2]), "v"(fr.b1[0]), "v"(fr.b1[1]), "v"(fr.b1[2]));
             STAMP(t2);
