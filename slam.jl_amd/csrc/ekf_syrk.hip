@@ -891,6 +891,19 @@ __device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__
                 else if (next_off) dma_chunk(c, next, ch + 3 - NCH, sm, buf, wave);
             }
             STAMP(t5);
+#ifdef DD_TIMING_BASE
+            constexpr bool tbase = true;
+#else
+            constexpr bool tbase = false;
+#endif
+            if (ch == NCH - 1 && ((xo & 4194304) || tbase)) {          // (P stored back UNCHANGED, the accumulators consumed: the baseline of the 16x16x32 experiment)
+                f32x16 zero[2];
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { asm volatile("" ::"v"(acc[rb][r])); zero[rb][r] = 0.0f; acc[rb][r] = 0.0f; }
+                store_p_mfma(c, tile.x * TILE, tile.y * TILE, pold, zero);
+            } else
             if (ch == NCH - 1 && (xo & 2048)) {
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
@@ -1027,6 +1040,143 @@ __device__ __forceinline__ void dd_stream_dma2(DdCtx& c, const int2* __restrict_
 }
 #endif
 
+
+#if defined(SLAMHIP_EXPERIMENTS) || defined(DD_TIMING_16)
+// ---- EXPERIMENT (round 4; TIMING ONLY; build with -DDD_TIMING_16 into an otherwise product library, against -DDD_TIMING_BASE: the
+//      experiments build's kernel has grown so large that its own timings are no longer those of the product) --------------------
+//      the pipeline of dd_stream_dma on the 16x16x32 bf16 MFMA shape
+// What a real kernel on that shape would execute per step and tile, with P left as it was (every P element is stored back
+// unchanged, so the filter stays valid and the memory traffic is the real one; the accumulators are computed and thrown away):
+//   * per wave and step 14 fragment reads in two batches (column side: 2 blocks x [h|m], [m|h], [h|l]... three K = 32 variants;
+//     row side: 4 blocks x two variants, two blocks per batch -- 56 fragment registers would not fit beside the accumulators and
+//     the P patch), on the CURRENT image (its half-row swizzle is not conflict-free for this lane pattern: a lower bound),
+//   * 24 v_mfma_f32_16x16x32_bf16, each summing two of the six split products,
+//   * the P patch as 8 dwordx4 loads and 8 dwordx4 stores per wave and tile (16 x 16 block: rows in registers, columns on lanes).
+typedef float f32x4e __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void read6(unsigned a0, unsigned a1, unsigned a2, bf16x8 (&f)[6]) {      // three variants x two blocks (+512 bytes)
+    asm volatile(
+        "ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %8\n\t"
+        "ds_read_b128 %3, %6 offset:512\n\tds_read_b128 %4, %7 offset:512\n\tds_read_b128 %5, %8 offset:512\n\t"
+        : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5])
+        : "v"(a0), "v"(a1), "v"(a2)
+        : "memory");
+}
+__device__ __forceinline__ void read4(unsigned a0, unsigned a1, bf16x8 (&f)[4], bool wait) {           // two variants x two blocks
+    asm volatile(
+        "ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %4 offset:512\n\tds_read_b128 %3, %5 offset:512\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3])
+        : "v"(a0), "v"(a1)
+        : "memory");
+    (void)wait;
+}
+
+template <int NCH, int PCH>
+__device__ __forceinline__ void dd_stream_dma16(DdCtx& c, const int2* __restrict__ list, int L, int nper, int& slot, char* sm,
+                                                unsigned* __restrict__ ctr, int wave, char* cw) {
+    constexpr int RD = NCH - 3;
+    auto fetch = [&](int sl) { return sl < L ? list[sl] : make_int2(-1, -1); };
+    int2 tile = fetch(slot);
+    int2 next = make_int2(-1, -1);
+    int next_slot = slot + nper;
+    unsigned claimed = 0;
+    const int lane = threadIdx.x & 63, r16 = lane & 15, g = lane >> 4;
+    f32x4e acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4e{0.f, 0.f, 0.f, 0.f};
+    f32x4e pold[4][2];
+    // per-lane offsets of the K = 32 variants [s1 | s2]: lane group g reads k-half g & 1 of split (g < 2 ? s1 : s2) of row r16
+    auto var_off = [&](int s1, int s2) { return (unsigned)((g < 2 ? s1 : s2) * IMG_ARR + r16 * 32 + (((g & 1) ^ (r16 >> 3)) & 1) * 16); };
+    const unsigned o_hm = var_off(0, 1), o_mh = var_off(1, 0), o_hl = var_off(0, 2), o_lh = var_off(2, 0);
+    const int pvoff = (r16 * TILE + 4 * g) * 4;
+    dma_chunk(c, tile, 0, sm, 0, wave);
+    dma_chunk(c, tile, 1, sm, 1, wave);
+    dma_chunk(c, tile, 2, sm, 2, wave);
+    wait_vm<6>();
+    bare_barrier();
+    int base = 0;
+    bool first = true;
+    for (;;) {
+        bool next_off = false;
+        static_for<0, NCH>([&](auto CH) {
+            constexpr int ch = decltype(CH)::value;
+            const int buf = (base + ch) % 3;
+            if (ch == PCH) {
+                const auto rs = tile_rsrc(c, tile.x * TILE, tile.y * TILE);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        pold[i][j] = __builtin_bit_cast(f32x4e, __builtin_amdgcn_raw_buffer_load_b128(rs, pvoff, ((32 * c.wc + 16 * j) * TILE + 64 * c.wr + 16 * i) * 4, 2));
+            }
+            const unsigned bb = lds_addr(sm) + buf * DMA_BUF;
+            const unsigned xa = bb + (64 * c.wr) * 32, ya = bb + IMG_CHUNK + (32 * c.wc) * 32;
+            bf16x8 fy[6], fx[4];
+            read6(ya + o_hm, ya + o_lh, ya + o_mh, fy);              // column side: [h|m], [l|h], [m|h] of the two 16-column blocks
+            read4(xa + o_hm, xa + o_hl, fx, true);                   // row side, blocks 0 and 1: [h|m], [h|l]
+            __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[2 * i], fy[3 * j], acc[i][j], 0, 0, 0);          // hh + mm
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[2 * i], fy[3 * j + 2], acc[i][j], 0, 0, 0);      // hm + mh
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[2 * i + 1], fy[3 * j + 1], acc[i][j], 0, 0, 0);  // hl + lh
+                }
+            __builtin_amdgcn_s_setprio(0);
+            read4(xa + 1024 + o_hm, xa + 1024 + o_hl, fx, true);     // row side, blocks 2 and 3
+            __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[2 * i], fy[3 * j], acc[2 + i][j], 0, 0, 0);
+                    acc[2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[2 * i], fy[3 * j + 2], acc[2 + i][j], 0, 0, 0);
+                    acc[2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[2 * i + 1], fy[3 * j + 1], acc[2 + i][j], 0, 0, 0);
+                }
+            __builtin_amdgcn_s_setprio(0);
+            if (ch == RD && threadIdx.x == 0) asm_lds_store_u32(cw, claimed);
+            constexpr int PL = (ch == PCH || ch == PCH + 1) ? 8 : 0;
+            if (ch <= 1) {
+                if (first) wait_vm<3>();
+                else wait_vm<11>();
+            } else if (ch + 2 < NCH) wait_vm<3 + PL>();
+            else if (next_off) wait_vm<3 + PL>();
+            else wait_vm<PL>();
+            bare_barrier();
+            if (ch == 0 && threadIdx.x == 0) claimed = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ch == RD) {
+                next_slot = nper + __builtin_amdgcn_readfirstlane((int)asm_lds_load_u32(cw));
+                next = fetch(next_slot);
+                next_off = next.x >= 0 && next.x != next.y;
+            }
+            if (ch + 3 < NCH) dma_chunk(c, tile, ch + 3, sm, buf, wave);
+            else if (next_off) dma_chunk(c, next, ch + 3 - NCH, sm, buf, wave);
+            if (ch == NCH - 1) {
+                const auto rs = tile_rsrc(c, tile.x * TILE, tile.y * TILE);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        // (P_old goes back as it came; the accumulators are consumed so that their MFMAs stay, and cleared)
+                        asm volatile("" ::"v"(acc[i][j]));
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4b, pold[i][j]), rs, pvoff, ((32 * c.wc + 16 * j) * TILE + 64 * c.wr + 16 * i) * 4, 2);
+                        acc[i][j] = f32x4e{0.f, 0.f, 0.f, 0.f};
+                    }
+            }
+        });
+        slot = next_slot;
+        if (!next_off) break;
+        tile = next;
+        base = (base + NCH) % 3;
+        first = false;
+    }
+    wait_vm<0>();
+}
+#endif
+
 // As dd_stream: processes list[slot], list[slot + nper], ... while they are off-diagonal; NCH = kp / 16 (>= 2).  On
 // entry gx/gy hold the request for chunk 0 of the first tile.  On return `slot` is the first unprocessed position;
 // nothing is in flight for it (the diagonal tiles that follow use the fp32 pipeline and request their own panels).
@@ -1137,6 +1287,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
         char* sm = reinterpret_cast<char*>(&smem[0][0][0][0]);
         unsigned* ctr = claim + 16 * xcd;                     // one counter per XCD list, 64 bytes apart
 #ifdef SLAMHIP_EXPERIMENTS
+        if (tile.x != tile.y && (c.xflags & 2097152) && kp == 8 * KB) {     // the 16x16x32 timing experiment (P unchanged)
+            char* cw = reinterpret_cast<char*>(&dma_claim_word[0]);
+            dd_stream_dma16<8, 2>(c, list, L, nper, slot, sm, ctr, wave, cw);
+            return;                                                          // (diagonal tiles skipped: P stays what it was everywhere)
+        } else
         if (tile.x != tile.y && (c.xflags & 32768)) {        // SLAMHIP_X bit 32768 (experiments build): the LDS-DMA pipeline without a barrier per step
             char* cw = reinterpret_cast<char*>(&dma_claim_word[0]);
             switch (kp / KB) {
@@ -1145,6 +1300,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
                 case 6: dd_stream_dma2<DBG, 6, 2>(c, list, L, nper, slot, sm, ctr, wave, cw); break;
                 default: dd_stream_dma2<DBG, 5, 2>(c, list, L, nper, slot, sm, ctr, wave, cw); break;
             }
+        } else
+#endif
+#ifdef DD_TIMING_16
+        if (tile.x != tile.y && kp == 8 * KB) {
+            char* cw = reinterpret_cast<char*>(&dma_claim_word[0]);
+            dd_stream_dma16<8, 2>(c, list, L, nper, slot, sm, ctr, wave, cw);
+            return;                                            // (diagonal tiles skipped: P stays what it was everywhere)
         } else
 #endif
         if (tile.x != tile.y && !(c.xflags & 512)) {         // the LDS-DMA pipeline, chunks two steps ahead (SLAMHIP_X bit 512: round 3's register-staged pipeline below)
@@ -1172,8 +1334,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
             }
         }
         // what is left for this workgroup: the list's diagonal tiles (fp32 pipeline, 1.3 % of the tiles), claimed one at a time
+#ifdef DD_TIMING_BASE
+        return;
+#endif
 #ifdef SLAMHIP_EXPERIMENTS
-        if (c.xflags & (1024 | 2048)) return;                  // (switch-off experiments: P stays what it was, diagonal tiles included)
+        if (c.xflags & (1024 | 2048 | 4194304)) return;        // (switch-off experiments: P stays what it was, diagonal tiles included)
 #endif
         while (slot < L) {
             tile = list[slot];
