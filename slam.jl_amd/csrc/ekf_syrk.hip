@@ -948,233 +948,8 @@ __device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__
 }
 
 
-#ifdef SLAMHIP_EXPERIMENTS
-// ---- EXPERIMENT: the same pipeline WITHOUT a barrier per step (round 4; 74 EKF tests green, 0.3409-0.3442 against 0.3392-0.3396 ms) ---------------------------------------------------------------------
-// The switch-off runs on dd_stream_dma (profiles/r04_downdate_dma_experiments.txt) say a workgroup's step is [requests + fragment
-// reads + barrier: ~1250 cycles of latency] + [its MFMAs: 768 cycles per SIMD], one after the other, and the MFMAs' time adds in
-// full.  Part of it is the barrier's place: behind the MFMAs, where the wave of a SIMD that got the matrix pipe first waits 384
-// cycles for its neighbour.  Here the two things the barrier stands for are counted in LDS instead, and a wave ARRIVES before
-// its MFMAs and WAITS after them:
-//   R: "my fragment reads of this step's chunk are done"   -> 8 arrivals free the chunk's buffer for the request three chunks on
-//   L: "my pieces of the NEXT chunk have landed"           -> 8 arrivals make that chunk readable
-// reads(c) -> arrive R -> wait for my pieces of chunk c + 1 -> arrive L -> MFMAs(c) -> wait L, wait R -> request chunk c + 3.
-// By the time a wave has issued its MFMAs the other seven have arrived long ago: the waits cost one LDS read each.
-// The claimed list position travels the same way (written before an arrival, read after the wait).
-__device__ __forceinline__ void lds_arrive(unsigned addr) {
-    if ((threadIdx.x & 63) == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
-}
-__device__ __forceinline__ void lds_wait_ge(unsigned addr, unsigned target) {
-    unsigned v;
-    do {
-        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-    } while ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)v) - target) < 0);
-}
-
-template <bool DBG, int NCH, int PCH>
-__device__ __forceinline__ void dd_stream_dma2(DdCtx& c, const int2* __restrict__ list, int L, int nper, int& slot, char* sm,
-                                               unsigned* __restrict__ ctr, int wave, char* cw) {
-    static_assert(NCH >= 5 && PCH >= 2 && PCH <= NCH - 2, "");
-    constexpr int RD = NCH - 3;        // the step at whose end the next tile's first chunk is requested
-    auto fetch = [&](int sl) { return sl < L ? list[sl] : make_int2(-1, -1); };
-    const unsigned aR = lds_addr(cw) + 4, aL = lds_addr(cw) + 8;
-    int2 tile = fetch(slot);
-    int2 next = make_int2(-1, -1);
-    int next_slot = slot + nper;
-    unsigned claimed = 0;
-    f32x16 acc[2];
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
-    float pold[2][16];
-    dma_chunk(c, tile, 0, sm, 0, wave);
-    dma_chunk(c, tile, 1, sm, 1, wave);
-    dma_chunk(c, tile, 2, sm, 2, wave);
-    if (threadIdx.x == 0) { asm_lds_store_u32(cw + 4, 0u); asm_lds_store_u32(cw + 8, 0u); }
-    wait_vm<6>();
-    bare_barrier();
-    int base = 0;                      // the buffer that holds chunk 0 of the current tile
-    bool first = true;
-    unsigned goal = 0;                 // arrivals expected at the end of the current step: 8 per step
-    for (;;) {
-        bool next_off = false;
-        static_for<0, NCH>([&](auto CH) {
-            constexpr int ch = decltype(CH)::value;
-            const int buf = (base + ch) % 3;
-            goal += NWAVE;
-            if (ch == PCH) load_p_mfma(c, tile.x * TILE, tile.y * TILE, pold);
-            DdFrags fr;
-            read_frags_d(c, sm, buf, fr);
-            lds_arrive(aR);
-            if (ch == RD && threadIdx.x == 0) asm_lds_store_u32(cw, claimed);
-            // my pieces of chunk ch + 1 have landed when at most these remain outstanding (dd_stream_dma's counts)
-            constexpr int PL = (ch == PCH || ch == PCH + 1) ? 32 : 0;
-            if (ch <= 1) {
-                if (first) wait_vm<3>();
-                else wait_vm<35>();
-            } else if (ch + 2 < NCH) wait_vm<3 + PL>();
-            else if (next_off) wait_vm<3 + PL>();
-            else wait_vm<PL>();
-            lds_arrive(aL);
-            mfma_frags_d(fr, acc);
-            if (ch == 0 && threadIdx.x == 0) claimed = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            lds_wait_ge(aL, goal);                     // chunk ch + 1 is readable (and, at step RD, the claim word is there)
-            if (ch == RD) {
-                next_slot = nper + __builtin_amdgcn_readfirstlane((int)asm_lds_load_u32(cw));
-                next = fetch(next_slot);
-                next_off = next.x >= 0 && next.x != next.y;
-            }
-            lds_wait_ge(aR, goal);                     // chunk ch's buffer is free
-            if (ch + 3 < NCH) dma_chunk(c, tile, ch + 3, sm, buf, wave);
-            else if (next_off) dma_chunk(c, next, ch + 3 - NCH, sm, buf, wave);
-            if (ch == NCH - 1) store_p_mfma(c, tile.x * TILE, tile.y * TILE, pold, acc);
-        });
-        slot = next_slot;
-        if (!next_off) break;
-        tile = next;
-        base = (base + NCH) % 3;
-        first = false;
-    }
-    wait_vm<0>();
-    bare_barrier();                    // (every wave is out of the counted hand-overs before the LDS array changes hands)
-}
-#endif
-
-
 #if defined(SLAMHIP_EXPERIMENTS) || defined(DD_TIMING_16)
-// ---- EXPERIMENT (round 4; TIMING ONLY; build with -DDD_TIMING_16 into an otherwise product library, against -DDD_TIMING_BASE: the
-//      experiments build's kernel has grown so large that its own timings are no longer those of the product) --------------------
-//      the pipeline of dd_stream_dma on the 16x16x32 bf16 MFMA shape
-// What a real kernel on that shape would execute per step and tile, with P left as it was (every P element is stored back
-// unchanged, so the filter stays valid and the memory traffic is the real one; the accumulators are computed and thrown away):
-//   * per wave and step 14 fragment reads in two batches (column side: 2 blocks x [h|m], [m|h], [h|l]... three K = 32 variants;
-//     row side: 4 blocks x two variants, two blocks per batch -- 56 fragment registers would not fit beside the accumulators and
-//     the P patch), on the CURRENT image (its half-row swizzle is not conflict-free for this lane pattern: a lower bound),
-//   * 24 v_mfma_f32_16x16x32_bf16, each summing two of the six split products,
-//   * the P patch as 8 dwordx4 loads and 8 dwordx4 stores per wave and tile (16 x 16 block: rows in registers, columns on lanes).
-typedef float f32x4e __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void read6(unsigned a0, unsigned a1, unsigned a2, bf16x8 (&f)[6]) {      // three variants x two blocks (+512 bytes)
-    asm volatile(
-        "ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %8\n\t"
-        "ds_read_b128 %3, %6 offset:512\n\tds_read_b128 %4, %7 offset:512\n\tds_read_b128 %5, %8 offset:512\n\t"
-        : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5])
-        : "v"(a0), "v"(a1), "v"(a2)
-        : "memory");
-}
-__device__ __forceinline__ void read4(unsigned a0, unsigned a1, bf16x8 (&f)[4], bool wait) {           // two variants x two blocks
-    asm volatile(
-        "ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %4 offset:512\n\tds_read_b128 %3, %5 offset:512\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3])
-        : "v"(a0), "v"(a1)
-        : "memory");
-    (void)wait;
-}
-
-template <int NCH, int PCH>
-__device__ __forceinline__ void dd_stream_dma16(DdCtx& c, const int2* __restrict__ list, int L, int nper, int& slot, char* sm,
-                                                unsigned* __restrict__ ctr, int wave, char* cw) {
-    constexpr int RD = NCH - 3;
-    auto fetch = [&](int sl) { return sl < L ? list[sl] : make_int2(-1, -1); };
-    int2 tile = fetch(slot);
-    int2 next = make_int2(-1, -1);
-    int next_slot = slot + nper;
-    unsigned claimed = 0;
-    const int lane = threadIdx.x & 63, r16 = lane & 15, g = lane >> 4;
-    f32x4e acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4e{0.f, 0.f, 0.f, 0.f};
-    f32x4e pold[4][2];
-    // per-lane offsets of the K = 32 variants [s1 | s2]: lane group g reads k-half g & 1 of split (g < 2 ? s1 : s2) of row r16
-    auto var_off = [&](int s1, int s2) { return (unsigned)((g < 2 ? s1 : s2) * IMG_ARR + r16 * 32 + (((g & 1) ^ (r16 >> 3)) & 1) * 16); };
-    const unsigned o_hm = var_off(0, 1), o_mh = var_off(1, 0), o_hl = var_off(0, 2), o_lh = var_off(2, 0);
-    const int pvoff = (r16 * TILE + 4 * g) * 4;
-    dma_chunk(c, tile, 0, sm, 0, wave);
-    dma_chunk(c, tile, 1, sm, 1, wave);
-    dma_chunk(c, tile, 2, sm, 2, wave);
-    wait_vm<6>();
-    bare_barrier();
-    int base = 0;
-    bool first = true;
-    for (;;) {
-        bool next_off = false;
-        static_for<0, NCH>([&](auto CH) {
-            constexpr int ch = decltype(CH)::value;
-            const int buf = (base + ch) % 3;
-            if (ch == PCH) {
-                const auto rs = tile_rsrc(c, tile.x * TILE, tile.y * TILE);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        pold[i][j] = __builtin_bit_cast(f32x4e, __builtin_amdgcn_raw_buffer_load_b128(rs, pvoff, ((32 * c.wc + 16 * j) * TILE + 64 * c.wr + 16 * i) * 4, 2));
-            }
-            const unsigned bb = lds_addr(sm) + buf * DMA_BUF;
-            const unsigned xa = bb + (64 * c.wr) * 32, ya = bb + IMG_CHUNK + (32 * c.wc) * 32;
-            bf16x8 fy[6], fx[4];
-            read6(ya + o_hm, ya + o_lh, ya + o_mh, fy);              // column side: [h|m], [l|h], [m|h] of the two 16-column blocks
-            read4(xa + o_hm, xa + o_hl, fx, true);                   // row side, blocks 0 and 1: [h|m], [h|l]
-            __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[2 * i], fy[3 * j], acc[i][j], 0, 0, 0);          // hh + mm
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[2 * i], fy[3 * j + 2], acc[i][j], 0, 0, 0);      // hm + mh
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[2 * i + 1], fy[3 * j + 1], acc[i][j], 0, 0, 0);  // hl + lh
-                }
-            __builtin_amdgcn_s_setprio(0);
-            read4(xa + 1024 + o_hm, xa + 1024 + o_hl, fx, true);     // row side, blocks 2 and 3
-            __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[2 * i], fy[3 * j], acc[2 + i][j], 0, 0, 0);
-                    acc[2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[2 * i], fy[3 * j + 2], acc[2 + i][j], 0, 0, 0);
-                    acc[2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[2 * i + 1], fy[3 * j + 1], acc[2 + i][j], 0, 0, 0);
-                }
-            __builtin_amdgcn_s_setprio(0);
-            if (ch == RD && threadIdx.x == 0) asm_lds_store_u32(cw, claimed);
-            constexpr int PL = (ch == PCH || ch == PCH + 1) ? 8 : 0;
-            if (ch <= 1) {
-                if (first) wait_vm<3>();
-                else wait_vm<11>();
-            } else if (ch + 2 < NCH) wait_vm<3 + PL>();
-            else if (next_off) wait_vm<3 + PL>();
-            else wait_vm<PL>();
-            bare_barrier();
-            if (ch == 0 && threadIdx.x == 0) claimed = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ch == RD) {
-                next_slot = nper + __builtin_amdgcn_readfirstlane((int)asm_lds_load_u32(cw));
-                next = fetch(next_slot);
-                next_off = next.x >= 0 && next.x != next.y;
-            }
-            if (ch + 3 < NCH) dma_chunk(c, tile, ch + 3, sm, buf, wave);
-            else if (next_off) dma_chunk(c, next, ch + 3 - NCH, sm, buf, wave);
-            if (ch == NCH - 1) {
-                const auto rs = tile_rsrc(c, tile.x * TILE, tile.y * TILE);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        // (P_old goes back as it came; the accumulators are consumed so that their MFMAs stay, and cleared)
-                        asm volatile("" ::"v"(acc[i][j]));
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4b, pold[i][j]), rs, pvoff, ((32 * c.wc + 16 * j) * TILE + 64 * c.wr + 16 * i) * 4, 2);
-                        acc[i][j] = f32x4e{0.f, 0.f, 0.f, 0.f};
-                    }
-            }
-        });
-        slot = next_slot;
-        if (!next_off) break;
-        tile = next;
-        base = (base + NCH) % 3;
-        first = false;
-    }
-    wait_vm<0>();
-}
+#include "ekf_syrk_exp_streams.inc"
 #endif
 
 // As dd_stream: processes list[slot], list[slot + nper], ... while they are off-diagonal; NCH = kp / 16 (>= 2).  On
@@ -1420,193 +1195,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
 
 
 #ifdef SLAMHIP_EXPERIMENTS
-// ---- EXPERIMENT (round 4, experiments build only, SLAMHIP_HALF=1; OFF-DIAGONAL TILES ONLY: wrong results) --------------------
-// The switch-off runs of this round say the split-bf16 down-date's phases ADD (panel pipeline 0.166 ms + MFMAs 0.128 + P loads
-// 0.043 + stores 0.08) instead of overlapping: the eight waves of a workgroup move in lockstep from barrier to barrier, and only
-// two workgroups fit a CU.  Here a workgroup is FOUR waves on a 64 x 128 half tile (wave w = column quarter w, both row blocks
-// of the half) -- NOW: a 128 x 64 half, 32 contiguous KB of the column-major tile, wave = (row half, column quarter); the
-// 64 x 128 split measured 0.298 ms without stores but 0.388 with them, against 0.344 / 0.357 of the product kernel --, 36 KB of LDS, so FOUR workgroups with barriers of their own share a CU: twice the phases to interleave, at the
-// price of re-reading the column panel per 64 rows (L2 -> LDS traffic x 1.5).  Timing experiment: what would that buy?
-constexpr int HX = 3 * 64 * 32;             // X part of a chunk: three split arrays of 64 rows x 32 bytes
-constexpr int HCH = HX + IMG_CHUNK;         // one chunk buffer: X (6144 B) then Y (12288 B)
-constexpr int HCLAIM = 2 * HCH;
-
-__device__ __forceinline__ void request_chunk_h(const char* img, int img_nch, int I, int half, int J, int chunk, const int (&voff)[5],
-                                                u32x4b (&g)[5]) {
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(img), (short)0, 0x7fffffff, 0x00020000);
-    // (the HALVED panel is the column panel: a workgroup's 128 x 64 half of a column-major tile is 32 contiguous KB)
-    const int sx = (J * img_nch + chunk) * IMG_CHUNK + half * 2048, sy = (I * img_nch + chunk) * IMG_CHUNK;
-    const int tid = threadIdx.x;
-    // pieces tid + 256 j of the 1152 sixteen-byte pieces [X: 3 x 128 | Y: 768]; voff[j] >= 0: offset inside the X image of the
-    // row block (split array * 4096 + piece), else -(offset inside the Y image) - 1
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        if (j == 4 && tid >= 128) break;
-        const int p = tid + 256 * j;
-        (void)voff;
-        g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, p < 384 ? sx + (p >> 7) * IMG_ARR + (p & 127) * 16 : sy + (p - 384) * 16, 0, 0);
-    }
-}
-
-__device__ __forceinline__ void fill_lds_h(char* sm, int buf, const u32x4b (&g)[5]) {
-    char* base = sm + buf * HCH + threadIdx.x * 16;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        if (j == 4 && threadIdx.x >= 128) break;
-        *reinterpret_cast<u32x4b*>(base + j * 4096) = g[j];
-    }
-}
-
-__device__ __forceinline__ void mfma_chunk_h(const DdCtx& c, const char* sm, int buf, f32x16 (&acc)[2]) {
-    const char* base = sm + buf * HCH + c.l31 * 32 + ((c.lh ^ (c.l31 >> 3)) & 1) * 16;
-    bf16x8 a[3];
-#pragma unroll
-    for (int sp = 0; sp < 3; ++sp) a[sp] = *reinterpret_cast<const bf16x8*>(base + sp * 2048 + (32 * (c.wc & 1)) * 32);
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-        bf16x8 b[3];
-#pragma unroll
-        for (int sp = 0; sp < 3; ++sp) b[sp] = *reinterpret_cast<const bf16x8*>(base + HX + sp * IMG_ARR + (64 * c.wr + 32 * rb) * 32);
-        __builtin_amdgcn_s_setprio(3);
-        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[rb], 0, 0, 0);      // (m, m)
-        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[rb], 0, 0, 0);      // (h, l)
-        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[rb], 0, 0, 0);      // (l, h)
-        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[rb], 0, 0, 0);      // (h, m)
-        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[rb], 0, 0, 0);      // (m, h)
-        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[rb], 0, 0, 0);      // (h, h)
-        __builtin_amdgcn_s_setprio(0);
-    }
-}
-
-// list entries: {I, 2 J + half}, I > J
-// one row block (32 rows x the wave's 32 columns) of the P tile in the MFMA layout: 16 dword loads / stores of two 128-byte lines
-__device__ __forceinline__ void load_p_rb(const DdCtx& c, int R0, int C0, int rb, float (&po)[16]) {
-    const auto rs = tile_rsrc(c, R0, C0);
-    const int voff = (4 * c.lh * TILE + c.l31) * 4;
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-        po[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, ((32 * c.wc + 8 * (r >> 2) + (r & 3)) * TILE + 64 * c.wr + 32 * rb) * 4, 2));
-}
-__device__ __forceinline__ void store_p_rb(const DdCtx& c, int R0, int C0, int rb, const float (&po)[16], f32x16& acc) {
-    const auto rs = tile_rsrc(c, R0, C0);
-    const int voff = (4 * c.lh * TILE + c.l31) * 4;
-    const bool adj = R0 == C0 + TILE;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float v = po[r] - acc[r];
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, ((32 * c.wc + 8 * (r >> 2) + (r & 3)) * TILE + 64 * c.wr + 32 * rb) * 4, 2);
-        if (rb == 0 && r == 15 && adj && c.wr == 0 && c.wc == 3 && c.lh == 1 && c.l31 == 0) c.side[(size_t)c.side_n + ((C0 + TILE - 4) >> 1)] = v;
-        acc[r] = 0.0f;
-    }
-}
-
-// SPLITP: the P tile's second row block is requested only after the tile's last LDS fill, into the registers the panel pieces
-// have just left (the pieces of the next tile's second chunk are then requested after the stores): 16 registers less at the peak
-template <int NCH, bool NOSTORE, bool SPLITP>
-__device__ __forceinline__ void dd_stream_h(DdCtx& c, const int2* __restrict__ list, int L, int nper, int slot, char* sm,
-                                            unsigned* __restrict__ ctr, const int (&voff)[5]) {
-    auto fetch = [&](int sl) { return sl < L ? list[sl] : make_int2(-1, -1); };
-    constexpr int PCH = 1;
-    int2 tile = fetch(slot);
-    if (tile.x < 0) return;
-    const int wq = c.wc;
-    int2 next = make_int2(-1, -1);
-    unsigned claimed = 0;
-    f32x16 acc[2];
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
-    float pold[2][16];
-    u32x4b g[5];
-    request_chunk_h(c.img, c.img_nch, tile.x, tile.y & 1, tile.y >> 1, 0, voff, g);
-    fill_lds_h(sm, 0, g);
-    __syncthreads();
-    request_chunk_h(c.img, c.img_nch, tile.x, tile.y & 1, tile.y >> 1, 1, voff, g);
-    int base = 0;
-    for (;;) {
-        bool next_ok = next.x >= 0;
-        c.wc = 2 * (tile.y & 1) + wq;                       // (uniform: the wave's column quarter of the 128-column tile)
-        const int R0 = tile.x * TILE, C0 = (tile.y >> 1) * TILE;
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            const int pb = (base + ch) & 1;
-            if (ch == PCH) {
-                if (SPLITP) load_p_rb(c, R0, C0, 0, pold[0]);
-                else load_p_mfma(c, R0, C0, pold);
-            }
-            mfma_chunk_h(c, sm, pb, acc);
-            if (ch == 1 && threadIdx.x == 0) lds_store_u32(sm + HCLAIM, claimed);
-            if (ch < NCH - 1) {
-                fill_lds_h(sm, pb ^ 1, g);
-                __syncthreads();
-                if (ch == 0 && threadIdx.x == 0) claimed = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (ch == 1) {
-                    next = fetch(nper + __builtin_amdgcn_readfirstlane((int)lds_load_u32(sm + HCLAIM)));
-                    next_ok = next.x >= 0;
-                }
-                if (ch + 2 < NCH) request_chunk_h(c.img, c.img_nch, tile.x, tile.y & 1, tile.y >> 1, ch + 2, voff, g);
-                else if (next_ok) request_chunk_h(c.img, c.img_nch, next.x, next.y & 1, next.y >> 1, 0, voff, g);
-            } else {
-                if (next_ok) fill_lds_h(sm, pb ^ 1, g);
-                if (SPLITP) load_p_rb(c, R0, C0, 1, pold[1]);
-                __syncthreads();
-                if (!SPLITP && next_ok) request_chunk_h(c.img, c.img_nch, next.x, next.y & 1, next.y >> 1, 1, voff, g);
-                if (!NOSTORE && SPLITP) {
-                    store_p_rb(c, R0, C0, 0, pold[0], acc[0]);
-                    store_p_rb(c, R0, C0, 1, pold[1], acc[1]);
-                } else
-                if (!NOSTORE) store_p_mfma(c, R0, C0, pold, acc);   // (a RUN-time switch here costs 0.09 ms: the two paths' different
-                                                                    //  store counts make the next panel wait a vmcnt(0))
-                else {
-#pragma unroll
-                    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) { asm volatile("" ::"v"(pold[rb][r] - acc[rb][r])); acc[rb][r] = 0.0f; }
-                }
-                if (SPLITP && next_ok) request_chunk_h(c.img, c.img_nch, next.x, next.y & 1, next.y >> 1, 1, voff, g);
-            }
-        }
-        if (!next_ok) return;
-        tile = next;
-        base = (base + NCH) & 1;
-    }
-}
-
-template <bool NOSTORE, bool SPLITP, int WPE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void downdate_f32_half(
-    float* __restrict__ P, int ld, const int2* __restrict__ tiles, int L, const int32_t* __restrict__ status,
-    const int32_t* __restrict__ dcount, int kp, const char* __restrict__ img, int img_nch, unsigned* __restrict__ claim,
-    float* __restrict__ side, int side_n) {
-    if (status[0] != 0) return;
-    if (dcount) {
-        const int k = 2 * dcount[0];
-        kp = (k + 15) / 16 * 16;
-        if (kp == 0) return;
-    }
-    __shared__ __attribute__((aligned(16))) char sm[HCLAIM + 16];
-    const int tid = threadIdx.x, lane = tid & 63;
-    DdCtx c;
-    c.side = side; c.side_n = side_n; c.P = P; c.ld = ld; c.img = img; c.img_nch = img_nch; c.kp = kp; c.dbg = 0; c.xflags = 0;
-    c.wr = __builtin_amdgcn_readfirstlane(tid >> 6) & 1; c.wc = __builtin_amdgcn_readfirstlane(tid >> 6) >> 1;   // wave = (row half, column quarter of the half tile)
-    c.l31 = lane & 31; c.lh = lane >> 5;
-    int voff[5];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int p = tid + 256 * j;
-        voff[j] = p < 384 ? (p >> 7) * IMG_ARR + (p & 127) * 16 : -((p - 384) * 16) - 1;
-    }
-    const int xcd = blockIdx.x & 7, rk = blockIdx.x >> 3, nper = gridDim.x >> 3;
-    const int2* list = tiles + (size_t)xcd * L;
-    unsigned* ctr = claim + 16 * xcd;
-    switch (kp / KB) {
-        case 8: dd_stream_h<8, NOSTORE, SPLITP>(c, list, L, nper, rk, sm, ctr, voff); break;
-        case 7: dd_stream_h<7, NOSTORE, SPLITP>(c, list, L, nper, rk, sm, ctr, voff); break;
-        case 6: dd_stream_h<6, NOSTORE, SPLITP>(c, list, L, nper, rk, sm, ctr, voff); break;
-        case 5: dd_stream_h<5, NOSTORE, SPLITP>(c, list, L, nper, rk, sm, ctr, voff); break;
-        default: break;
-    }
-}
+#include "ekf_syrk_exp_half.inc"
 #endif
 
 // ---- fp64 down-date on the fp64 matrix cores ------------------------------------------
@@ -1842,62 +1431,7 @@ __global__ __launch_bounds__(512) void tile_copy_floor_kernel(T* __restrict__ P,
 
 // out = {milliseconds of the fastest pass, its launch form: 0 = one workgroup per tile / 1 = persistent}.  Synchronises.
 #ifdef SLAMHIP_EXPERIMENTS
-// EXPERIMENT (round 4, SLAMHIP_COPY_LAG=1): the same copy with the WRITE of a unit one iteration behind its read (the next unit
-// is requested before this one is stored), as the down-date writes a tile some 10 us after it read it -- does the memory
-// system care how far a tile's write trails its read?
-template <typename T>
-__global__ __launch_bounds__(512) void tile_copy_lag_kernel(T* __restrict__ P, long long total_bytes, T one) {
-    typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
-    const long long nunits = total_bytes >> 16;                       // (whole units only)
-    long long t = blockIdx.x;
-    if (t >= nunits) return;
-    vec_t v[8], w[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<vec_t*>(reinterpret_cast<char*>(P) + (t << 16)) + u * 512 + threadIdx.x);
-    for (;;) {
-        const long long tn = t + gridDim.x;
-        const bool more = tn < nunits;
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(reinterpret_cast<vec_t*>(reinterpret_cast<char*>(P) + (tn << 16)) + u * 512 + threadIdx.x);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) __builtin_nontemporal_store(v[u] * one, reinterpret_cast<vec_t*>(reinterpret_cast<char*>(P) + (t << 16)) + u * 512 + threadIdx.x);
-        if (!more) return;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = w[u];
-        t = tn;
-    }
-}
-#endif
-
-#ifdef SLAMHIP_EXPERIMENTS
-// EXPERIMENT (round 4, SLAMHIP_COPY_LAG=2): the copy with the DOWN-DATE'S OWN memory instructions -- every off-diagonal tile read
-// with load_p_mfma (32 dword loads per wave: two 128-byte lines each, the accumulator layout of the 32 x 32 MFMA) and written
-// back with store_p_mfma, by the down-date's grid (512 workgroups of 8 waves walking its per-XCD lists), no panels, no matrix
-// cores: is it the access pattern that keeps the down-date above the plain copy?
-__global__ __launch_bounds__(NTHREADS) void tile_copy_mfma_kernel(float* __restrict__ P, int ld, const int2* __restrict__ tiles, int L,
-                                                                 float* __restrict__ side, int side_n) {
-    DdCtx c;
-    c.P = P; c.ld = ld; c.side = side; c.side_n = side_n;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    c.wr = wave & 1; c.wc = wave >> 1; c.l31 = lane & 31; c.lh = lane >> 5;
-    const int xcd = blockIdx.x & 7, nper = gridDim.x >> 3;
-    const int2* list = tiles + (size_t)xcd * L;
-    for (int sl = blockIdx.x >> 3; sl < L; sl += nper) {
-        const int2 t = list[sl];
-        if (t.x < 0) break;
-        if (t.x == t.y) continue;
-        float pold[2][16];
-        f32x16 acc[2];
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
-        load_p_mfma(c, t.x * TILE, t.y * TILE, pold);
-        store_p_mfma(c, t.x * TILE, t.y * TILE, pold, acc);
-    }
-}
+#include "ekf_syrk_exp_copy.inc"
 #endif
 
 int launch_copy_floor(slam_ekf* h, int reps, double out[2]) {
