@@ -1563,6 +1563,11 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
                 if (wgs > L) wgs = L;
                 if (wgs < 1) wgs = 1;
 #ifdef SLAMHIP_EXPERIMENTS
+                if (dyn && slam_exp_env("SLAMHIP_SP", 0)) {        // the software-pipelined one-workgroup-per-CU probe (timing only: P unchanged)
+                    const int per = h->num_cus / 8;
+                    hipLaunchKernelGGL(downdate_f32_sp, dim3(8 * per), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, lst, L, h->d_status,
+                                       dcount, (const char*)img, h->kcap / 16, (float*)h->Pside, h->npad / 2);
+                } else
                 if (dyn && slam_exp_env("SLAMHIP_HALF", 0)) {      // the half-tile experiment (off-diagonal tiles only: WRONG results)
                     // SLAMHIP_HALF: 1 = as written (spills 6 registers), 2 = without stores, 3 = the P tile's second row block late
                     // (SPLITP), 4 = three workgroups per CU (170 registers)
