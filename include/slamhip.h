@@ -343,6 +343,20 @@ int slam_pf_stream(slam_pf_t h, void** stream);
  * skipped steps are enqueued again from the library's log -- and repeats the call. */
 int slam_pf_step_auto(slam_pf_t h, double V, double G, double wheelbase, const double Q[4], double dt, const double* z,
                       const int32_t* ids, int m, const double R[4], double neff_frac, int force, int proposal);
+/* K consecutive slam_pf_step_auto calls in ONE call -- the same filter afterwards, bit for bit.  Step k: control
+ * (VG[2k], VG[2k+1]) = (V, G); its m[k] observations are the (range, bearing) pairs at z + 2 zstride k, their landmark
+ * ids at ids + zstride k (m[k] <= zstride); force[k] as slam_pf_step_auto's force (force == NULL: the Neff rule at every
+ * step).  wheelbase, Q, dt, R, neff_frac, proposal are common to the K steps.
+ * Runs of at least four consecutive steps that CANNOT resample (force[k] == 0) go, where the filter allows it -- fp32, the
+ * whole filter on this shard, proposal = 0, m[k] <= 32, at most 2048 landmarks and 1024 particles per compute unit of the
+ * device -- as persistent launches of up to 16 steps (csrc/pf_batch.hip): poses and weights stay in registers between
+ * the steps, every workgroup reduces the step's statistics itself, the statistics tail of a step runs under the next step's
+ * sweep.  Every other step is enqueued as slam_pf_step_auto enqueues it, as is everything when flags bit 0 is set.
+ * *enqueued (may be NULL): the steps taken -- less than K only together with SLAM_PF_HALTED (sharded halting flow: resolve
+ * the halt, call again with the remaining steps). */
+int slam_pf_step_auto_batch(slam_pf_t h, int K, const double* VG, double wheelbase, const double Q[4], double dt,
+                            const double* z, const int32_t* ids, const int32_t* m, int zstride, const double R[4],
+                            double neff_frac, const int32_t* force, int proposal, int flags, int* enqueued);
 /* Wait for everything queued.  out (may be NULL) = {Neff of the last step, 1 if it resampled, resamplings so far,
  * steps so far}.  (A queued step reports to the host only every eighth step, when it halts or fails; this call asks the
  * device for the last step's outcome.) */

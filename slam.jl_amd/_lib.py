@@ -131,6 +131,8 @@ SIGNATURES = {
     "slam_pf_stream": (C.c_int, [_h, C.POINTER(C.c_void_p)]),
     "slam_pf_step_auto": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, _dp, C.c_double, _dp, _ip, C.c_int, _dp, C.c_double,
                                     C.c_int, C.c_int]),
+    "slam_pf_step_auto_batch": (C.c_int, [_h, C.c_int, _dp, C.c_double, _dp, C.c_double, _dp, _ip, _ip, C.c_int, _dp, C.c_double,
+                                          _ip, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "slam_pf_flush": (C.c_int, [_h, _dp]),
     "slam_pf_halt_info": (C.c_int, [_h, _dp]),
     "slam_pf_resume": (C.c_int, [_h, C.c_int64]),

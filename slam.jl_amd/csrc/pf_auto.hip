@@ -53,42 +53,6 @@ struct PfAutoArgs {
 };
 static_assert(sizeof(PfAutoArgs) <= 4096, "kernel argument segment");
 
-// The planning of pf_stage on the device: observation i of landmark l = ids[i] - 1 gets its code (landmark, first
-// sighting / repeat of a first sighting) and its meta word (where the record is read and written) from the landmark's
-// state word; a repeat inside the call sees the state its first occurrence leaves behind.
-// (l, st: thread i < m holds observation i's landmark and its state word, loaded by the caller ahead of time)
-__device__ __forceinline__ void plan_obs(int l_mine, int32_t st_mine, int m, int32_t* s_l,
-                                         int32_t* s_st, int32_t* s_ids, int32_t* s_meta, int32_t* s_first) {
-    const int tid = threadIdx.x;
-    if (tid < m) {
-        s_l[tid] = l_mine;
-        s_st[tid] = st_mine;
-    }
-    __syncthreads();
-    if (tid < m) {
-        const int l = s_l[tid];
-        int j0 = tid;
-        for (int j = 0; j < tid; ++j)
-            if (s_l[j] == l) { j0 = j; break; }
-        const int32_t st = s_st[tid];
-        const int tab = st & LS_TAB, rb = (st & LS_BUF) ? 1 : 0;
-        const int wb = tab ? (rb ^ 1) : rb;                  // behind a table the update goes to the OTHER buffer
-        const int32_t prior = tab | (rb ? META_RBUF : 0);
-        int32_t code, meta;
-        if (j0 == tid) {
-            code = l | ((st & LS_SEEN) ? 0 : NEW_FLAG);
-            meta = tab | (rb ? META_RBUF : 0) | (wb ? META_WBUF : 0);
-        } else {                                             // the first occurrence has made the landmark (buffer wb, identity)
-            code = l | ((st & LS_SEEN) ? 0 : FRESH_FLAG);
-            meta = (wb ? META_RBUF : 0) | (wb ? META_WBUF : 0);
-        }
-        s_ids[tid] = code;
-        s_meta[tid] = meta | (prior << META_PRIOR_SHIFT);
-        s_first[tid] = j0 == tid;
-    }
-    __syncthreads();
-}
-
 // the first NS of six sums at once: one LDS exchange and one barrier pair for all of them (256 threads); the result reaches every thread
 template <int NS = 6>
 __device__ __forceinline__ void block_reduce6(double (&v)[6], double (*sh6)[6]) {
@@ -106,21 +70,6 @@ __device__ __forceinline__ void block_reduce6(double (&v)[6], double (*sh6)[6]) 
     for (int i = 0; i < NS; ++i) v[i] = sh6[0][i] + sh6[1][i] + sh6[2][i] + sh6[3][i];
 }
 
-
-// One lane writes a step's outcome to the host's mirror (pinned memory).
-__device__ __forceinline__ void pf_publish(PfMirror* mir, double neff, long long nresamples, long long resampled_seq, int error,
-                                           long long halt_seq, long long seq) {
-    __hip_atomic_store(&mir->neff, neff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&mir->nresamples, nresamples, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&mir->resampled_seq, resampled_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (error) __hip_atomic_store(&mir->error, (long long)error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (halt_seq) {
-        __hip_atomic_store(&mir->halt_seq, halt_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __hip_atomic_store(&mir->done_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
 
 // slam_pf_flush's request: the outcome of the LAST completed step, whatever its number.  (After a halt nothing is to be
 // said: the halting step has published itself and the steps behind it were skipped.)
@@ -925,7 +874,7 @@ const char* pf_error_text(long long code) {
 }
 
 // legacy mode -> auto mode: the host's bookkeeping becomes the device's
-static int pf_auto_enter(slam_pf* h) {
+int pf_auto_enter(slam_pf* h) {
     if (h->auto_on) return SLAM_OK;
     std::vector<int32_t> st(h->nl);
     for (int l = 0; l < h->nl; ++l)
@@ -1099,7 +1048,7 @@ static int pf_auto_enqueue(slam_pf* h, const PfStepRec& r) {
 }
 
 // wait (polling the pinned mirror) until step `target` is confirmed or a step has halted
-static int pf_auto_wait(slam_pf* h, long long target) {
+int pf_auto_wait(slam_pf* h, long long target) {
     volatile long long* done = &h->h_mir->done_seq;
     volatile long long* halt = &h->h_mir->halt_seq;
     unsigned long long spins = 0;
@@ -1118,7 +1067,7 @@ static int pf_auto_wait(slam_pf* h, long long target) {
     return SLAM_OK;
 }
 
-static void pf_auto_trim(slam_pf* h) {
+void pf_auto_trim(slam_pf* h) {
     const long long done = h->h_mir->done_seq;
     size_t k = 0;
     while (k < h->log.size() && h->log[k].seq <= done) ++k;
@@ -1136,7 +1085,7 @@ static int pf_auto_replay(slam_pf* h) {
 // A step has halted: its sweep is done, its resampling is not, everything queued behind it was skipped.  Returns
 // SLAM_PF_HALTED when the caller has to resample (sharded filter); a filter that lives on this shard resamples here
 // (the legacy path: lazy if a table is free, else the eager gather) and the skipped steps are enqueued again.
-static int pf_auto_handle_halt(slam_pf* h) {
+int pf_auto_handle_halt(slam_pf* h) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     const long long s = h->h_mir->halt_seq;
     h->h_mir->done_seq = s;                                // (it is: the halting tail publishes both)

@@ -911,4 +911,57 @@ __device__ __forceinline__ bool pf_peer_gone(const PfInbox* inbox, int world) {
 }
 
 
+// ---- the auto mode's step plan and publication (shared by pf_auto.hip and pf_batch.hip) -------------------------------------
+// The planning of pf_stage on the device: observation i of landmark l = ids[i] - 1 gets its code (landmark, first
+// sighting / repeat of a first sighting) and its meta word (where the record is read and written) from the landmark's
+// state word; a repeat inside the call sees the state its first occurrence leaves behind.
+// (l, st: thread i < m holds observation i's landmark and its state word, loaded by the caller ahead of time)
+__device__ __forceinline__ void plan_obs(int l_mine, int32_t st_mine, int m, int32_t* s_l,
+                                         int32_t* s_st, int32_t* s_ids, int32_t* s_meta, int32_t* s_first) {
+    const int tid = threadIdx.x;
+    if (tid < m) {
+        s_l[tid] = l_mine;
+        s_st[tid] = st_mine;
+    }
+    __syncthreads();
+    if (tid < m) {
+        const int l = s_l[tid];
+        int j0 = tid;
+        for (int j = 0; j < tid; ++j)
+            if (s_l[j] == l) { j0 = j; break; }
+        const int32_t st = s_st[tid];
+        const int tab = st & LS_TAB, rb = (st & LS_BUF) ? 1 : 0;
+        const int wb = tab ? (rb ^ 1) : rb;                  // behind a table the update goes to the OTHER buffer
+        const int32_t prior = tab | (rb ? META_RBUF : 0);
+        int32_t code, meta;
+        if (j0 == tid) {
+            code = l | ((st & LS_SEEN) ? 0 : NEW_FLAG);
+            meta = tab | (rb ? META_RBUF : 0) | (wb ? META_WBUF : 0);
+        } else {                                             // the first occurrence has made the landmark (buffer wb, identity)
+            code = l | ((st & LS_SEEN) ? 0 : FRESH_FLAG);
+            meta = (wb ? META_RBUF : 0) | (wb ? META_WBUF : 0);
+        }
+        s_ids[tid] = code;
+        s_meta[tid] = meta | (prior << META_PRIOR_SHIFT);
+        s_first[tid] = j0 == tid;
+    }
+    __syncthreads();
+}
+
+// One lane writes a step's outcome to the host's mirror (pinned memory).
+__device__ __forceinline__ void pf_publish(PfMirror* mir, double neff, long long nresamples, long long resampled_seq, int error,
+                                           long long halt_seq, long long seq) {
+    __hip_atomic_store(&mir->neff, neff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&mir->nresamples, nresamples, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&mir->resampled_seq, resampled_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (error) __hip_atomic_store(&mir->error, (long long)error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (halt_seq) {
+        __hip_atomic_store(&mir->halt_seq, halt_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __hip_atomic_store(&mir->done_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+
 }  // namespace

@@ -191,6 +191,7 @@ struct slam_pf {
     int halted;                  // a sharded filter's step wants a resampling: the caller exchanges, then slam_pf_resume
     double halt_gmax;            // largest normalised log-weight of the halted step
     long long last_resampled_seq;
+    double* d_pb_lines;          // pf_batch.hip: the workgroups' statistics lines of the persistent launch, two parities (allocated at the first one)
 };
 
 // ---- observation codes, per-landmark state words, sizes ------------------------------------------------------------------
@@ -206,7 +207,7 @@ constexpr int META_PRIOR_SHIFT = 10;        // bits 10..18: table + 1 and buffer
 constexpr int PF_OCAP = 1024;               // observations per call; the meta words sit PF_OCAP ints behind the codes
 constexpr int PF_TAB_MAX = 64;              // live ancestor tables before the maps are materialised
 constexpr int PF_AUTO_MAXOBS = 64;          // observations per slam_pf_step_auto call (planned per workgroup in LDS)
-constexpr int PF_LOG = 32;                  // steps the host may run ahead of the device
+constexpr int PF_LOG = 64;                  // steps the host may run ahead of the device (a persistent launch carries up to 16)
 constexpr int PF_PUBLISH_EVERY = 8;         // a step publishes to the host's mirror when its number is a multiple of this
                                             // (or when it halts / fails); slam_pf_flush asks for the last one
 constexpr int32_t LS_TAB = 0xff, LS_BUF = 1 << 8, LS_SEEN = 1 << 9;     // per-landmark state word of the auto mode
@@ -245,6 +246,10 @@ inline bool pf_sharded(const slam_pf* h) { return h->d_peers != nullptr && h->xc
 // pf_auto.hip
 int pf_auto_flush(slam_pf* h);             // wait for the steps slam_pf_step_auto has queued (resolving a halted one)
 int pf_auto_leave(slam_pf* h);             // auto mode -> legacy mode: wait for the queue, bring the bookkeeping back to the host
+int pf_auto_enter(slam_pf* h);             // legacy mode -> auto mode: the host's bookkeeping becomes the device's
+int pf_auto_handle_halt(slam_pf* h);       // a step has halted: resample the legacy way, enqueue the skipped steps again
+void pf_auto_trim(slam_pf* h);             // drop the logged steps the device has confirmed
+int pf_auto_wait(slam_pf* h, long long target);   // poll the mirror until step `target` is confirmed or a step has halted
 const char* pf_error_text(long long code);
 // pf_legacy.hip
 double pf_take_pending(slam_pf* h);        // the normalisation shift slam_pf_normalize deferred (and forget it)

@@ -505,7 +505,7 @@ extern "C" int slam_pf_destroy(slam_pf_t h) {
     }
     if (h->d_lmtab) (void)hipFree(h->d_lmtab);
     void* devs[] = {h->logw2[0], h->logw2[1], h->d_part, h->d_out, h->d_cdf, h->d_bsum, h->d_src, h->d_anc, h->d_tab[0], h->d_tab[1],
-                    h->d_lmeta, h->d_ctl, h->d_lmstate, h->inbox};
+                    h->d_lmeta, h->d_ctl, h->d_lmstate, h->inbox, h->d_pb_lines};
     if (h->xchg_host) (void)hipHostUnregister(h->xchg_host);
     if (h->h_mir) (void)hipHostFree(h->h_mir);
     for (void* p : devs)
@@ -643,6 +643,7 @@ extern "C" int slam_pf_create(slam_pf_t* out, int dtype, int64_t n_local, int64_
     h->d_ctl = nullptr; h->d_lmstate = nullptr; h->h_mir = h->h_mir_dev = nullptr;
     h->auto_on = 0; h->auto_seq = 0; h->pub_seq = 0; h->nresamples = 0; h->halted = 0; h->halt_gmax = 0.0; h->last_resampled_seq = 0;
     h->d_xchg = nullptr; h->xchg_host = nullptr; h->xchg_rank = 0; h->xchg_world = 1;
+    h->d_pb_lines = nullptr;
     for (int i = 0; i < 4; ++i) h->last_out[i] = 0.0;
     const int rc = pf_create_impl(h);
     if (rc) { slam_pf_destroy(h); return rc; }

@@ -221,6 +221,44 @@ class PFShard:
             check(rc)
         return False
 
+    @staticmethod
+    def prepare_batch(controls, obs, force=None):
+        """K steps in the layout slam_pf_step_auto_batch takes, converted once: ``controls`` K x (V, G); ``obs`` K pairs
+        (z 2 x m_k, ids m_k); ``force`` None (the Neff rule at every step), one value for all steps or K values (None / False /
+        True each).  Returns an opaque tuple for ``step_auto_batch``."""
+        K = len(obs)
+        vg = np.ascontiguousarray(np.asarray(controls, dtype=np.float64).reshape(K, 2))
+        ms = np.array([np.asarray(i).reshape(-1).shape[0] for _, i in obs], dtype=np.int32)
+        stride = max(1, int(ms.max()) if K else 1)
+        zz = np.zeros((K, stride, 2))
+        ii = np.zeros((K, stride), dtype=np.int32)
+        for k, (z, ids) in enumerate(obs):
+            if ms[k]:
+                zz[k, :ms[k]] = _obs(z)
+                ii[k, :ms[k]] = np.asarray(ids, dtype=np.int32).reshape(-1)
+        if force is None or isinstance(force, (bool, np.bool_)):
+            force = [force] * K
+        ff = np.array([-1 if f is None else int(bool(f)) for f in force], dtype=np.int32)
+        if ff.shape[0] != K:
+            raise ValueError("force: one value per step")
+        return K, vg, zz, ii, ms, stride, ff
+
+    def step_auto_batch(self, batch, wheelbase, Q, dt, R, neff_frac=0.75, proposal=False, one_by_one=False, start=0):
+        """K filter steps ENQUEUED by one call (slam_pf_step_auto_batch; ``batch`` from prepare_batch): the same filter as
+        K step_auto calls, bit for bit; where the filter allows it up to 16 steps are one persistent launch.  Returns the
+        number of steps taken from ``start`` on: all of them, or fewer when the library reports SLAM_PF_HALTED (sharded
+        halting flow: resolve the halt and call again with ``start`` advanced)."""
+        K, vg, zz, ii, ms, stride, ff = batch
+        pq = Q.ptr if isinstance(Q, _Small) else _ptr(_small(Q))
+        pr = R.ptr if isinstance(R, _Small) else _ptr(_small(R))
+        took = C.c_int(0)
+        rc = lib.slam_pf_step_auto_batch(self._h, K - start, _ptr(vg[start:]), wheelbase, pq, dt, _ptr(zz[start:]),
+                                         _ptr(ii[start:], C.c_int32), _ptr(ms[start:], C.c_int32), stride, pr, neff_frac,
+                                         _ptr(ff[start:], C.c_int32), 1 if proposal else 0, 1 if one_by_one else 0, C.byref(took))
+        if rc and rc != SLAM_PF_HALTED:
+            check(rc)
+        return int(took.value)
+
     def flush(self):
         """Wait for the queued steps: (Neff of the last step, it resampled?, resamplings so far, steps so far), or None
         when the library reports SLAM_PF_HALTED."""
@@ -633,6 +671,19 @@ class FastSLAM:
         while sh.step_auto(V, G, wheelbase, Q, dt, z, ids, R, neff_frac=self.neff_frac, force=force_resample,
                            proposal=proposal, prepared=prepared):
             self._resolve_halt()
+
+    def step_async_batch(self, batch, wheelbase, Q, dt, R, proposal=False, one_by_one=False):
+        """K ``step_async`` calls as one (shard.step_auto_batch, ``batch`` from PFShard.prepare_batch): one persistent launch
+        per up to 16 steps where the filter allows it.  Halts of the sharded halting flow are resolved on the way."""
+        self._gmax_norm = None
+        sh = self.shard
+        k, K = 0, batch[0]
+        while k < K:
+            took = sh.step_auto_batch(batch, wheelbase, Q, dt, R, neff_frac=self.neff_frac, proposal=proposal,
+                                      one_by_one=one_by_one, start=k)
+            k += took
+            if k < K:
+                self._resolve_halt()
 
     def flush(self):
         """Wait for the steps queued by step_async.  Returns (Neff of the last step, it resampled?)."""
