@@ -395,7 +395,7 @@ int slam_pf_attach_exchange(slam_pf_t h, int rank, int world, void* page, size_t
  * reading freed memory -- best effort).
  * Limits of the IPC mappings on ROCm 7.2 (both checked BEFORE anything is opened; slam_pf_attach_peers returns
  * SLAM_E_CAPACITY and the caller keeps the halting flow -- slam.jl_amd/pf.py does that by itself): no exported buffer of a
- * peer in ANOTHER process may exceed 2047 MiB (hipIpcOpenMemHandle of a larger allocation never returns; the landmark records
+ * peer in ANOTHER process may exceed 2047 MiB (a filter with a larger one hung in its attach flow, cause unknown; the landmark records
  * are therefore kept in chunks of at most 1 GiB, so 262144 particles x 512 landmarks per rank attach), and the inbox (the only
  * fine-grained export) must stay within 2 MiB, i.e. n_global <= 32 M particles.
  * slam_pf_comm_info: out = {ranks, 1 if peers are attached, SLAM_PF_HALTED returns so far, resamplings so far}. */

@@ -15,7 +15,7 @@ module SLAMHip
 export SlamState, EKFSlamState, set_state!, predict, update, add_features, associate,
        compute_association, predict_observation, mpi_to_pi,
        ekf_predict!, ekf_update!, augment!, observe!, cov_block, cov_diag, landmark_blocks, gate_mode!, gate_info, state_written!, feature_ellipses, vehicle_ellipse,
-       PFSlamState, set_pose!, init_landmarks!, pf_predict!, update_known!, step!, step_async!, flush!,
+       PFSlamState, set_pose!, init_landmarks!, pf_predict!, update_known!, step!, step_async!, step_async_batch!, flush!,
        resample!, mean_pose, weights, particles, peer_blob, attach_peers!, peer_selftest, detach_peers!, comm_info
 
 const libslamhip = get(ENV, "SLAMHIP_LIB", joinpath(@__DIR__, "libslamhip.so"))
@@ -416,6 +416,33 @@ function step_async!(s::PFSlamState, V::Real, G::Real, wheelbase::Real, Q::Abstr
                  Cdouble, Cint, Cint),
                 s.handle, V, G, wheelbase, colmajor4(Q), dt, pairs64(z), Vector{Int32}(vec(collect(ids))), size(z, 2),
                 colmajor4(R), neff_frac, force, proposal ? 1 : 0))
+    s
+end
+
+"""
+K `step_async!` calls as ONE (slam_pf_step_auto_batch): `controls` is K x 2 (V, G per row), `obs` a vector of K pairs `(z, ids)`
+(z 2 x m_k), `force` a vector of K integers (-1 the Neff rule, 0 never, 1 always).  Runs of at least four consecutive steps that
+cannot resample go as one persistent launch where the filter allows it; the result is the K calls' bit for bit.
+"""
+function step_async_batch!(s::PFSlamState, controls::AbstractMatrix, wheelbase::Real, Q::AbstractMatrix, dt::Real, obs::AbstractVector,
+                           R::AbstractMatrix; neff_frac::Real = 0.75, force::AbstractVector = fill(-1, length(obs)),
+                           proposal::Bool = false, one_by_one::Bool = false)
+    K = length(obs)
+    ms = Int32[size(o[1], 2) for o in obs]
+    stride = max(1, maximum(ms; init = 0))
+    zz = zeros(Float64, 2, stride, K)                 # (range, bearing) pairs, zstride pairs per step
+    ii = zeros(Int32, stride, K)
+    for k in 1:K
+        zz[:, 1:ms[k], k] = obs[k][1]
+        ii[1:ms[k], k] = vec(collect(obs[k][2]))
+    end
+    vg = Matrix{Float64}(transpose(Float64.(controls)))      # 2 x K: (V, G) per step, contiguous
+    took = Ref{Cint}(0)
+    check(ccall((:slam_pf_step_auto_batch, libslamhip), Cint,
+                (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Ptr{Int32}, Ptr{Int32}, Cint, Ptr{Cdouble},
+                 Cdouble, Ptr{Int32}, Cint, Cint, Ref{Cint}),
+                s.handle, K, vg, wheelbase, colmajor4(Q), dt, zz, ii, ms, stride, colmajor4(R), neff_frac,
+                Vector{Int32}(force), proposal ? 1 : 0, one_by_one ? 1 : 0, took))
     s
 end
 

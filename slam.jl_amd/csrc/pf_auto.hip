@@ -85,7 +85,8 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
     // line_level: what a statistics line of this launch is -- 0: the tree's leaf (64 particles, observation-parallel kernel),
     // 1: the 256-particle node (the sweep kernels)
     __shared__ double s_w[4][3];
-    __shared__ double s_pass[16][3];              // the tree nodes above each pass of 1024 lines / records
+    __shared__ double s_pass[PF_AUTO_PASS_MAX][3];        // the tree nodes above each pass of 1024 lines / records (the host refuses
+                                                  // a filter that needs more passes: slam_pf_step_auto, slam_pf_attach_peers)
     __shared__ double s_g[12];
     __shared__ double s_rv[PF_MAX_WORLD][3];      // the ranks' records of the legacy scalar exchange (thread 0)
     __shared__ int s_tref[PF_TAB_MAX];
@@ -189,7 +190,7 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
             }
         } else {
             const WRec pr = wrec_tree256(r, stride, s_w);
-            if (tid == 0 && ps < 16) { s_pass[ps][0] = pr.m; s_pass[ps][1] = pr.s1; s_pass[ps][2] = pr.s2; }
+            if (tid == 0 && ps < PF_AUTO_PASS_MAX) { s_pass[ps][0] = pr.m; s_pass[ps][1] = pr.s1; s_pass[ps][2] = pr.s2; }
         }
     }
     int npass = npass_l;
@@ -218,7 +219,7 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
             WRec q[4];
             collect4(recs, 4, 1024 * ps + 4 * tid, nc_global, xkey, true, q);
             const WRec pr = wrec_tree256(wrec_combine4(q[0], q[1], q[2], q[3]), 1, s_w);
-            if (tid == 0 && ps < 16) { s_pass[ps][0] = pr.m; s_pass[ps][1] = pr.s1; s_pass[ps][2] = pr.s2; }
+            if (tid == 0 && ps < PF_AUTO_PASS_MAX) { s_pass[ps][0] = pr.m; s_pass[ps][1] = pr.s1; s_pass[ps][2] = pr.s2; }
         }
     }
     __syncthreads();
@@ -227,7 +228,7 @@ __device__ __forceinline__ void pf_auto_tail(const PfAutoArgs& a, const int32_t*
         ctl->stamps[2] = wall_clock64();
         // the passes' nodes -> the root, still the radix-4 tree (absent children are the identity), in place in LDS (a register
         // array here would raise the whole step kernel's allocation)
-        int cnt = npass < 16 ? npass : 16;
+        int cnt = npass < PF_AUTO_PASS_MAX ? npass : PF_AUTO_PASS_MAX;
         auto pget = [&](int k) { return k < cnt ? WRec{s_pass[k][0], s_pass[k][1], s_pass[k][2]} : wrec_empty(); };
 #pragma unroll 1
         while (cnt > 1) {
@@ -856,6 +857,15 @@ __global__ __launch_bounds__(256) void pf_auto_resample_kernel(T* pose0, T* pose
 // ---- auto mode: host side -------------------------------------------------------------------------------------------
 static int pf_auto_nb(const slam_pf* h) { return (int)((h->n_global + SCAN_BLOCK - 1) / SCAN_BLOCK); }
 
+// passes of 1024 lines / records the step kernel's tail makes (pf_auto_tail): over this rank's lines (one per 256 particles in the
+// sweep kernels -- the observation-parallel kernel's 64-particle lines only run on small filters) and, with peers, over the
+// ranks' 1024-particle records
+int pf_auto_passes(const slam_pf* h) {
+    const long long lines = (h->n + 255) / 256, recs = pf_sharded(h) ? (h->n_global + 1023) / 1024 + PF_MAX_WORLD : 0;
+    const long long a = (lines + 1023) / 1024, b = (recs + 1023) / 1024;
+    return (int)(a > b ? a : b);
+}
+
 // may a step resample on the device?  The whole filter here, or a sharded one whose peers are attached.
 static bool pf_auto_lazy_ok(const slam_pf* h) {
     if (h->lazy_off || pf_auto_nb(h) > AUTO_NB_MAX) return false;
@@ -1159,6 +1169,12 @@ extern "C" int slam_pf_step_auto(slam_pf_t h, double V, double G, double wheelba
     ARG_CHECK(m == 0 || (z != nullptr && ids != nullptr && R != nullptr), "null argument");
     for (int i = 0; i < m; ++i) ARG_CHECK(ids[i] >= 1 && ids[i] <= h->nl, "landmark id out of range");
     ARG_CHECK(!h->halted, "a halted step is waiting for slam_pf_resume");
+    if (pf_auto_passes(h) > PF_AUTO_PASS_MAX) {
+        slam_set_error("slam_pf_step_auto: the step's statistics hand-over folds at most %d passes of 1024 lines (%lld particles on one rank, "
+                       "%lld over the ranks of a filter with peers); use slam_pf_step / slam_pf_normalize / slam_pf_resample",
+                       PF_AUTO_PASS_MAX, (long long)PF_AUTO_PASS_MAX * 1024 * 256, (long long)PF_AUTO_PASS_MAX * 1024 * 1024);
+        return SLAM_E_CAPACITY;
+    }
     if (proposal) {
         ARG_CHECK(Q[0] > 0.0, "Q is not positive definite");
         const double lq10 = 0.5 * (Q[1] + Q[2]) / sqrt(Q[0]);

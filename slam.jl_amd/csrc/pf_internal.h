@@ -22,8 +22,8 @@ constexpr int PF_CTL_MAXOBS = 64;           // = PF_AUTO_MAXOBS
 constexpr int PF_MAX_WORLD = 8;
 
 // ---- the landmark records: [landmark][5][n] in CHUNKS of whole landmarks ----------------------------------------------------
-// One allocation per chunk of 2^shift landmarks, every chunk below 2 GiB: hipIpcOpenMemHandle of a larger allocation never
-// returns on this runtime (ROCm 7.2, dmabuf IPC), and BASELINE.json's weak-scaling shape (262144 particles x
+// One allocation per chunk of 2^shift landmarks, every chunk below 2 GiB: a sharded filter with a larger exported buffer hung in
+// its attach flow (cause unknown, fenced: pf_peers.hip), and BASELINE.json's weak-scaling shape (262144 particles x
 // 512 landmarks per rank) is 2.5 GiB per buffer.  A filter whose buffer stays below 1 GiB has ONE chunk (every shape of the
 // fixed-size filter from two ranks on).  The table lives in device memory, is written once at create and is read through the
 // constant address space (wave-uniform index: scalar loads).
@@ -208,6 +208,7 @@ constexpr int PF_OCAP = 1024;               // observations per call; the meta w
 constexpr int PF_TAB_MAX = 64;              // live ancestor tables before the maps are materialised
 constexpr int PF_AUTO_MAXOBS = 64;          // observations per slam_pf_step_auto call (planned per workgroup in LDS)
 constexpr int PF_LOG = 64;                  // steps the host may run ahead of the device (a persistent launch carries up to 16)
+constexpr int PF_AUTO_PASS_MAX = 64;          // passes of 1024 statistics lines / records the tail of an auto step folds (16.7 M particles a rank)
 constexpr int PF_PUBLISH_EVERY = 8;         // a step publishes to the host's mirror when its number is a multiple of this
                                             // (or when it halts / fails); slam_pf_flush asks for the last one
 constexpr int32_t LS_TAB = 0xff, LS_BUF = 1 << 8, LS_SEEN = 1 << 9;     // per-landmark state word of the auto mode
@@ -246,6 +247,7 @@ inline bool pf_sharded(const slam_pf* h) { return h->d_peers != nullptr && h->xc
 // pf_auto.hip
 int pf_auto_flush(slam_pf* h);             // wait for the steps slam_pf_step_auto has queued (resolving a halted one)
 int pf_auto_leave(slam_pf* h);             // auto mode -> legacy mode: wait for the queue, bring the bookkeeping back to the host
+int pf_auto_passes(const slam_pf* h);      // passes of the statistics hand-over an auto step of this filter makes (<= PF_AUTO_PASS_MAX)
 int pf_auto_enter(slam_pf* h);             // legacy mode -> auto mode: the host's bookkeeping becomes the device's
 int pf_auto_handle_halt(slam_pf* h);       // a step has halted: resample the legacy way, enqueue the skipped steps again
 void pf_auto_trim(slam_pf* h);             // drop the logged steps the device has confirmed

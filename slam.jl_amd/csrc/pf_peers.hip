@@ -88,8 +88,11 @@ struct PfPeerBlob {
 static_assert(sizeof(PfPeerBlob) <= SLAM_PF_PEER_BLOB_BYTES, "peer blob");
 constexpr uint64_t PF_BLOB_MAGIC = 0x534c414d50465034ull;      // "SLAMPFP4"
 // What an IPC mapping may carry on this runtime (ROCm 7.2, dmabuf IPC; DESIGN section 7 has the records):
-//   * hipIpcOpenMemHandle of an allocation above 2 GiB never returns (1.91 GiB opens in milliseconds, 2.50 GiB hangs both
-//     processes): every exported buffer must stay below PF_IPC_MAX_BYTES -- the landmark records are chunked for that reason;
+//   * a sharded filter whose exported buffers exceeded 2 GiB HUNG in its attach flow (round 3: 1.91 GiB attached in
+//     milliseconds, 2.50 GiB left both processes waiting, tools/ipc_gen_test.py big:*).  The cause is NOT located: opening a
+//     2.5 GiB allocation by itself, alone and pairwise, returns at once (profiles/r04_ipc_open_stack.txt, r04_ipc_pair_probe.txt),
+//     so it is something in the filter's own attach or first step above the 2^31-byte boundary, not the runtime call.  Until
+//     it is found every exported buffer stays below PF_IPC_MAX_BYTES -- the landmark records are chunked for that reason;
 //   * the import of a FINE-GRAINED (hipExtMallocWithFlags) allocation larger than one 2 MiB fragment was seen with only its
 //     first 2 MiB mapped (tools/ipc_probe.hip: page fault at import + 2 MiB in 3 of 7 runs; plain hipMalloc imports of the same
 //     size never): the only fine-grained export is the inbox, which must stay within PF_IPC_FINE_MAX_BYTES.
@@ -179,8 +182,8 @@ extern "C" int slam_pf_attach_peers(slam_pf_t h, int rank, int world, const void
                 const uint64_t n64 = (uint64_t)b.n, esz = (uint64_t)h->esz;
                 const uint64_t largest = std::max<uint64_t>(std::max<uint64_t>(3 * n64 * esz, (uint64_t)PF_TAB_MAX * n64 * 4), b.lm_chunk_bytes);
                 if (largest > PF_IPC_MAX_BYTES) {
-                    slam_set_error("rank %d exports a buffer of %.2f GiB: above the 2 GiB an IPC mapping can carry on this runtime "
-                                   "(use more ranks, or the halting flow)", r, (double)largest / 1073741824.0);
+                    slam_set_error("rank %d exports a buffer of %.2f GiB: a filter with exported buffers above 2 GiB hung in its attach flow "
+                                   "(cause unknown) and is refused (use more ranks, or the halting flow)", r, (double)largest / 1073741824.0);
                     return SLAM_E_CAPACITY;
                 }
                 if (b.inbox_bytes > PF_IPC_FINE_MAX_BYTES) {

@@ -740,12 +740,13 @@ def test_auto_mode_observation_ways_on_256_particle_workgroups(pkg, dtype, n, m)
         g.shard.close()
 
 
-@pytest.mark.parametrize("n", [200, 1024 * 256 + 700])
+@pytest.mark.parametrize("n", [200, 1024 * 256 + 700, 16 * 1024 * 256 + 300])
 def test_auto_mode_grid_sizes_of_the_statistics_hand_over(pkg, n):
     """The step kernel's last workgroup collects one tagged statistics line per workgroup, 1024 lines per pass: a grid of ONE
-    workgroup (it collects its own line) and one of 1027 workgroups (a second pass, a ragged last workgroup) against the
-    synchronous driver -- same particles, same Neff, same resampling steps; legacy calls in between reuse the partials
-    buffer (their lines carry no tag of the next auto step)."""
+    workgroup (it collects its own line), one of 1027 workgroups (a second pass, a ragged last workgroup) and one of 16386 (a
+    SEVENTEENTH pass: round 4's tail kept sixteen pass nodes and dropped the rest without a word; now 64, and the host refuses
+    what lies beyond) against the synchronous driver -- same particles, same Neff, same resampling steps; legacy calls in between
+    reuse the partials buffer (their lines carry no tag of the next auto step)."""
     nl, seed, dtype = 6, 13, "f32"
     lm = scene(nl, 23)
     f = {}
