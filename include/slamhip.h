@@ -107,8 +107,10 @@ int slam_ekf_dtype(slam_ekf_t h, int* dtype);
  * 128 for fp32, 64 for fp64) on and below the diagonal exist, each one contiguous E x E column-major block, the tiles of
  * column band J one after the other (I = J, J+1, ..., T-1), band after band: tile (I, J) is block number
  * J*T - J*(J-1)/2 + (I - J) with T = ld / E (ld is returned for that purpose); element (r, c), r >= c tile-wise, sits at
- * block * E*E + (c % E) * E + (r % E).  Diagonal tiles are complete and symmetric.  slam_ekf_get_state /
- * slam_ekf_get_block return ordinary column-major data. */
+ * block * E*E + (c % E) * E + (r % E).  Diagonal tiles are complete and symmetric: a caller who writes an off-diagonal
+ * entry of a diagonal tile must write BOTH mirrored entries (r, c) and (c, r) -- the kernels read whichever is cheaper, and
+ * slam_ekf_state_written takes a landmark's 2 x 2 block from the entries (f, f), (f + 1, f), (f + 1, f + 1), i.e. the LOWER one.
+ * slam_ekf_get_state / slam_ekf_get_block return ordinary column-major data. */
 int slam_ekf_device_ptrs(slam_ekf_t h, void** d_x, void** d_P, int* ld, void** stream);
 /* The raw views are READ-ONLY as far as the landmarks go -- unless the caller says so afterwards.  The gating
  * (associate / observe, src/data-association.jl:21-63) does not read the landmarks' 2 x 2 covariance blocks from d_P but

@@ -854,6 +854,9 @@ __device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__
             if (ch == PCH && (xo & 524288)) load_p_mfma<0>(c, tile.x * TILE, tile.y * TILE, pold);                  // (cache policy of the P loads: default)
             else
 #endif
+            // (the hand-counted waits below assume the queue order [chunk request][P loads] and [chunk request][P stores]: nothing but
+            //  these scheduling fences keeps the compiler from swapping two builtins that do not depend on each other)
+            __builtin_amdgcn_sched_barrier(0);
             if (ch == PCH && !(DBG && (c.dbg & 4)) && !(xo & 4096)) load_p_mfma(c, tile.x * TILE, tile.y * TILE, pold);
             DdFrags fr;
             if (!(xo & 8192)) read_frags_d(c, sm, buf, fr);
@@ -870,11 +873,15 @@ __device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__
             if (ch == RD && threadIdx.x == 0) asm_lds_store_u32(cw, claimed);
             // chunk ch + 1 (this tile's, or the next tile's first) has landed when at most these remain outstanding
             constexpr int PL = (ch == PCH || ch == PCH + 1) ? 32 : 0;           // the P tile's loads sit behind it
+            // (the timing experiments that switch the P stores / loads off do not issue those 32 operations: the count drops)
+            const bool no_st = (DBG && (c.dbg & 1)) || (xo & 2048), no_ld = (DBG && (c.dbg & 4)) || (xo & 4096);
             if (ch <= 1) {                                                      // ... the previous tile's stores and chunk ch + 2
-                if (first) wait_vm<3>();
+                if (first || no_st) wait_vm<3>();
                 else wait_vm<35>();
-            } else if (ch + 2 < NCH) wait_vm<3 + PL>();
-            else if (next_off) wait_vm<3 + PL>();                               // (chunk ch + 2 is the next tile's)
+            } else if (ch + 2 < NCH || next_off) {                              // (chunk ch + 2 is this tile's or the next tile's)
+                if (no_ld) wait_vm<3>();
+                else wait_vm<3 + PL>();
+            } else if (no_ld) wait_vm<0>();
             else wait_vm<PL>();
             STAMP(t3);
             bare_barrier();
@@ -890,6 +897,7 @@ __device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__
                 if (ch + 3 < NCH) dma_chunk(c, tile, ch + 3, sm, buf, wave);
                 else if (next_off) dma_chunk(c, next, ch + 3 - NCH, sm, buf, wave);
             }
+            __builtin_amdgcn_sched_barrier(0);                                  // (the chunk request stays in front of the tile's stores)
             STAMP(t5);
 #ifdef DD_TIMING_BASE
             constexpr bool tbase = true;

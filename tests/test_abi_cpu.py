@@ -191,3 +191,15 @@ def test_julia_binding_names_exported_symbols_with_the_right_arity(pkg):
                  "slam_pf_resample", "slam_pf_get_mean_pose", "slam_pf_get_weights", "slam_ekf_ellipses", "slam_ekf_get_block",
                  "slam_ekf_observe"):
         assert need in bound, need
+
+
+def test_the_downdates_lds_dma_pipeline_keeps_its_queue_order():
+    """dd_stream_dma's hand-counted s_waitcnt vmcnt(N) hold only while a step's chunk request stands in front of the P
+    tile's loads / stores in the wave's memory queue.  tools/check_downdate_isa.py compiles csrc/ekf_syrk.hip to assembly (the
+    Makefile's flags) and looks at the order in the product kernel; a toolchain or source change that swaps them fails here, not
+    silently on the GPU."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_downdate_isa.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("ok:")
