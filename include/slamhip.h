@@ -218,6 +218,8 @@ int slam_ekf_timing(slam_ekf_t h, int enable);
 int slam_ekf_timing_read(slam_ekf_t h, int kid, double* total_ms, int64_t* launches);
 /* The fastest bracketed launch of kernel `kid` since the last reset, in milliseconds (0: none).  Synchronises. */
 int slam_ekf_timing_min(slam_ekf_t h, int kid, double* min_ms);
+/* out = {bracketed launches, their mean, sample standard deviation and minimum in milliseconds} since the last reset.  Synchronises. */
+int slam_ekf_timing_stats(slam_ekf_t h, int kid, double out[4]);
 int slam_ekf_timing_reset(slam_ekf_t h);
 /* Diagnostics: when enabled the factorisation kernel records 100 MHz wall-clock stamps at its
  * phase boundaries; out8 (may be NULL) receives the stamps of the last update. */

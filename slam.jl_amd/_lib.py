@@ -101,6 +101,7 @@ SIGNATURES = {
     "slam_ekf_timing_read": (C.c_int, [_h, C.c_int, _dp, C.POINTER(C.c_int64)]),
     "slam_ekf_timing_reset": (C.c_int, [_h]),
     "slam_ekf_timing_min": (C.c_int, [_h, C.c_int, _dp]),
+    "slam_ekf_timing_stats": (C.c_int, [_h, C.c_int, _dp]),
     "slam_ekf_debug_stamps": (C.c_int, [_h, C.c_int, C.POINTER(C.c_uint64)]),
     "slam_ekf_state_written": (C.c_int, [_h]),
     "slam_ekf_copy_floor": (C.c_int, [_h, C.c_int, _dp]),

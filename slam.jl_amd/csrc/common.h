@@ -171,6 +171,7 @@ struct slam_ekf {
     std::vector<TimingPair> pairs;
     std::vector<TimingPair> free_pairs;
     double t_ms[SLAM_K_COUNT];
+    double t_sq[SLAM_K_COUNT];    // sum of the squared launch durations (slam_ekf_timing_stats)
     double t_min[SLAM_K_COUNT];   // fastest bracketed launch since the last reset (0: none)
     int64_t t_n[SLAM_K_COUNT];
 };

@@ -98,6 +98,7 @@ static int fold_timing(slam_ekf* h) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             h->t_ms[p.kid] += ms;
+            h->t_sq[p.kid] += (double)ms * (double)ms;
             if (h->t_min[p.kid] == 0.0 || ms < h->t_min[p.kid]) h->t_min[p.kid] = ms;
             h->t_n[p.kid] += 1;
         }
@@ -343,7 +344,7 @@ extern "C" int slam_ekf_create(slam_ekf_t* out, int dtype, int max_landmarks, in
     if (getenv("SLAMHIP_FACTOR") && !strcmp(getenv("SLAMHIP_FACTOR"), "pivot1")) h->factor_blocked = 2;     // round 3's one pivot per MFMA
 #endif
     h->timing = 0;
-    for (int i = 0; i < SLAM_K_COUNT; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; h->t_min[i] = 0; }
+    for (int i = 0; i < SLAM_K_COUNT; ++i) { h->t_ms[i] = 0; h->t_sq[i] = 0; h->t_n[i] = 0; h->t_min[i] = 0; }
     const int rc = create_impl(h);
     if (rc != SLAM_OK) {
         slam_ekf_destroy(h);
@@ -884,11 +885,24 @@ extern "C" int slam_ekf_timing_min(slam_ekf_t h, int kid, double* min_ms) {
     return SLAM_OK;
 }
 
+extern "C" int slam_ekf_timing_stats(slam_ekf_t h, int kid, double out[4]) {
+    ARG_CHECK(h != nullptr && out != nullptr, "null argument");
+    ARG_CHECK(kid >= 0 && kid < SLAM_K_COUNT, "kernel id out of range");
+    HIP_TRY(hipSetDevice(h->device));
+    const int rc = fold_timing(h);
+    if (rc) return rc;
+    const double nn = (double)h->t_n[kid];
+    const double mean = nn > 0 ? h->t_ms[kid] / nn : 0.0;
+    const double var = nn > 1 ? (h->t_sq[kid] - nn * mean * mean) / (nn - 1.0) : 0.0;
+    out[0] = nn; out[1] = mean; out[2] = var > 0 ? sqrt(var) : 0.0; out[3] = h->t_min[kid];
+    return SLAM_OK;
+}
+
 extern "C" int slam_ekf_timing_reset(slam_ekf_t h) {
     ARG_CHECK(h != nullptr, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     const int rc = fold_timing(h);
     if (rc) return rc;
-    for (int i = 0; i < SLAM_K_COUNT; ++i) { h->t_ms[i] = 0; h->t_n[i] = 0; h->t_min[i] = 0; }
+    for (int i = 0; i < SLAM_K_COUNT; ++i) { h->t_ms[i] = 0; h->t_sq[i] = 0; h->t_n[i] = 0; h->t_min[i] = 0; }
     return SLAM_OK;
 }

@@ -420,6 +420,12 @@ class EKFSlamState(SlamState):
         check(lib.slam_ekf_timing_min(self._h, _lib.KERNEL_IDS[kernel], C.byref(ms)))
         return ms.value
 
+    def timing_stats(self, kernel):
+        """(launches, mean_ms, stdev_ms, min_ms) of the bracketed launches of `kernel` since the last reset."""
+        out = np.zeros(4)
+        check(lib.slam_ekf_timing_stats(self._h, _lib.KERNEL_IDS[kernel], _ptr(out)))
+        return int(out[0]), float(out[1]), float(out[2]), float(out[3])
+
 
 # ---- the reference's function surface ---------------------------------------------------
 

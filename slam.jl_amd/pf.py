@@ -749,7 +749,11 @@ class PFSlamState(FastSLAM):
     arguments and owns n / world of them on its own GPU.
     """
 
-    def __init__(self, n, max_landmarks, seed=0, dtype="f32", device=0, neff_frac=0.75, distributed=None):
+    def __init__(self, n, max_landmarks, seed=0, dtype="f32", device=0, neff_frac=0.75, distributed=None, peers=None):
+        """``peers`` (sharded filter): None = the device-side exchange where it can be had (one node, at most 8 ranks, the
+        self-test passes; SLAMHIP_PF_PEERS=0 says no), False = the halting flow through ``torch.distributed`` (RCCL on the
+        GPUs) whatever the node could do.  ``self.peers`` says which one runs, ``self.selftest_ok`` what the self-test of
+        the GPUs' view of each other's inboxes said (None: not tried)."""
         import torch.distributed as dist
         use_dist = dist.is_available() and dist.is_initialized() if distributed is None else distributed
         if use_dist:
@@ -766,6 +770,8 @@ class PFSlamState(FastSLAM):
             shard = PFShard(per, max_landmarks, seed, dtype=dtype, first=rank * per, n_global=n, device=device)
             comm = TorchComm(torch.device("cuda", int(device)))
             self.peers = False
+            self.selftest_ok = None
+            want_peers = (os.environ.get("SLAMHIP_PF_PEERS", "1") != "0") if peers is None else bool(peers)
             if world > 1:
                 # the ranks' GPUs address each other's buffers (IPC handles, moved here by an object all-gather): the
                 # per-step scalars travel GPU to GPU and a resampling step stays on the device.  SLAMHIP_PF_PEERS=0, more
@@ -778,7 +784,7 @@ class PFSlamState(FastSLAM):
                 dist.all_gather_object(blobs, (socket_host(), mine))
                 say("blobs gathered")
                 one_node = len({h for h, _ in blobs}) == 1
-                if one_node and world <= 8 and os.environ.get("SLAMHIP_PF_PEERS", "1") != "0":
+                if one_node and world <= 8 and want_peers:
                     # attach, then prove that the GPUs see each other's inbox writes; any rank failing either step sends
                     # every rank to the fallback (the decision must be the same everywhere)
                     # one rank at a time (a precaution: with dmabuf IPC the importer asks the EXPORTER's process for the
@@ -801,6 +807,7 @@ class PFSlamState(FastSLAM):
                     say(f"self-test {ok}")
                     oks = [None] * world
                     dist.all_gather_object(oks, bool(ok))
+                    self.selftest_ok = bool(all(oks))
                     if all(oks):
                         self.peers = True
                     else:
@@ -813,6 +820,8 @@ class PFSlamState(FastSLAM):
         else:
             shard = PFShard(n, max_landmarks, seed, dtype=dtype, device=device)
             comm = None
+            self.peers = False
+            self.selftest_ok = None
         super().__init__(shard, comm, neff_frac)
         self.n = n
 

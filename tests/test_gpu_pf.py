@@ -1126,3 +1126,35 @@ def test_rccl_collectives_of_the_sharded_flow_on_a_one_rank_group(pkg, tmp_path)
     assert int(a["resamples"]) == int(s["resamples"]) >= 3
     assert np.array_equal(a["pose"], s["pose"]) and np.array_equal(a["lm"], s["lm"])
     assert np.allclose(a["logw"], s["logw"], rtol=0, atol=1e-12)
+
+
+def test_bench_fastslam_leg_with_two_ranks_on_one_card():
+    """exactly the path `bench.py --gpus N` takes on a multi-GPU node, rehearsed with two processes on ONE card
+    (SLAM_BENCH_REHEARSE: gloo as the control plane, both ranks on device 0, a smaller filter): the sharded filter is checked
+    against a one-rank filter before anything is timed (comm.parity_vs_one_rank, for the device-side exchange bit for bit and for
+    the halting flow over the collectives), the self-test of the peers is reported, and BOTH exchange paths are timed in the
+    same run (regimes_peers, regimes_rccl)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SLAM_BENCH_REHEARSE="1", SLAM_BENCH_NP="65536", HSA_ENABLE_IPC_MODE_LEGACY="0", SLAM_BENCH_PF_BUDGET_S="400")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-pmc",
+                        "--no-configs", "--landmarks", "1000", "--obs", "16", "--prewarm-ms", "10"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    f = line["fastslam"]
+    assert "error" not in f, f
+    c = f["comm"]
+    par = c["parity_vs_one_rank"]
+    assert par["peers"]["available"] and par["peers"]["ok"] and par["peers"]["poses_equal"] and par["peers"]["logw_max_ulp"] == 0.0, par
+    assert par["rccl"]["ok"] and par["rccl"]["poses_equal"] and par["rccl"]["logw_max_ulp"] <= 4.0, par
+    assert par["peers"]["resamples"][0] == par["peers"]["resamples"][1] >= 1
+    assert c["selftest_ok"] is True and c["peers_attached"] is True and c["timed_paths"] == ["peers", "rccl"]
+    for key in ("regimes_peers", "regimes_rccl"):
+        assert {"no_resample", "every_step", "neff_triggered"} <= set(f[key]), f[key]
+        assert all(v["ms_per_step"] > 0 for v in f[key].values())
+    assert f["comm_rccl"]["peers_attached"] is False and f["comm_rccl"]["halts"] >= 1      # (the halting flow halted: it ran)
+    assert f["regimes"] == f["regimes_peers"] and f["weak_scaling"]["peers_attached"] is True

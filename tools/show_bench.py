@@ -6,7 +6,7 @@ for l in open(sys.argv[1]):
         j = json.loads(l)
         print("value", round(j["value"]), j["unit"][:12], "| ms/step", round(j["ms_per_step"], 4), "| n_gpus", j["n_gpus"])
         r = j["roofline"]
-        print("roofline", {k: r.get(k) for k in ("bound", "achieved", "peak", "frac", "traffic", "avg_launch_ms")})
+        print("roofline", {k: r.get(k) for k in ("bound", "achieved", "peak", "frac", "traffic", "avg_launch_ms", "stdev_ms", "launches", "avg_launch_ms_timed_region", "copy_floor_ms", "kernel_over_floor")})
         print(" ", j.get("traffic_note"))
         print("kernels", {k: round(v * 1e3, 1) for k, v in j["kernel_ms_per_step"].items()})
         if "other_kernels" in j:
