@@ -146,107 +146,6 @@ __device__ inline PreGate pre_gate(double dx, double dy, const double* pvv, doub
     return g;
 }
 
-// The observations of one launch travel IN the kernel arguments (2 KB of the 4 KB a launch may carry): every workgroup
-// needs all of them at its start, and reading them from the pinned host page the caller's z was staged in meant a few
-// thousand 64-byte reads across PCIe per sweep, on the critical path of a 9 us kernel.  First parameter: the kernel
-// indexes the argument segment itself (a dynamic index into the by-value copy would move the struct to scratch).
-constexpr int GATE_CHUNK = 128;        // observations per launch
-struct GateObs {
-    double z[2 * GATE_CHUNK];
-};
-
-template <typename T>
-__global__ __launch_bounds__(GATE_BLOCK * OBS_WAVES) void gate_kernel(GateObs zarg, const T* __restrict__ x, const T* __restrict__ P,
-                                                           int ld, int N, double* __restrict__ zdev, int nz, double R0,
-                                                           double R1, double R2, double R3, double gate1, double gate2,
-                                                           double* __restrict__ part, const double* __restrict__ pmax_ptr,
-                                                           int pregate, int tlog, const T* __restrict__ side, int side_n) {
-    extern __shared__ double smem[];
-    double* zs = smem;                 // [nz][2]
-    double* red = smem + 2 * nz;       // [nz][3]
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    constexpr int NT = GATE_BLOCK * OBS_WAVES;
-    typedef const __attribute__((address_space(4))) GateObs* KargPtr;
-    const KargPtr ka = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    for (int i = tid; i < 2 * nz; i += NT) {
-        const double v = ka->z[i];
-        zs[i] = v;
-        if (blockIdx.x == 0) zdev[i] = v;            // the device copy the compaction, the update and add_features read
-    }
-
-    const double R[4] = {R0, R1, R2, R3};
-    double pose[3] = {(double)x[0], (double)x[1], (double)x[2]};
-    double pvv[9];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) pvv[r * 3 + c] = (double)P[p_off(ld, tlog, r, c)];
-
-    // the landmark constants are evaluated by every wave (cheaper than a hand-over through LDS: ~200 flops)
-    const int j0 = blockIdx.x * GATE_BLOCK + lane;
-    bool valid = j0 < N;
-    const double INF = __builtin_inf();
-    if (pregate) {
-        // N2: which of this wave's landmarks are within reach of ANY of this wave's observations?  Needs the landmark's
-        // mean only; the others are provably outside both gates for every one of them and skip the covariance loads.
-        __syncthreads();                                        // the observations are in LDS
-        bool need = false;
-        if (valid) {
-            const int f = 3 + 2 * j0;
-            const double dx = (double)x[f] - pose[0], dy = (double)x[f + 1] - pose[1];
-            const PreGate g = pre_gate(dx, dy, pvv, *pmax_ptr, R, gate2);
-            const double zp0 = sqrt(dx * dx + dy * dy), zp1 = atan2(dy, dx) - pose[2];
-            for (int i = wave; i < nz; i += OBS_WAVES) {
-                const double v0 = zs[2 * i] - zp0, v1 = mpi_to_pi_d(zs[2 * i + 1] - zp1);
-                if (!(v0 * v0 > g.b0) && !(v1 * v1 > g.b1)) need = true;
-            }
-        }
-        valid = need;
-    }
-    PairConst pc;
-    if (valid) pc = landmark_const(x, P, ld, tlog, j0, pose, pvv, R, side, side_n);
-    // per-observation result of this wave, default "nothing in either gate"
-    for (int i = tid; i < nz; i += NT) {
-        red[3 * i] = INF;
-        red[3 * i + 1] = (double)0x7fffffff;
-        red[3 * i + 2] = 0.0;
-    }
-    __syncthreads();
-
-    // Almost every (observation, landmark) pair is far outside both gates: the common path is a
-    // 2-vector innovation, a 2x2 quadratic form and two ballots, with no LDS traffic at all.
-    for (int i = wave; i < nz; i += OBS_WAVES) {
-        double nis = INF, nd = INF;
-        if (valid) pair_eval(pc, zs[2 * i], zs[2 * i + 1], nis, nd);
-        const bool cand = valid && (nis < gate1) && (nd < INF);
-        const bool near = valid && (nis <= gate2);
-        const unsigned long long cand_mask = __ballot(cand);
-        const unsigned long long near_mask = __ballot(near);
-        if ((cand_mask | near_mask) != 0ull) {       // wave-uniform, rare
-            double nd_c = INF;
-            int j_c = 0x7fffffff;
-            if (cand_mask != 0ull) {
-                if (cand) { nd_c = nd; j_c = j0 + 1; }
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) {
-                    const double o_nd = __shfl_xor(nd_c, off);
-                    const int o_j = __shfl_xor(j_c, off);
-                    if (o_nd < nd_c || (o_nd == nd_c && o_j < j_c)) { nd_c = o_nd; j_c = o_j; }
-                }
-            }
-            if (lane == 0) {
-                red[3 * i] = nd_c;
-                red[3 * i + 1] = (double)j_c;
-                red[3 * i + 2] = 1.0;                // near_mask != 0 or a candidate (which is also near-or-matched)
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < 3 * nz; i += NT) part[(size_t)blockIdx.x * 3 * nz + i] = red[i];
-}
-
 // observe(): turn the association vector into the update's and add_features' inputs without leaving the device.
 // One wave walks the observations in order, 64 at a time: matched ones (assoc >= 1) are compacted to the front
 // of zbuf/idf (zsrc may BE zbuf: a write position never passes the read position of a later chunk), new ones
@@ -303,49 +202,149 @@ __device__ __forceinline__ void compact_wave(const int32_t* assoc, int nz, const
     if (lane == 0) __hip_atomic_store(flag_host, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// One wave per observation folds the per-workgroup partials into assoc[i].  With `compact_total` > 0 (observe(),
-// last chunk) the LAST workgroup to finish -- an arrival counter in device memory -- then turns
-// assoc[0 .. compact_total) into the update's inputs: no extra launch, and the fold stays nz-way parallel.
-__global__ __launch_bounds__(64) void gate_final_kernel(
-    const double* __restrict__ part, int nblocks, int nz, int32_t* assoc, int32_t* assoc_all,     // (the two alias)
-    int compact_total, const double* zsrc, double* zbuf, int32_t* __restrict__ idf,
-    double* __restrict__ zn, int32_t* __restrict__ count, int32_t* __restrict__ assoc_host, int32_t* arrive,
-    int32_t* __restrict__ flag_host, int32_t seq) {
-    const int i = blockIdx.x;
-    const int lane = threadIdx.x;
-    const double INF = __builtin_inf();
-    double nd_c = INF, j_c = (double)0x7fffffff;
-    bool near = false;
-    for (int b = lane; b < nblocks; b += 64) {
-        const double* r = part + ((size_t)b * nz + i) * 3;
-        const double r0 = r[0], r1 = r[1], r2 = r[2];
-        if (r0 < nd_c || (r0 == nd_c && r1 < j_c)) { nd_c = r0; j_c = r1; }
-        near = near || (r2 != 0.0);
+// The observations of one launch travel IN the kernel arguments (2 KB of the 4 KB a launch may carry): every workgroup
+// needs all of them at its start, and reading them from the pinned host page the caller's z was staged in meant a few
+// thousand 64-byte reads across PCIe per sweep, on the critical path of a 9 us kernel.  First parameter: the kernel
+// indexes the argument segment itself (a dynamic index into the by-value copy would move the struct to scratch).
+constexpr int GATE_CHUNK = 128;        // observations per launch
+__device__ __forceinline__ const double* zdev_base(const double*, const double* zbuf) { return zbuf; }     // (the chunks' copies sit in the one buffer)
+struct GateObs {
+    double z[2 * GATE_CHUNK];
+};
+
+template <typename T>
+__global__ __launch_bounds__(GATE_BLOCK * OBS_WAVES) void gate_kernel(GateObs zarg, const T* __restrict__ x, const T* __restrict__ P,
+                                                           int ld, int N, double* __restrict__ zdev, int nz, double R0,
+                                                           double R1, double R2, double R3, double gate1, double gate2,
+                                                           double* __restrict__ part, const double* __restrict__ pmax_ptr,
+                                                           int pregate, int tlog, const T* __restrict__ side, int side_n,
+                                                           int part_cap, int32_t* assoc, int32_t* assoc_all, int compact_total,
+                                                           double* zbuf, int32_t* __restrict__ idf, double* __restrict__ zn,
+                                                           int32_t* __restrict__ count, int32_t* __restrict__ assoc_host, int32_t* arrive,
+                                                           int32_t* __restrict__ flag_host, int32_t seq) {
+    extern __shared__ double smem[];
+    double* zs = smem;                 // [nz][2]
+    double* red = smem + 2 * nz;       // [nz][3]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    constexpr int NT = GATE_BLOCK * OBS_WAVES;
+    typedef const __attribute__((address_space(4))) GateObs* KargPtr;
+    const KargPtr ka = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    for (int i = tid; i < 2 * nz; i += NT) {
+        const double v = ka->z[i];
+        zs[i] = v;
+        // the device copy the compaction (this launch's last workgroup), the update and add_features read: write-through
+        if (blockIdx.x == 0) __hip_atomic_store(zdev + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // Round 5: ONE launch.  What used to be the partials of every workgroup for every observation (nz x N / 64 records, folded by a
+    // second kernel) is now SPARSE: almost no workgroup has a landmark inside an observation's gates, and the few that do append
+    // {nd, landmark} to the observation's list (a slot from an atomic counter) and raise its `near` word; the workgroup that
+    // arrives LAST folds the lists -- a couple of entries per observation -- takes the decisions and, for observe(), compacts
+    // them.  part = [list: chunk observations x part_cap entries x 2 doubles][cnt: int32 per observation][near: int32 per observation].
+    double* const list = part;
+    int32_t* const cnt = reinterpret_cast<int32_t*>(part + (size_t)2 * GATE_CHUNK * part_cap);
+    int32_t* const nearw = cnt + GATE_CHUNK;
+
+    const double R[4] = {R0, R1, R2, R3};
+    double pose[3] = {(double)x[0], (double)x[1], (double)x[2]};
+    double pvv[9];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double o_nd = __shfl_xor(nd_c, off);
-        const double o_j = __shfl_xor(j_c, off);
-        if (o_nd < nd_c || (o_nd == nd_c && o_j < j_c)) { nd_c = o_nd; j_c = o_j; }
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pvv[r * 3 + c] = (double)P[p_off(ld, tlog, r, c)];
+
+    // the landmark constants are evaluated by every wave (cheaper than a hand-over through LDS: ~200 flops)
+    const int j0 = blockIdx.x * GATE_BLOCK + lane;
+    bool valid = j0 < N;
+    const double INF = __builtin_inf();
+    if (pregate) {
+        // N2: which of this wave's landmarks are within reach of ANY of this wave's observations?  Needs the landmark's
+        // mean only; the others are provably outside both gates for every one of them and skip the covariance loads.
+        __syncthreads();                                        // the observations are in LDS
+        bool need = false;
+        if (valid) {
+            const int f = 3 + 2 * j0;
+            const double dx = (double)x[f] - pose[0], dy = (double)x[f + 1] - pose[1];
+            const PreGate g = pre_gate(dx, dy, pvv, *pmax_ptr, R, gate2);
+            const double zp0 = sqrt(dx * dx + dy * dy), zp1 = atan2(dy, dx) - pose[2];
+            for (int i = wave; i < nz; i += OBS_WAVES) {
+                const double v0 = zs[2 * i] - zp0, v1 = mpi_to_pi_d(zs[2 * i + 1] - zp1);
+                if (!(v0 * v0 > g.b0) && !(v1 * v1 > g.b1)) need = true;
+            }
+        }
+        valid = need;
     }
-    const bool any_near = __ballot(near) != 0ull;
-    int last = 0;
-    if (lane == 0) {
-        int32_t a;
-        if (nd_c < INF) a = (int32_t)j_c;            // jbest != 0          (:43)
-        else if (!any_near) a = -1;                  // outer > gate2       (:46)
-        else a = 0;                                  // dropped
-        // write-through at agent scope, drained, then the arrival: the workgroup whose add comes last reads the
-        // decisions with agent-scope loads (no release/acquire fence = no L2 write-back + invalidate)
-        __hip_atomic_store(assoc + i, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (compact_total > 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            last = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    PairConst pc;
+    if (valid) pc = landmark_const(x, P, ld, tlog, j0, pose, pvv, R, side, side_n);
+    __syncthreads();                                            // (the observations are in LDS)
+
+    // Almost every (observation, landmark) pair is far outside both gates: the common path is a
+    // 2-vector innovation, a 2x2 quadratic form and two ballots, with no LDS traffic at all.
+    for (int i = wave; i < nz; i += OBS_WAVES) {
+        double nis = INF, nd = INF;
+        if (valid) pair_eval(pc, zs[2 * i], zs[2 * i + 1], nis, nd);
+        const bool cand = valid && (nis < gate1) && (nd < INF);
+        const bool near = valid && (nis <= gate2);
+        const unsigned long long cand_mask = __ballot(cand);
+        const unsigned long long near_mask = __ballot(near);
+        if ((cand_mask | near_mask) != 0ull) {       // wave-uniform, rare
+            double nd_c = INF;
+            int j_c = 0x7fffffff;
+            if (cand_mask != 0ull) {
+                if (cand) { nd_c = nd; j_c = j0 + 1; }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const double o_nd = __shfl_xor(nd_c, off);
+                    const int o_j = __shfl_xor(j_c, off);
+                    if (o_nd < nd_c || (o_nd == nd_c && o_j < j_c)) { nd_c = o_nd; j_c = o_j; }
+                }
+            }
+            if (lane == 0) {
+                (void)__hip_atomic_fetch_or(nearw + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // near_mask != 0 or a candidate (also near-or-matched)
+                if (cand_mask != 0ull) {
+                    const int e = __hip_atomic_fetch_add(cnt + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    double* o = list + ((size_t)i * part_cap + e) * 2;
+                    __hip_atomic_store(o, nd_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(o + 1, (double)j_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
     }
-    if (compact_total > 0 && __shfl(last, 0)) {
-        compact_wave(assoc_all, compact_total, zsrc, zbuf, idf, zn, count, assoc_host, lane, flag_host, seq);
-        if (lane == 0) __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed
+    // every wave's write-through stores and atomics are out; then this workgroup's arrival.  The workgroup whose add comes last
+    // reads the lists with agent-scope loads (no release / acquire fence = no L2 write-back + invalidate)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* const s_last = reinterpret_cast<int*>(red);
+    if (tid == 0) *s_last = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (!*s_last) return;
+    // ---- the last workgroup: per observation the best candidate (smallest nd, the lower landmark on a tie -- whatever order the
+    //      entries arrived in), the decision of src/data-association.jl:43-47; the words are re-armed for the next launch ----
+    for (int i = tid; i < nz; i += NT) {
+        const int c = __hip_atomic_load(cnt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int nr = __hip_atomic_load(nearw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double nd_c = INF, j_c = (double)0x7fffffff;
+        for (int e = 0; e < c; ++e) {
+            const double* o = list + ((size_t)i * part_cap + e) * 2;
+            const double r0 = __hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double r1 = __hip_atomic_load(o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (r0 < nd_c || (r0 == nd_c && r1 < j_c)) { nd_c = r0; j_c = r1; }
+        }
+        int32_t a;
+        if (nd_c < INF) a = (int32_t)j_c;            // jbest != 0          (:43)
+        else if (!nr) a = -1;                        // outer > gate2       (:46)
+        else a = 0;                                  // dropped
+        __hip_atomic_store(assoc + i, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(cnt + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(nearw + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            // re-armed
+    if (compact_total > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // observe(), last chunk: assoc[0 .. compact_total) -> the update's inputs, no extra launch
+        if (wave == 0) compact_wave<true>(assoc_all, compact_total, zdev_base(zdev, zbuf), zbuf, idf, zn, count, assoc_host, lane, flag_host, seq);
     }
 }
 
@@ -905,22 +904,20 @@ int launch_gate(slam_ekf* h, int nz, const double R[4], double gate1, double gat
         double* zc = h->obsbuf + 2 * (size_t)o;
         {
             KTimer t(h, SLAM_K_GATE);
+            const bool last = o + CHUNK >= nz;
+            const int ctot = (compact && last) ? nz : 0;
             if (h->dtype == SLAM_F32)
                 hipLaunchKernelGGL(gate_kernel<float>, dim3(nblocks), dim3(GATE_BLOCK * OBS_WAVES), shmem, h->stream, zarg,
                                    (const float*)h->x, (const float*)h->P, h->ld, h->N, zc, cz, R[0], R[1], R[2], R[3],
-                                   gate1, gate2, h->gate_part, (const double*)h->d_pmax, pregate, 7, (const float*)h->Pside, h->npad / 2);
+                                   gate1, gate2, h->gate_part, (const double*)h->d_pmax, pregate, 7, (const float*)h->Pside, h->npad / 2,
+                                   h->gate_blocks_cap, h->d_assoc + o, h->d_assoc, ctot, h->obsbuf, h->idfbuf, h->znbuf, h->d_count,
+                                   h->h_assoc_dev, h->d_count + 2, h->h_flag_dev, h->obs_seq);
             else
                 hipLaunchKernelGGL(gate_kernel<double>, dim3(nblocks), dim3(GATE_BLOCK * OBS_WAVES), shmem, h->stream, zarg,
                                    (const double*)h->x, (const double*)h->P, h->ld, h->N, zc, cz, R[0], R[1], R[2], R[3],
-                                   gate1, gate2, h->gate_part, (const double*)h->d_pmax, pregate, 6, (const double*)h->Pside, h->npad / 2);
-        }
-        HIP_TRY(hipGetLastError());
-        {
-            KTimer t(h, SLAM_K_GATE_FIN);
-            const bool last = o + CHUNK >= nz;
-            hipLaunchKernelGGL(gate_final_kernel, dim3(cz), dim3(64), 0, h->stream, (const double*)h->gate_part, nblocks, cz,
-                               h->d_assoc + o, h->d_assoc, (compact && last) ? nz : 0, h->obsbuf, h->obsbuf, h->idfbuf, h->znbuf,
-                               h->d_count, h->h_assoc_dev, h->d_count + 2, h->h_flag_dev, h->obs_seq);
+                                   gate1, gate2, h->gate_part, (const double*)h->d_pmax, pregate, 6, (const double*)h->Pside, h->npad / 2,
+                                   h->gate_blocks_cap, h->d_assoc + o, h->d_assoc, ctot, h->obsbuf, h->idfbuf, h->znbuf, h->d_count,
+                                   h->h_assoc_dev, h->d_count + 2, h->h_flag_dev, h->obs_seq);
         }
         HIP_TRY(hipGetLastError());
     }
