@@ -93,7 +93,6 @@ int slam_ekf_get_state(slam_ekf_t h, void* x, void* P, int n, int ldP);
  * covariance that is too large to download (80 GB at N = 50k fp64; the reference ships the whole matrix per step,
  * sim/browser/wsserver.jl:36).  Elements come from the symmetric view, whichever triangle holds them. */
 int slam_ekf_get_block(slam_ekf_t h, int r0, int c0, int nr, int nc, void* out, int ld_out);
-int slam_ekf_get_diag(slam_ekf_t h, void* out);
 /* The landmarks' 2 x 2 covariance blocks (what compute_association, src/data-association.jl:59, and the ellipses of
  * sim/browser/wsserver.jl:72-85 need of state.cov), packed: out[0][j] = P[f, f], out[1][j] = P[f+1, f], out[2][j] =
  * P[f+1, f+1], f = 3 + 2 j; three rows of N values in the handle's dtype.  Read from the side array the gating sweep
@@ -101,7 +100,6 @@ int slam_ekf_get_diag(slam_ekf_t h, void* out);
 int slam_ekf_get_landmark_blocks(slam_ekf_t h, void* out);
 int slam_ekf_get_pose(slam_ekf_t h, double pose[3]);       /* state.x[1:3]          */
 int slam_ekf_num_landmarks(slam_ekf_t h, int* N);          /* (length(x)-3)/2       */
-int slam_ekf_dtype(slam_ekf_t h, int* dtype);
 /* Raw device views (for zero-copy interop, e.g. a torch tensor over x): d_x has 3+2*max_landmarks elements.
  * d_P is NOT a column-major matrix: the covariance is stored TILE-MAJOR, BLOCK LOWER -- only the square tiles (edge E =
  * 128 for fp32, 64 for fp64) on and below the diagonal exist, each one contiguous E x E column-major block, the tiles of
@@ -159,8 +157,6 @@ int slam_ekf_associate(slam_ekf_t h, const double* z, int nz, const double R[4],
 #define SLAM_GATE_AUTO   0
 #define SLAM_GATE_SWEEP  1
 #define SLAM_GATE_GRID   2
-int slam_ekf_set_gate_mode(slam_ekf_t h, int mode);
-int slam_ekf_gate_info(slam_ekf_t h, int64_t out[8]);
 
 /* compute_association(x, P, z, R, idf)  src/data-association.jl:53-63.
  * out = {nis, nd}.  Synchronises. */
@@ -209,28 +205,6 @@ int slam_ekf_ellipses(slam_ekf_t h, double* features, double vehicle[6]);
 int slam_ekf_set_async(slam_ekf_t h, int async_updates);
 /* Wait for the handle's stream; returns the first deferred error (and clears it). */
 int slam_ekf_sync(slam_ekf_t h);
-/* enable = 1: every kernel launch is bracketed by HIP events on the handle's
- * stream; enable = a mask of (2 << SLAM_K_x): only those kernels (an event pair costs
- * ~10 us of stream time, so a benchmark brackets the dominant kernel only); 0: off.
- * timing_read synchronises, folds the pending events into per-kernel
- * totals and returns total milliseconds and launch count for kernel id `kid`. */
-int slam_ekf_timing(slam_ekf_t h, int enable);
-int slam_ekf_timing_read(slam_ekf_t h, int kid, double* total_ms, int64_t* launches);
-/* The fastest bracketed launch of kernel `kid` since the last reset, in milliseconds (0: none).  Synchronises. */
-int slam_ekf_timing_min(slam_ekf_t h, int kid, double* min_ms);
-/* out = {bracketed launches, their mean, sample standard deviation and minimum in milliseconds} since the last reset.  Synchronises. */
-int slam_ekf_timing_stats(slam_ekf_t h, int kid, double out[4]);
-int slam_ekf_timing_reset(slam_ekf_t h);
-/* Diagnostics: when enabled the factorisation kernel records 100 MHz wall-clock stamps at its
- * phase boundaries; out8 (may be NULL) receives the stamps of the last update. */
-int slam_ekf_debug_stamps(slam_ekf_t h, int enable, uint64_t* out8);
-/* Measurement hook (bench.py: roofline.copy_floor_ms): the bare memory side of the covariance down-date (src/ekf.jl:75) on
- * THIS handle's matrix -- every stored tile the down-date touches read once and written back unchanged (bit-exact), in
- * the down-date's own band-major order, no panels, no matrix-core work; `reps` individually timed passes of each of two launch
- * forms.  out = {milliseconds of the FASTEST pass, its form's index (0: one workgroup per tile, 1: persistent grid)}.  The
- * down-date's launch time over this figure compares across the boxes of a pool whose memory systems differ by a few
- * per cent.  Synchronises; the state is unchanged. */
-int slam_ekf_copy_floor(slam_ekf_t h, int reps, double out[2]);
 
 /* ---- FastSLAM-1.0 particle path (known correspondences) ----------------------------
  *
@@ -329,7 +303,6 @@ int slam_pf_mean_pose_sums(slam_pf_t h, double out[4]);
 /* Download (host buffers, handle dtype; any may be NULL): pose [3][n], logw [n], lm [nl][5][n]. */
 int slam_pf_download(slam_pf_t h, void* pose, void* logw, void* lm);
 int slam_pf_sync(slam_pf_t h);
-int slam_pf_stream(slam_pf_t h, void** stream);
 
 /* ---- the filter step without the host in the loop ("auto mode") -------------------------------------------------
  * slam_pf_step_auto: one whole filter step -- slam_pf_step (proposal = 0) or slam_pf_step_proposal (1), the
@@ -407,14 +380,6 @@ int slam_pf_attach_exchange(slam_pf_t h, int rank, int world, void* page, size_t
 int slam_pf_export_peer(slam_pf_t h, void* blob);
 int slam_pf_attach_peers(slam_pf_t h, int rank, int world, const void* blobs);
 int slam_pf_detach_peers(slam_pf_t h);
-/* Collective: a barrier among the attached ranks through their inboxes; SLAM_OK when every peer's word arrived within
- * timeout_ms.  The caller's check, right after attaching, that the GPUs see each other's writes. */
-int slam_pf_peer_selftest(slam_pf_t h, int timeout_ms);
-int slam_pf_comm_info(slam_pf_t h, int64_t out[4]);
-/* Diagnostics: 100 MHz wall-clock stamps of the last auto step: kernel start, every workgroup's statistics collected,
- * statistics folded, decision taken, bookkeeping done, published; [6] the collecting workgroup finished its own share,
- * [7] = [0] + 100 x the number of polls it needed.  Waits for the queue. */
-int slam_pf_debug_stamps(slam_pf_t h, uint64_t out[8]);
 
 /* ---- SURVEY 8b's whole-filter calls (filter wholly on this shard) --------------------------------------------------
  * slam_pf_resample: F4 -- normalise, and resample (systematic, slam_pf_resample_local) if Neff < neff_frac * n;

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/slamhip.h"
+#include "../../include/slamhip_diag.h"
 
 #define SLAM_PI 3.14159265358979323846
 

@@ -98,10 +98,11 @@ constexpr int NTHREADS = 64 * NWAVE;
 struct DdCtx : DdCtxP {       // per-thread constants of the down-date kernel
     const float* X;
     const float* Y;
-    int pitch, kp, nchunks, xflags;     // xflags: SLAMHIP_X (512: round 3's register-staged chunk pipeline instead of the LDS-DMA one)
+    int pitch, kp, nchunks, dbg, xflags;
     const char* img;     // pre-split bf16 image of the panel (split-bf16 path, reference form), or null
     int img_nch;         // chunks of 16 columns per 128-row block in the image
     int wr, wc, l31, lh, q, cl, srow, sc4;
+    unsigned long long t_head, t_wait, t_epi, t_total;     // DBG instantiation only (shader clocks, summed over tiles)
 };
 
 __device__ __forceinline__ void load_p_tile(const DdCtx& c, int R0, int C0, f32x4 (&pold)[2][4]) {
@@ -124,7 +125,7 @@ __device__ __forceinline__ void load_p_tile(const DdCtx& c, int R0, int C0, f32x
 // bit-for-bit symmetric.
 template <bool diag>
 __device__ __forceinline__ void store_p_tile(const DdCtx& c, int R0, int C0, const f32x4 (&pold)[2][4],
-                                             const f32x16 (&acc)[2], float* sD, float* sV) {
+                                             const f32x16 (&acc)[2], float* sD, float* sV, int dbg) {
     const auto rs = tile_rsrc(c, R0, C0);       // the tile (the in-tile mirror of a diagonal tile goes to the same one)
     const int voff = (c.cl * TILE + 4 * c.q) * 4;
     const int q = c.q, cl = c.cl;
@@ -140,6 +141,7 @@ __device__ __forceinline__ void store_p_tile(const DdCtx& c, int R0, int C0, con
             const f32x4 prod = *reinterpret_cast<const f32x4*>(&sD[col * SP + 4 * q]);
             const f32x4 val = pold[rb][s] - prod;
             const int soff = ((32 * c.wc + 8 * s) * TILE + 64 * c.wr + 32 * rb) * 4;
+            if (dbg & 1) continue;                                 // experiment: no stores (P stays as it is)
             if (!diag) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rs, voff, soff, 0);
                 // the tile below a diagonal tile holds P[f+1, f] of the landmark straddling the boundary: (row 0, column 127) of the
@@ -160,7 +162,7 @@ __device__ __forceinline__ void store_p_tile(const DdCtx& c, int R0, int C0, con
             }
         }
         wave_lds_fence();
-        if (diag) {                                 // in-tile mirror: upper triangle of a diagonal tile
+        if (diag && !(dbg & 1)) {                                 // in-tile mirror: upper triangle of a diagonal tile
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int rr = cl + 8 * s;                         // row of the sub-block -> column of the mirror
@@ -215,14 +217,16 @@ __device__ __forceinline__ void read_frag(const DdCtx& c, const smem_t& sm, int 
         f.b[rb] = *reinterpret_cast<const f32x4*>(&sm[buf][0][64 * c.wr + 32 * rb + c.l31][kk + 4 * c.lh]);
 }
 
+template <bool DBG>
 __device__ __forceinline__ void mfma_step(const DdCtx& c, const Frag& f, f32x16 (&acc)[2]) {
-    __builtin_amdgcn_s_setprio(3);     // the wave that has its operands keeps the matrix pipe (A/B: -0.6 %)
+    if (DBG && (c.dbg & 2)) return;
+    if (!(c.xflags & 2)) __builtin_amdgcn_s_setprio(3);     // the wave that has its operands keeps the matrix pipe (A/B: -0.6 %)
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
             acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t], f.b[rb][t], acc[rb], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+    if (!(c.xflags & 2)) __builtin_amdgcn_s_setprio(0);
 }
 
 // One tile, start to finish.  On entry gx/gy hold (or are about to receive) the first panel chunk of
@@ -234,7 +238,7 @@ __device__ __forceinline__ void mfma_step(const DdCtx& c, const Frag& f, f32x16 
 // order, so anything waited for after the 64 KiB P tile has been requested also waits for the P tile:
 // the P loads are therefore issued right after the LAST panel request of the tile and nothing but the
 // epilogue ever waits behind them.
-template <bool DIAG>
+template <bool DIAG, bool DBG>
 __device__ __forceinline__ void dd_tile(DdCtx& c, int2 tile, int2 next, smem_t& smem, float* sD, float* sV,
                                         f32x4 (&gx)[2], f32x4 (&gy)[2]) {
     const int R0 = tile.x * TILE;     // rows  (I)
@@ -248,25 +252,31 @@ __device__ __forceinline__ void dd_tile(DdCtx& c, int2 tile, int2 next, smem_t& 
     f32x4 pold[2][4];                 // the wave's 64 x 32 part of the P tile
     Frag f0;
 
+    constexpr bool PROF = DBG;
+    unsigned long long tp0 = 0, tp1 = 0;
+    if (PROF) tp0 = __builtin_amdgcn_s_memtime();
     fill_lds(c, smem, 0, gx, gy);
     __syncthreads();
+    if (PROF) { tp1 = __builtin_amdgcn_s_memtime(); c.t_head += tp1 - tp0; }
     if (nch > 1) request_chunk(c, tile, 1, gx, gy);
-    if (nch <= 2) load_p_tile(c, R0, C0, pold);
+    if (nch <= 2 && !(DBG && (c.dbg & 4))) load_p_tile(c, R0, C0, pold);
     int ch = 0;
     // chunk ch is followed by chunk ch+1: four steps, then the hand-over of the other LDS buffer
 #define DD_STEPS(BUF, N)                                   \
     _Pragma("unroll") for (int st = 0; st < (N); ++st) {   \
         read_frag(c, smem, BUF, 8 * st, f0);               \
-        mfma_step(c, f0, acc);                        \
+        mfma_step<DBG>(c, f0, acc);                        \
     }
 #define DD_CHUNK(REQUEST, LOADP)                                                                   \
     {                                                                                              \
         const int buf = ch & 1;                                                                    \
         DD_STEPS(buf, 4)                                                                           \
+        if (PROF) tp1 = __builtin_amdgcn_s_memtime();                                              \
         fill_lds(c, smem, buf ^ 1, gx, gy);                                                        \
         __syncthreads();                                                                           \
+        if (PROF) c.t_wait += __builtin_amdgcn_s_memtime() - tp1;                                  \
         if (REQUEST) request_chunk(c, tile, ch + 2, gx, gy);                                       \
-        if ((LOADP)) load_p_tile(c, R0, C0, pold);                        \
+        if ((LOADP) && !(DBG && (c.dbg & 4))) load_p_tile(c, R0, C0, pold);                        \
         ++ch;                                                                                      \
     }
     while (ch + 3 < nch) DD_CHUNK(true, false)
@@ -278,16 +288,22 @@ __device__ __forceinline__ void dd_tile(DdCtx& c, int2 tile, int2 next, smem_t& 
         DD_STEPS(buf, 2)
         if (c.kp - ch * KC > 16) {
             read_frag(c, smem, buf, 16, f0);
-            mfma_step(c, f0, acc);
+            mfma_step<DBG>(c, f0, acc);
             read_frag(c, smem, buf, 24, f0);
-            mfma_step(c, f0, acc);
+            mfma_step<DBG>(c, f0, acc);
         }
     }
 #undef DD_STEPS
+    if (PROF) tp1 = __builtin_amdgcn_s_memtime();
     __syncthreads();                  // every wave is done with the panels: LDS becomes epilogue scratch
     if (next.x >= 0) request_chunk(c, next, 0, gx, gy);
-    store_p_tile<DIAG>(c, R0, C0, pold, acc, sD, sV);
+    store_p_tile<DIAG>(c, R0, C0, pold, acc, sD, sV, DBG ? c.dbg : 0);
     __syncthreads();                  // scratch free again before the next tile's LDS fill
+    if (PROF) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        c.t_epi += t - tp1;
+        c.t_total += t - tp0;
+    }
 }
 
 // ---- streaming path for runs of OFF-DIAGONAL tiles -----------------------------------------------------------------
@@ -336,7 +352,7 @@ __device__ __forceinline__ void store_p_mfma(const DdCtx& c, int R0, int C0, con
 // On entry gx/gy hold the request for chunk 0 of the first tile; on return `slot` is the first unprocessed position
 // and, if that tile exists, gx/gy hold the request for ITS chunk 0 -- the contract of dd_tile, which takes over for
 // the diagonal tiles.
-template <int NCH, int POFF = 2>
+template <bool DBG, int NCH, int POFF = 2>
 __device__ __forceinline__ void dd_stream(DdCtx& c, const int2* __restrict__ list, int L, int nper, int& slot, smem_t& smem,
                                           f32x4 (&gx)[2], f32x4 (&gy)[2]) {
     auto fetch = [&](int sl) { return sl < L ? list[sl] : make_int2(-1, -1); };
@@ -366,7 +382,7 @@ __device__ __forceinline__ void dd_stream(DdCtx& c, const int2* __restrict__ lis
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
                     read_frag(c, smem, pb, 8 * st, f0);
-                    mfma_step(c, f0, acc);
+                    mfma_step<DBG>(c, f0, acc);
                 }
                 fill_lds(c, smem, pb ^ 1, gx, gy);               // chunk ch + 1 of this tile
                 __syncthreads();
@@ -375,7 +391,7 @@ __device__ __forceinline__ void dd_stream(DdCtx& c, const int2* __restrict__ lis
             } else {
                 for (int st = 0; st < last_steps; ++st) {
                     read_frag(c, smem, pb, 8 * st, f0);
-                    mfma_step(c, f0, acc);
+                    mfma_step<DBG>(c, f0, acc);
                 }
                 if (next_off) fill_lds(c, smem, pb ^ 1, gx, gy); // chunk 0 of the next tile
                 __syncthreads();
@@ -429,6 +445,7 @@ __device__ __forceinline__ void request_chunk_b(const DdCtx& c, int2 t, int chun
     const auto ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.Y), (short)0, c.ld * c.pitch * 4, 0x00020000);
     const int tid = threadIdx.x;
     const int voff = (stage_row(tid) * c.pitch + 4 * (tid & 3)) * 4;
+    if (c.dbg & 8) t = make_int2(0, 0);        // experiment (DBG build only sets dbg): every tile reads the panels of tile (0,0)
     gx = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, (t.x * TILE * c.pitch + chunk * KB) * 4, 0));
     gy = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, voff, (t.y * TILE * c.pitch + chunk * KB) * 4, 0));
 }
@@ -443,6 +460,7 @@ __device__ __forceinline__ void split2(float v0, float v1, unsigned& h, unsigned
     l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
 }
 
+template <bool DBG>
 __device__ __forceinline__ void fill_lds_b(const DdCtx& c, char* sm, int buf, const f32x4& gx, const f32x4& gy) {
     const int tid = threadIdx.x;
     char* base = sm + buf * (6 * BARR) + stage_row(tid) * BROW + (tid & 3) * 8;
@@ -450,8 +468,13 @@ __device__ __forceinline__ void fill_lds_b(const DdCtx& c, char* sm, int buf, co
     for (int pnl = 0; pnl < 2; ++pnl) {
         const f32x4 g = pnl ? gy : gx;
         unsigned h0, m0, l0, h1, m1, l1;
+        if (DBG && (c.dbg & 16)) {             // experiment: no split arithmetic (wrong numbers)
+            h0 = m0 = l0 = __float_as_uint(g.x) ^ __float_as_uint(g.y);
+            h1 = m1 = l1 = __float_as_uint(g.z) ^ __float_as_uint(g.w);
+        } else {
         split2(g.x, g.y, h0, m0, l0);
         split2(g.z, g.w, h1, m1, l1);
+        }
         *reinterpret_cast<u32x2*>(base + (3 * pnl + 0) * BARR) = u32x2{h0, h1};
         *reinterpret_cast<u32x2*>(base + (3 * pnl + 1) * BARR) = u32x2{m0, m1};
         *reinterpret_cast<u32x2*>(base + (3 * pnl + 2) * BARR) = u32x2{l0, l1};
@@ -459,7 +482,9 @@ __device__ __forceinline__ void fill_lds_b(const DdCtx& c, char* sm, int buf, co
 }
 
 // one chunk = one k16 step: 3 + 2 x 3 fragments, 2 x 6 MFMAs, smallest terms first
+template <bool DBG>
 __device__ __forceinline__ void mfma_chunk_b(const DdCtx& c, const char* sm, int buf, f32x16 (&acc)[2]) {
+    if (DBG && (c.dbg & 2)) return;
     const char* base = sm + buf * (6 * BARR) + c.l31 * BROW + c.lh * 16;
     bf16x8 a[3];                       // Y: the wave's 32 columns (the MFMA's A operand, as in read_frag)
 #pragma unroll
@@ -469,14 +494,14 @@ __device__ __forceinline__ void mfma_chunk_b(const DdCtx& c, const char* sm, int
         bf16x8 b[3];                   // X: 32 of the wave's 64 rows
 #pragma unroll
         for (int sp = 0; sp < 3; ++sp) b[sp] = *reinterpret_cast<const bf16x8*>(base + sp * BARR + (64 * c.wr + 32 * rb) * BROW);
-        __builtin_amdgcn_s_setprio(3);
+        if (!(c.xflags & 2)) __builtin_amdgcn_s_setprio(3);
         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[rb], 0, 0, 0);      // (m, m)
         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[rb], 0, 0, 0);      // (h, l)
         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[rb], 0, 0, 0);      // (l, h)
         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[rb], 0, 0, 0);      // (h, m)
         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[rb], 0, 0, 0);      // (m, h)
         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[rb], 0, 0, 0);      // (h, h)
-        __builtin_amdgcn_s_setprio(0);
+        if (!(c.xflags & 2)) __builtin_amdgcn_s_setprio(0);
     }
 }
 
@@ -494,9 +519,21 @@ typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void request_chunk_p(const DdCtx& c, int2 t, int chunk, u32x4b (&g)[3]) {
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(c.img), (short)0, 0x7fffffff, 0x00020000);
     const int tid = threadIdx.x;
+#ifdef SLAMHIP_EXPERIMENTS
+    // experiment (SLAMHIP_DEBUG bit 65536, round 4): EVERY tile reads the image of tile (0, 0) -- 192 KB that never leave the
+    // L2s: what the panels' fabric traffic (every XCD fetches every column band's image once: 0.12 GB of the 0.2 GB the launch
+    // moves beyond P itself) costs in time.  Wrong numbers.
+    if (c.xflags & 256) t = make_int2(0, 0);
+#endif
     const int sx = (t.x * c.img_nch + chunk) * IMG_CHUNK, sy = (t.y * c.img_nch + chunk) * IMG_CHUNK;
     // pieces tid, tid + 512, tid + 1024 of the 1536 sixteen-byte pieces [X image | Y image]
     g[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, sx, 0);
+#ifdef SLAMHIP_EXPERIMENTS
+    if (c.dbg & 64) {          // experiment: the Y image is NOT loaded (what a column panel resident in LDS would save; wrong numbers)
+        if (tid < 256) g[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + 512) * 16, sx, 0);
+        return;
+    }
+#endif
     g[1] = tid < 256 ? __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + 512) * 16, sx, 0)
                      : __builtin_amdgcn_raw_buffer_load_b128(rs, (tid - 256) * 16, sy, 0);
     g[2] = __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + 256) * 16, sy, 0);
@@ -508,25 +545,43 @@ __device__ __forceinline__ void fill_lds_p(char* sm, int buf, const u32x4b (&g)[
     for (int j = 0; j < 3; ++j) *reinterpret_cast<u32x4b*>(base + j * 8192) = g[j];
 }
 
+template <bool DBG>
 __device__ __forceinline__ void mfma_chunk_p(const DdCtx& c, const char* sm, int buf, f32x16 (&acc)[2], bool negate = false) {
+    if (DBG && (c.dbg & 2)) return;
     // row r of an array sits at r * 32, its k-half h at ((h ^ (r >> 3)) & 1) * 16; all rows here are l31 + multiples of 32
     const char* base = sm + buf * (2 * IMG_CHUNK) + c.l31 * 32 + ((c.lh ^ (c.l31 >> 3)) & 1) * 16;
     bf16x8 a[3];
 #pragma unroll
     for (int sp = 0; sp < 3; ++sp) a[sp] = *reinterpret_cast<const bf16x8*>(base + IMG_CHUNK + sp * IMG_ARR + (32 * c.wc) * 32);
+    if (DBG && negate) {       // WRAP experiment: the second walk over the image takes back what the first one subtracted
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) {
+            u32x4b t = __builtin_bit_cast(u32x4b, a[sp]);
+            t ^= 0x80008000u;
+            a[sp] = __builtin_bit_cast(bf16x8, t);
+        }
+    }
     bf16x8 b[3];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
+        // (experiment, bit 8: the second row block reuses the first one's fragments -- a third fewer LDS reads, wrong numbers:
+        //  what a 64 x 64 register tile per wave would save on the fragment side)
+        if (!(DBG && (c.dbg & 8) && rb == 1)) {
 #pragma unroll
         for (int sp = 0; sp < 3; ++sp) b[sp] = *reinterpret_cast<const bf16x8*>(base + sp * IMG_ARR + (64 * c.wr + 32 * rb) * 32);
-        __builtin_amdgcn_s_setprio(3);
+        }
+        // (experiments build, SLAMHIP_X bit 128: the priorities the other way round -- a wave is favoured while it ISSUES
+        //  memory and LDS operations and steps back during its MFMAs)
+        if (c.xflags & 128) __builtin_amdgcn_s_setprio(0);
+        else if (!(c.xflags & 2)) __builtin_amdgcn_s_setprio(3);
         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[rb], 0, 0, 0);      // (m, m)
         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[rb], 0, 0, 0);      // (h, l)
         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[rb], 0, 0, 0);      // (l, h)
         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[rb], 0, 0, 0);      // (h, m)
         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[rb], 0, 0, 0);      // (m, h)
         acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[rb], 0, 0, 0);      // (h, h)
-        __builtin_amdgcn_s_setprio(0);
+        if (c.xflags & 128) __builtin_amdgcn_s_setprio(3);
+        else if (!(c.xflags & 2)) __builtin_amdgcn_s_setprio(0);
     }
 }
 
@@ -562,7 +617,7 @@ __device__ __forceinline__ unsigned lds_load_u32(const char* p) { return *(const
 #define DD_POFF8 (7 + DD_PCH0)
 #endif
 
-template <int NCH, int POFF, bool WRAP = false, bool DYN = false>
+template <bool DBG, int NCH, int POFF, bool WRAP = false, bool DYN = false>
 __device__ __forceinline__ void dd_stream_p(DdCtx& c, const int2* __restrict__ list, int L, int nper, int& slot, char* sm,
                                             unsigned* __restrict__ ctr = nullptr) {
     auto fetch = [&](int sl) { return sl < L ? list[sl] : make_int2(-1, -1); };
@@ -590,8 +645,8 @@ __device__ __forceinline__ void dd_stream_p(DdCtx& c, const int2* __restrict__ l
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             const int pb = (base + ch) & 1;
-            if (ch == PCH) load_p_mfma(c, tile.x * TILE, tile.y * TILE, pold);
-            mfma_chunk_p(c, sm, pb, acc, WRAP && ch >= 8);
+            if (ch == PCH && !(DBG && (c.dbg & 4))) load_p_mfma(c, tile.x * TILE, tile.y * TILE, pold);
+            mfma_chunk_p<DBG>(c, sm, pb, acc, WRAP && ch >= 8);
             if (DYN && ch == 1 && threadIdx.x == 0) lds_store_u32(sm + CLAIM_OFF, claimed);
             if (ch < NCH - 1) {
                 fill_lds_p(sm, pb ^ 1, g);
@@ -609,7 +664,7 @@ __device__ __forceinline__ void dd_stream_p(DdCtx& c, const int2* __restrict__ l
                 if (next_off) fill_lds_p(sm, pb ^ 1, g);
                 __syncthreads();
                 if (next_off) request_chunk_p(c, next, 1, g);
-                store_p_mfma(c, tile.x * TILE, tile.y * TILE, pold, acc);
+                if (!(DBG && (c.dbg & 1))) store_p_mfma(c, tile.x * TILE, tile.y * TILE, pold, acc);
             }
         }
         slot = DYN ? next_slot : slot + nper;
@@ -674,6 +729,33 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 __device__ __forceinline__ void bare_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct DdFrags { bf16x8 a[3], b[3], b1[3]; };
+#ifdef SLAMHIP_EXPERIMENTS
+// EXPERIMENT (SLAMHIP_X bit 1048576, timing only, WRONG numbers): the step's matrix work as 24 v_mfma_f32_16x16x32_bf16 on the
+// same fragment registers instead of 12 v_mfma_f32_32x32x16_bf16 -- the same pipe cycles per FLOP; MI355X_MICROARCH.md ('DVFS
+// give-back' item 7) reports a higher clock held on the 16x16x32 shape.  Run with the stores off.
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mfma_frags_16(const DdFrags& f, f32x16 (&acc)[2]) {
+    __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        f32x4m c[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[q] = f32x4m{acc[rb][4 * q], acc[rb][4 * q + 1], acc[rb][4 * q + 2], acc[rb][4 * q + 3]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bf16x8 bb = rb ? f.b1[q % 3] : f.b[q % 3];
+            c[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[0], bb, c[q], 0, 0, 0);
+            c[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[1], bb, c[q], 0, 0, 0);
+            c[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[2], bb, c[q], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[rb][4 * q + r] = c[q][r];
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+#endif
 __device__ __forceinline__ void read_frags_d(const DdCtx& c, const char* sm, int buf, DdFrags& f) {
     const unsigned base = lds_addr(sm) + buf * DMA_BUF + c.l31 * 32 + ((c.lh ^ (c.l31 >> 3)) & 1) * 16;
     const unsigned ya = base + IMG_CHUNK + (32 * c.wc) * 32, xa = base + (64 * c.wr) * 32;
@@ -687,6 +769,23 @@ __device__ __forceinline__ void read_frags_d(const DdCtx& c, const char* sm, int
         : "memory");
 }
 __device__ __forceinline__ void mfma_frags_d(const DdFrags& f, f32x16 (&acc)[2]) {
+#ifdef DD_MFMA_INTERLEAVE     // (build-time A/B: the two row blocks' chains interleaved, no MFMA directly behind the one it depends on)
+    __builtin_amdgcn_s_setprio(3);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1], f.b[1], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1], f.b1[1], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], f.b[2], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], f.b1[2], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[2], f.b[0], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[2], f.b1[0], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], f.b[1], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], f.b1[1], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1], f.b[0], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1], f.b1[0], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], f.b[0], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], f.b1[0], acc[1], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    return;
+#endif
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         __builtin_amdgcn_s_setprio(3);
@@ -704,10 +803,20 @@ __device__ __forceinline__ void mfma_frags_d(const DdFrags& f, f32x16 (&acc)[2])
 // Measured and dropped (round 4, one box each, profiles/r04_downdate_dma_experiments.txt): the barrier between the fragment reads
 // and the MFMAs; the second row block's fragment reads behind the first one's MFMAs; a tile's stores behind the next tile's first
 // MFMAs instead of one burst -- all within 1 % of this form.
-template <int NCH, int PCH>
+template <bool DBG, int NCH, int PCH>
 __device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__ list, int L, int nper, int& slot, char* sm,
-                                              unsigned* __restrict__ ctr, int wave, char* cw) {
+                                              unsigned* __restrict__ ctr, int wave, char* cw, unsigned long long* prof = nullptr) {
     static_assert(NCH >= 5 && PCH >= 2 && PCH <= NCH - 2, "");
+#ifdef SLAMHIP_EXPERIMENTS
+    // (SLAMHIP_STAMPS=1: where a wave's cycles go -- shader-clock sums over all its steps: fragment reads, MFMA issue, the wait
+    //  for the chunk per step of the tile, barrier, DMA issue, stores)
+    unsigned long long ph_lds = 0, ph_mfma = 0, ph_bar = 0, ph_issue = 0, ph_store = 0, ph_vm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_steps = 0;
+    // (the in-kernel clock: shader-clock ticks over 100 MHz ticks around the whole stream, MI355X_MICROARCH.md 'DVFS give-back' item 6)
+    const unsigned long long clk0 = prof ? __builtin_amdgcn_s_memtime() : 0, rt0 = prof ? __builtin_amdgcn_s_memrealtime() : 0;
+#define STAMP(var) do { if (prof) { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define STAMP(var) do { } while (0)
+#endif
     constexpr int RD = NCH - 3;        // the step at whose end the next tile's first chunk is requested
     auto fetch = [&](int sl) { return sl < L ? list[sl] : make_int2(-1, -1); };
     int2 tile = fetch(slot);
@@ -732,23 +841,51 @@ __device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__
         static_for<0, NCH>([&](auto CH) {
             constexpr int ch = decltype(CH)::value;
             const int buf = (base + ch) % 3;
+            [[maybe_unused]] unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+            STAMP(t0);
+#ifdef SLAMHIP_EXPERIMENTS
+            // switch-off experiments on THIS pipeline (SLAMHIP_X bits, wrong results except where P stays what it was):
+            // 1024 no MFMAs, 2048 no stores, 4096 no P loads (with 2048 only), 8192 no fragment reads, 16384 no chunk requests
+            const int xo = c.xflags;
+#else
+            constexpr int xo = 0;
+#endif
+#ifdef SLAMHIP_EXPERIMENTS
+            if (ch == PCH && (xo & 524288)) load_p_mfma<0>(c, tile.x * TILE, tile.y * TILE, pold);                  // (cache policy of the P loads: default)
+            else
+#endif
             // (the hand-counted waits below assume the queue order [chunk request][P loads] and [chunk request][P stores]: nothing but
-            //  these scheduling fences keeps the compiler from swapping two builtins that do not depend on each other;
-            //  tools/check_downdate_isa.py looks at the order in the built kernel)
+            //  these scheduling fences keeps the compiler from swapping two builtins that do not depend on each other)
             __builtin_amdgcn_sched_barrier(0);
-            if (ch == PCH) load_p_mfma(c, tile.x * TILE, tile.y * TILE, pold);
+            if (ch == PCH && !(DBG && (c.dbg & 4)) && !(xo & 4096)) load_p_mfma(c, tile.x * TILE, tile.y * TILE, pold);
             DdFrags fr;
-            read_frags_d(c, sm, buf, fr);
-            mfma_frags_d(fr, acc);
+            if (!(xo & 8192)) read_frags_d(c, sm, buf, fr);
+            else     // (the registers are taken as they are: no instruction stands in for the reads)
+                asm volatile("" : "=v"(fr.a[0]), "=v"(fr.a[1]), "=v"(fr.a[2]), "=v"(fr.b[0]), "=v"(fr.b[1]), "=v"(fr.b[2]), "=v"(fr.b1[0]), "=v"(fr.b1[1]), "=v"(fr.b1[2]));
+            STAMP(t1);
+#ifdef SLAMHIP_EXPERIMENTS
+            if (xo & 1048576) mfma_frags_16(fr, acc);
+            else
+#endif
+            if (!(xo & 1024)) mfma_frags_d(fr, acc);
+            else asm volatile("" ::"v"(fr.a[0]), "v"(fr.a[1]), "v"(fr.a[2]), "v"(fr.b[0]), "v"(fr.b[1]), "v"(fr.b[2]), "v"(fr.b1[0]), "v"(fr.b1[1]), "v"(fr.b1[2]));
+            STAMP(t2);
             if (ch == RD && threadIdx.x == 0) asm_lds_store_u32(cw, claimed);
             // chunk ch + 1 (this tile's, or the next tile's first) has landed when at most these remain outstanding
             constexpr int PL = (ch == PCH || ch == PCH + 1) ? 32 : 0;           // the P tile's loads sit behind it
+            // (the timing experiments that switch the P stores / loads off do not issue those 32 operations: the count drops)
+            const bool no_st = (DBG && (c.dbg & 1)) || (xo & 2048), no_ld = (DBG && (c.dbg & 4)) || (xo & 4096);
             if (ch <= 1) {                                                      // ... the previous tile's stores and chunk ch + 2
-                if (first) wait_vm<3>();
+                if (first || no_st) wait_vm<3>();
                 else wait_vm<35>();
-            } else if (ch + 2 < NCH || next_off) wait_vm<3 + PL>();             // (chunk ch + 2 is this tile's or the next tile's)
+            } else if (ch + 2 < NCH || next_off) {                              // (chunk ch + 2 is this tile's or the next tile's)
+                if (no_ld) wait_vm<3>();
+                else wait_vm<3 + PL>();
+            } else if (no_ld) wait_vm<0>();
             else wait_vm<PL>();
+            STAMP(t3);
             bare_barrier();
+            STAMP(t4);
             if (ch == 0 && threadIdx.x == 0) claimed = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (ch == RD) {          // (the claim of step 0 is read as late as the next tile's first chunk allows: its return
                                      //  comes behind the previous tile's stores in wave 0's queue)
@@ -756,10 +893,49 @@ __device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__
                 next = fetch(next_slot);
                 next_off = next.x >= 0 && next.x != next.y;
             }
-            if (ch + 3 < NCH) dma_chunk(c, tile, ch + 3, sm, buf, wave);
-            else if (next_off) dma_chunk(c, next, ch + 3 - NCH, sm, buf, wave);
+            if (!(xo & 16384)) {
+                if (ch + 3 < NCH) dma_chunk(c, tile, ch + 3, sm, buf, wave);
+                else if (next_off) dma_chunk(c, next, ch + 3 - NCH, sm, buf, wave);
+            }
             __builtin_amdgcn_sched_barrier(0);                                  // (the chunk request stays in front of the tile's stores)
-            if (ch == NCH - 1) store_p_mfma(c, tile.x * TILE, tile.y * TILE, pold, acc);
+            STAMP(t5);
+#ifdef DD_TIMING_BASE
+            constexpr bool tbase = true;
+#else
+            constexpr bool tbase = false;
+#endif
+            if (ch == NCH - 1 && ((xo & 4194304) || tbase)) {          // (P stored back UNCHANGED, the accumulators consumed: the baseline of the 16x16x32 experiment)
+                f32x16 zero[2];
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { asm volatile("" ::"v"(acc[rb][r])); zero[rb][r] = 0.0f; acc[rb][r] = 0.0f; }
+                store_p_mfma(c, tile.x * TILE, tile.y * TILE, pold, zero);
+            } else
+            if (ch == NCH - 1 && (xo & 2048)) {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (!(xo & 4096)) asm volatile("" ::"v"(pold[rb][r] - acc[rb][r]));
+                        else asm volatile("" ::"v"(acc[rb][r]));
+                        acc[rb][r] = 0.0f;
+                    }
+            } else
+#ifdef SLAMHIP_EXPERIMENTS
+            if (ch == NCH - 1 && (xo & 65536)) store_p_mfma<0>(c, tile.x * TILE, tile.y * TILE, pold, acc);          // (cache policy of the P stores: default)
+            else if (ch == NCH - 1 && (xo & 131072)) store_p_mfma<1>(c, tile.x * TILE, tile.y * TILE, pold, acc);   // (sc0)
+            else if (ch == NCH - 1 && (xo & 262144)) store_p_mfma<3>(c, tile.x * TILE, tile.y * TILE, pold, acc);   // (sc0 nt)
+            else
+#endif
+            if (ch == NCH - 1 && !(DBG && (c.dbg & 1))) store_p_mfma(c, tile.x * TILE, tile.y * TILE, pold, acc);
+            STAMP(t6);
+#ifdef SLAMHIP_EXPERIMENTS
+            if (prof) {
+                ph_lds += t1 - t0; ph_mfma += t2 - t1; ph_vm[ch < 8 ? ch : 7] += t3 - t2; ph_bar += t4 - t3; ph_issue += t5 - t4; ph_store += t6 - t5;
+                ++ph_steps;
+            }
+#endif
         });
         slot = next_slot;
         if (!next_off) break;
@@ -768,7 +944,21 @@ __device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__
         first = false;
     }
     wait_vm<0>();                      // (nothing of this path is in flight when the diagonal tiles take the LDS array over)
+#ifdef SLAMHIP_EXPERIMENTS
+    if (prof && (threadIdx.x & 63) == 0) {
+        unsigned long long* o = prof + ((size_t)blockIdx.x * NWAVE + wave) * 16;
+        o[0] = ph_steps; o[1] = ph_lds; o[2] = ph_mfma; o[3] = ph_bar; o[4] = ph_issue; o[5] = ph_store;
+        for (int i = 0; i < 8; ++i) o[6 + i] = ph_vm[i];
+        o[14] = __builtin_amdgcn_s_memtime() - clk0; o[15] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+#endif
+#undef STAMP
 }
+
+
+#if defined(SLAMHIP_EXPERIMENTS) || defined(DD_TIMING_16)
+#include "ekf_syrk_exp_streams.inc"
+#endif
 
 // As dd_stream: processes list[slot], list[slot + nper], ... while they are off-diagonal; NCH = kp / 16 (>= 2).  On
 // entry gx/gy hold the request for chunk 0 of the first tile.  On return `slot` is the first unprocessed position;
@@ -776,7 +966,7 @@ __device__ __forceinline__ void dd_stream_dma(DdCtx& c, const int2* __restrict__
 // The P tile is streamed: read once, written once per launch.  Its loads and stores carry the non-temporal policy
 // (aux = 2), which leaves the XCD's L2 to the panels (one-box A/B: loads -1.5 %, stores -2 %, both -3.5 % of the
 // kernel's time, and the kernels that follow it gain as much again).
-template <int NCH, int POFF, int AUXL = 2, int AUXS = 2>
+template <bool DBG, int NCH, int POFF, int AUXL = 2, int AUXS = 2>
 __device__ __forceinline__ void dd_stream_b(DdCtx& c, const int2* __restrict__ list, int L, int nper, int& slot, char* sm,
                                             f32x4& gx, f32x4& gy) {
     auto fetch = [&](int sl) { return sl < L ? list[sl] : make_int2(-1, -1); };
@@ -789,7 +979,7 @@ __device__ __forceinline__ void dd_stream_b(DdCtx& c, const int2* __restrict__ l
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
     float pold[2][16];
-    fill_lds_b(c, sm, 0, gx, gy);
+    fill_lds_b<DBG>(c, sm, 0, gx, gy);
     __syncthreads();
     request_chunk_b(c, tile, 1, gx, gy);
     int base = 0;
@@ -798,18 +988,18 @@ __device__ __forceinline__ void dd_stream_b(DdCtx& c, const int2* __restrict__ l
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             const int pb = (base + ch) & 1;
-            if (ch == PCH) load_p_mfma<AUXL>(c, tile.x * TILE, tile.y * TILE, pold);
-            mfma_chunk_b(c, sm, pb, acc);
+            if (ch == PCH && !(DBG && (c.dbg & 4))) load_p_mfma<AUXL>(c, tile.x * TILE, tile.y * TILE, pold);
+            mfma_chunk_b<DBG>(c, sm, pb, acc);
             if (ch < NCH - 1) {
-                fill_lds_b(c, sm, pb ^ 1, gx, gy);                  // chunk ch + 1 of this tile
+                fill_lds_b<DBG>(c, sm, pb ^ 1, gx, gy);                  // chunk ch + 1 of this tile
                 __syncthreads();
                 if (ch + 2 < NCH) request_chunk_b(c, tile, ch + 2, gx, gy);
                 else if (next_off) request_chunk_b(c, next, 0, gx, gy);
             } else {
-                if (next_off) fill_lds_b(c, sm, pb ^ 1, gx, gy);    // chunk 0 of the next tile
+                if (next_off) fill_lds_b<DBG>(c, sm, pb ^ 1, gx, gy);    // chunk 0 of the next tile
                 __syncthreads();
                 if (next_off) request_chunk_b(c, next, 1, gx, gy);
-                store_p_mfma<AUXS>(c, tile.x * TILE, tile.y * TILE, pold, acc);
+                if (!(DBG && (c.dbg & 1))) store_p_mfma<AUXS>(c, tile.x * TILE, tile.y * TILE, pold, acc);
             }
         }
         slot += nper;
@@ -825,11 +1015,12 @@ __device__ __forceinline__ void dd_stream_b(DdCtx& c, const int2* __restrict__ l
 // wave that moves on to the next tile's MFMAs lets its stores drain behind them.  The first tile is
 // peeled so that the loop header sees the same load/store history on both of its incoming edges and the
 // compiler can emit counted vmcnt waits for the panel chunk instead of vmcnt(0).
-template <int STREAM = 0, int POFF = 2, bool BF = false>   // STREAM = chunks per tile (2..4) for the streaming path, 0: dd_tile only; BF: split-bf16 streaming path where kp allows
+template <bool DBG, int STREAM = 0, int POFF = 2, bool BF = false>   // STREAM = chunks per tile (2..4) for the streaming path, 0: dd_tile only; BF: split-bf16 streaming path where kp allows
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void downdate_f32_mfma(float* __restrict__ P, int ld, int n,
                                                                  const float* __restrict__ X, const float* __restrict__ Y,
                                                                  int pitch, int kp, const int2* __restrict__ tiles, int L,
-                                                                 const int32_t* __restrict__ status, int xflags,
+                                                                 const int32_t* __restrict__ status, int dbg,
+                                                                 unsigned long long* __restrict__ prof,
                                                                  const int32_t* __restrict__ dcount, int joseph,
                                                                  const char* __restrict__ img, int img_nch,
                                                                  unsigned* __restrict__ claim,        // non-null: the grid claims its tiles (dd_stream_p<DYN>)
@@ -847,7 +1038,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // provably wave-uniform
     DdCtx c;
     c.side = side; c.side_n = side_n;
-    c.P = P; c.X = X; c.Y = Y; c.ld = ld; c.pitch = pitch; c.kp = kp; c.xflags = xflags;
+    c.P = P; c.X = X; c.Y = Y; c.ld = ld; c.pitch = pitch; c.kp = kp; c.dbg = dbg & 0xff; c.xflags = dbg >> 8;      // (experiments build: bit 64 = no Y image loads)
     c.img = img; c.img_nch = img_nch;
     c.nchunks = (kp + KC - 1) / KC;                           // kp is a multiple of 16: the last chunk may be half
     c.wr = wave & 1;                  // row half of the tile
@@ -858,11 +1049,13 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
     c.cl = lane >> 3;
     c.srow = tid >> 3;                // staging rows srow, srow + 64
     c.sc4 = tid & 7;
+    c.t_head = c.t_wait = c.t_epi = c.t_total = 0;
+    const unsigned long long rt0 = DBG ? __builtin_amdgcn_s_memrealtime() : 0, mt0 = DBG ? __builtin_amdgcn_s_memtime() : 0;
     const int xcd = blockIdx.x & 7;
     const int rk = blockIdx.x >> 3;
     const int nper = gridDim.x >> 3;
     // persistent launches only (fewer workgroups than tiles): the second half of the grid starts ~3.4 us late (speed only)
-    if (nper < L && rk >= (nper >> 1) && !claim) __builtin_amdgcn_s_sleep(127);
+    if (nper < L && rk >= (nper >> 1) && !(c.xflags & 1) && !claim) __builtin_amdgcn_s_sleep(127);
     const int2* list = tiles + (size_t)xcd * L;
     float* sD = &smem[0][0][0][0] + wave * (2 * 32 * SP);                   // per-wave scratches alias the panel buffers
     float* sV = sD + 32 * SP;
@@ -876,33 +1069,67 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
         // the product's launch at 80 <= k <= 128: a persistent grid that CLAIMS its tiles (dd_stream_p<DYN>)
         char* sm = reinterpret_cast<char*>(&smem[0][0][0][0]);
         unsigned* ctr = claim + 16 * xcd;                     // one counter per XCD list, 64 bytes apart
-        if (tile.x != tile.y && !(c.xflags & 512)) {         // the LDS-DMA pipeline, chunks two steps ahead (SLAMHIP_X bit 512: round 3's register-staged pipeline below)
-            static_assert(sizeof(smem) == 3 * DMA_BUF, "three 24 KB chunk buffers");
+#ifdef SLAMHIP_EXPERIMENTS
+        if (tile.x != tile.y && (c.xflags & 2097152) && kp == 8 * KB) {     // the 16x16x32 timing experiment (P unchanged)
+            char* cw = reinterpret_cast<char*>(&dma_claim_word[0]);
+            dd_stream_dma16<8, 2>(c, list, L, nper, slot, sm, ctr, wave, cw);
+            return;                                                          // (diagonal tiles skipped: P stays what it was everywhere)
+        } else
+        if (tile.x != tile.y && (c.xflags & 32768)) {        // SLAMHIP_X bit 32768 (experiments build): the LDS-DMA pipeline without a barrier per step
             char* cw = reinterpret_cast<char*>(&dma_claim_word[0]);
             switch (kp / KB) {
-                case 8: dd_stream_dma<8, DD_DMA_PCH8>(c, list, L, nper, slot, sm, ctr, wave, cw); break;
-                case 7: dd_stream_dma<7, 2>(c, list, L, nper, slot, sm, ctr, wave, cw); break;
-                case 6: dd_stream_dma<6, 2>(c, list, L, nper, slot, sm, ctr, wave, cw); break;
-                default: dd_stream_dma<5, 2>(c, list, L, nper, slot, sm, ctr, wave, cw); break;
+                case 8: dd_stream_dma2<DBG, 8, 2>(c, list, L, nper, slot, sm, ctr, wave, cw); break;
+                case 7: dd_stream_dma2<DBG, 7, 2>(c, list, L, nper, slot, sm, ctr, wave, cw); break;
+                case 6: dd_stream_dma2<DBG, 6, 2>(c, list, L, nper, slot, sm, ctr, wave, cw); break;
+                default: dd_stream_dma2<DBG, 5, 2>(c, list, L, nper, slot, sm, ctr, wave, cw); break;
+            }
+        } else
+#endif
+#ifdef DD_TIMING_16
+        if (tile.x != tile.y && kp == 8 * KB) {
+            char* cw = reinterpret_cast<char*>(&dma_claim_word[0]);
+            dd_stream_dma16<8, 2>(c, list, L, nper, slot, sm, ctr, wave, cw);
+            return;                                            // (diagonal tiles skipped: P stays what it was everywhere)
+        } else
+#endif
+        if (tile.x != tile.y && !(c.xflags & 512)) {         // the LDS-DMA pipeline, chunks two steps ahead (SLAMHIP_X bit 512: round 3's register-staged pipeline below)
+            static_assert(sizeof(smem) == 3 * DMA_BUF, "three 24 KB chunk buffers");
+#ifdef SLAMHIP_EXPERIMENTS
+#define DMA_PROF prof
+#else
+#define DMA_PROF nullptr
+#endif
+            char* cw = reinterpret_cast<char*>(&dma_claim_word[0]);
+            switch (kp / KB) {
+                case 8: dd_stream_dma<DBG, 8, DD_DMA_PCH8>(c, list, L, nper, slot, sm, ctr, wave, cw, DMA_PROF); break;
+                case 7: dd_stream_dma<DBG, 7, 2>(c, list, L, nper, slot, sm, ctr, wave, cw, DMA_PROF); break;
+                case 6: dd_stream_dma<DBG, 6, 2>(c, list, L, nper, slot, sm, ctr, wave, cw, DMA_PROF); break;
+                default: dd_stream_dma<DBG, 5, 2>(c, list, L, nper, slot, sm, ctr, wave, cw, DMA_PROF); break;
             }
         } else
         if (tile.x != tile.y) {
             switch (kp / KB) {
                 // (DD_PCH0 = 1, build-time A/B: the P tile requested at the tile's FIRST chunk instead of its second)
-                case 8: dd_stream_p<8, DD_POFF8, false, true>(c, list, L, nper, slot, sm, ctr); break;
-                case 7: dd_stream_p<7, 6 + DD_PCH0, false, true>(c, list, L, nper, slot, sm, ctr); break;
-                case 6: dd_stream_p<6, 5 + DD_PCH0, false, true>(c, list, L, nper, slot, sm, ctr); break;
-                default: dd_stream_p<5, 4 + DD_PCH0, false, true>(c, list, L, nper, slot, sm, ctr); break;
+                case 8: dd_stream_p<DBG, 8, DD_POFF8, false, true>(c, list, L, nper, slot, sm, ctr); break;
+                case 7: dd_stream_p<DBG, 7, 6 + DD_PCH0, false, true>(c, list, L, nper, slot, sm, ctr); break;
+                case 6: dd_stream_p<DBG, 6, 5 + DD_PCH0, false, true>(c, list, L, nper, slot, sm, ctr); break;
+                default: dd_stream_p<DBG, 5, 4 + DD_PCH0, false, true>(c, list, L, nper, slot, sm, ctr); break;
             }
         }
         // what is left for this workgroup: the list's diagonal tiles (fp32 pipeline, 1.3 % of the tiles), claimed one at a time
+#ifdef DD_TIMING_BASE
+        return;
+#endif
+#ifdef SLAMHIP_EXPERIMENTS
+        if (c.xflags & (1024 | 2048 | 4194304)) return;        // (switch-off experiments: P stays what it was, diagonal tiles included)
+#endif
         while (slot < L) {
             tile = list[slot];
             if (tile.x < 0) break;
             __syncthreads();                                   // every wave is done with the image buffers and the claim word
             request_chunk(c, tile, 0, gx, gy);
-            if (tile.x != tile.y) dd_tile<false>(c, tile, make_int2(-1, -1), smem, sD, sV, gx, gy);
-            else dd_tile<true>(c, tile, make_int2(-1, -1), smem, sD, sV, gx, gy);
+            if (tile.x != tile.y) dd_tile<false, DBG>(c, tile, make_int2(-1, -1), smem, sD, sV, gx, gy);
+            else dd_tile<true, DBG>(c, tile, make_int2(-1, -1), smem, sD, sV, gx, gy);
             if (tid == 0)
                 lds_store_u32(sm + CLAIM_OFF, __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             __syncthreads();
@@ -916,20 +1143,23 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
         if (img) {                     // the W1 kernel left the panel pre-split, as this path's LDS image
             switch (kp / KB) {
                 case 8:
-                    dd_stream_p<8, 7>(c, list, L, nper, slot, sm); break;
-                case 7: dd_stream_p<7, 6>(c, list, L, nper, slot, sm); break;
-                case 6: dd_stream_p<6, 5>(c, list, L, nper, slot, sm); break;
-                default: dd_stream_p<5, 4>(c, list, L, nper, slot, sm); break;
+#ifdef SLAMHIP_EXPERIMENTS
+                    if (DBG && (c.dbg & 128)) { dd_stream_p<DBG, 16, 15, true>(c, list, L, nper, slot, sm); break; }
+#endif
+                    dd_stream_p<DBG, 8, 7>(c, list, L, nper, slot, sm); break;
+                case 7: dd_stream_p<DBG, 7, 6>(c, list, L, nper, slot, sm); break;
+                case 6: dd_stream_p<DBG, 6, 5>(c, list, L, nper, slot, sm); break;
+                default: dd_stream_p<DBG, 5, 4>(c, list, L, nper, slot, sm); break;
             }
         } else {
         request_chunk_b(c, tile, 0, gx[0], gy[0]);
         // (the P tile is requested at the start of the tile's second chunk: one-box A/B of offsets NCH-4 / NCH-2 /
         //  NCH-1 gave 0.411 / 0.408 / 0.402 ms)
         switch (kp / KB) {
-            case 8: dd_stream_b<8, 7>(c, list, L, nper, slot, sm, gx[0], gy[0]); break;
-            case 7: dd_stream_b<7, 6>(c, list, L, nper, slot, sm, gx[0], gy[0]); break;
-            case 6: dd_stream_b<6, 5>(c, list, L, nper, slot, sm, gx[0], gy[0]); break;
-            default: dd_stream_b<5, 4>(c, list, L, nper, slot, sm, gx[0], gy[0]); break;
+            case 8: dd_stream_b<DBG, 8, 7>(c, list, L, nper, slot, sm, gx[0], gy[0]); break;
+            case 7: dd_stream_b<DBG, 7, 6>(c, list, L, nper, slot, sm, gx[0], gy[0]); break;
+            case 6: dd_stream_b<DBG, 6, 5>(c, list, L, nper, slot, sm, gx[0], gy[0]); break;
+            default: dd_stream_b<DBG, 5, 4>(c, list, L, nper, slot, sm, gx[0], gy[0]); break;
         }
         }
         tile = slot < L ? list[slot] : make_int2(-1, -1);
@@ -941,17 +1171,17 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
     // off-diagonal tiles first (the lists keep the diagonal ones at their end)
     if (STREAM >= 2 && tile.x != tile.y && c.nchunks == STREAM) {
         slot = rk;
-        dd_stream<(STREAM >= 2 ? STREAM : 2), POFF>(c, list, L, nper, slot, smem, gx, gy);
+        dd_stream<DBG, (STREAM >= 2 ? STREAM : 2), POFF>(c, list, L, nper, slot, smem, gx, gy);
         tile = slot < L ? list[slot] : make_int2(-1, -1);
         slot += nper;
         next = slot < L ? list[slot] : make_int2(-1, -1);
     } else if (tile.x != tile.y) {
-        dd_tile<false>(c, tile, next, smem, sD, sV, gx, gy);               // peeled first tile
+        dd_tile<false, DBG>(c, tile, next, smem, sD, sV, gx, gy);               // peeled first tile
         while (next.x >= 0 && next.x != next.y) {
             tile = next;
             slot += nper;
             next = slot < L ? list[slot] : make_int2(-1, -1);
-            dd_tile<false>(c, tile, next, smem, sD, sV, gx, gy);
+            dd_tile<false, DBG>(c, tile, next, smem, sD, sV, gx, gy);
         }
         tile = next;
         slot += nper;
@@ -959,14 +1189,22 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(4, 4))
     }
     // diagonal tiles: same pipeline, element-wise masks where a 4-group straddles the diagonal
     while (tile.x >= 0) {
-        dd_tile<true>(c, tile, next, smem, sD, sV, gx, gy);
+        dd_tile<true, DBG>(c, tile, next, smem, sD, sV, gx, gy);
         tile = next;
         slot += nper;
         next = slot < L ? list[slot] : make_int2(-1, -1);
     }
+    if (DBG && prof && lane == 0) {                   // per wave: panel waits, lifetime (10 ns), epilogue, lifetime (clocks)
+        unsigned long long* o = prof + ((size_t)blockIdx.x * NWAVE + wave) * 4;
+        o[0] = c.t_head + c.t_wait; o[1] = __builtin_amdgcn_s_memrealtime() - rt0; o[2] = c.t_epi;
+        o[3] = __builtin_amdgcn_s_memtime() - mt0;
+    }
 }
 
 
+#ifdef SLAMHIP_EXPERIMENTS
+#include "ekf_syrk_exp_half.inc"
+#endif
 
 // ---- fp64 down-date on the fp64 matrix cores ------------------------------------------
 // 64 x 64 tile per 256-thread workgroup, wave (wr, wc) owns rows 32 wr.., columns 32 wc.. as 2 x 2 blocks of
@@ -1084,7 +1322,7 @@ __global__ __launch_bounds__(256) void downdate_f64_mfma(double* __restrict__ P,
 //          split-bf16 path (one-box A/B tools/gpu_order.sh: -3 %; with one workgroup per tile: -11 %).
 void build_tile_order(int T, std::vector<int2>& out, int order) {
     constexpr int NX = 8;
-    constexpr int SR = 4;              // tile rows per super-row
+    const int SR = slam_exp_env("SLAMHIP_SR", 4);      // tile rows per super-row (experiments build only)
     const int nsr = (T + SR - 1) / SR;
     std::vector<std::vector<int2>> lists(NX);
     if (order == 2) {
@@ -1132,6 +1370,23 @@ int ensure_tile_order(slam_ekf* h, int T) {
     std::vector<int2> order, orderB, orderH;
     build_tile_order(T, order, 0);
     build_tile_order(T, orderB, 2);
+#ifdef SLAMHIP_EXPERIMENTS
+    {   // the half-tile experiment's lists: the band-major order with every off-diagonal tile as its two 64-row halves
+        std::vector<std::vector<int2>> lists(8);
+        for (int J = 0; J < T; ++J)
+            for (int I = J + 1; I < T; ++I) {
+                const int r = I % 16;
+                auto& l = lists[r < 8 ? r : 15 - r];
+                l.push_back(make_int2(I, 2 * J));
+                l.push_back(make_int2(I, 2 * J + 1));
+            }
+        size_t LH = 1;
+        for (auto& l : lists) LH = std::max(LH, l.size());
+        orderH.assign(LH * 8, make_int2(-1, -1));
+        for (int x = 0; x < 8; ++x)
+            for (size_t i = 0; i < lists[x].size(); ++i) orderH[x * LH + i] = lists[x][i];
+    }
+#endif
     const size_t total = order.size() + orderB.size() + orderH.size();
     HIP_TRY(hipStreamSynchronize(h->stream));          // earlier down-dates may still read the old list
     if ((int)total > h->tiles_cap) {
@@ -1183,6 +1438,9 @@ __global__ __launch_bounds__(512) void tile_copy_floor_kernel(T* __restrict__ P,
 }  // namespace
 
 // out = {milliseconds of the fastest pass, its launch form: 0 = one workgroup per tile / 1 = persistent}.  Synchronises.
+#ifdef SLAMHIP_EXPERIMENTS
+#include "ekf_syrk_exp_copy.inc"
+#endif
 
 int launch_copy_floor(slam_ekf* h, int reps, double out[2]) {
     const int n = 3 + 2 * h->N;
@@ -1197,6 +1455,18 @@ int launch_copy_floor(slam_ekf* h, int reps, double out[2]) {
     const long long bytes = ntiles * (long long)E * E * (long long)h->esz, units = (bytes + 65535) >> 16;
     auto one_pass = [&](int form) {
         const long long grid = form == 0 ? units : std::min<long long>(units, 2 * h->num_cus);
+#ifdef SLAMHIP_EXPERIMENTS
+        if (h->dtype == SLAM_F32 && slam_exp_env("SLAMHIP_COPY_LAG", 0) == 2) {
+            if (ensure_tile_order(h, (int)T) == SLAM_OK)
+                hipLaunchKernelGGL(tile_copy_mfma_kernel, dim3(8 * (2 * h->num_cus / 8)), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld,
+                                   (const int2*)h->tiles + h->tilesB_off, h->tilesB_len, (float*)h->Pside, h->npad / 2);
+            return;
+        }
+        if (h->dtype == SLAM_F32 && slam_exp_env("SLAMHIP_COPY_LAG", 0)) {
+            hipLaunchKernelGGL(tile_copy_lag_kernel<float>, dim3((unsigned)std::min<long long>(units, 2 * h->num_cus)), dim3(512), 0, h->stream, (float*)h->P, bytes, 1.0f);
+            return;
+        }
+#endif
         if (h->dtype == SLAM_F32)
             hipLaunchKernelGGL(tile_copy_floor_kernel<float>, dim3((unsigned)grid), dim3(512), 0, h->stream, (float*)h->P, bytes, 1.0f);
         else
@@ -1247,45 +1517,91 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
     KTimer t(h, SLAM_K_SYRK);
     if (h->dtype == SLAM_F32) {
         // persistent: two workgroups per CU (VGPR- and LDS-limited residency), never more than there are tiles
-        int per_xcd = 2 * h->num_cus / 8;
+        // persistent: two workgroups per CU (VGPR- and LDS-limited residency), never more than there are tiles
+        int per_xcd = slam_exp_env("SLAMHIP_PER_CU", 2) * h->num_cus / 8;      // (experiments build: 1 = one workgroup per CU)
         if (per_xcd > h->tiles_len) per_xcd = h->tiles_len;
         if (per_xcd < 1) per_xcd = 1;
+#ifdef SLAMHIP_EXPERIMENTS
+        if (h->debug_flags & 32) {  // timing experiments on the split-bf16 path (1 no stores, 2 no MFMAs, 4 no P loads, 16 no split), launched like the product's
+            const bool bandB = slam_exp_env("SLAMHIP_ORDER", 2) != 0;
+            const int2* lst = bandB ? (const int2*)h->tiles + h->tilesB_off : (const int2*)h->tiles;
+            const int L = bandB ? h->tilesB_len : h->tiles_len;
+            int wgs = slam_exp_env("SLAMHIP_WGS", L);
+            if (wgs > L) wgs = L;
+            hipLaunchKernelGGL((downdate_f32_mfma<true, 4, 3, true>), dim3(8 * wgs), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,
+                               (const float*)X, (const float*)Y, pitch, kp_total, lst, L,
+                               h->d_status, h->debug_flags & ~32, (unsigned long long*)nullptr, dcount, joseph, IMGARGS);
+        }
+        else if (h->debug_flags)      // timing experiments only (SLAMHIP_DEBUG): parts of the kernel switched off
+            hipLaunchKernelGGL(downdate_f32_mfma<true>, dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,
+                               (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
+                               h->d_status, h->debug_flags, (unsigned long long*)h->dd_prof, dcount, joseph, IMGARGS);
+        else
+#endif
         if (!(h->xflags & 4) && kp_total > 32 && kp_total <= 128) {     // (observe(): kp_total is an upper bound; the kernel falls back to dd_tile if the real chunk count differs)
             // streaming (tile-boundary-free) path for the off-diagonal tiles, one instantiation per chunk count
             const int nch = (kp_total + KC - 1) / KC;
 // (P tile requested three chunks before the epilogue at four chunks per tile, two otherwise: one-box A/B, tools/gpu_abx.sh:
             //  offsets 1 / 2 / 3 / 4 gave 0.449 / 0.440 / 0.434 / 0.453 ms)
 #define DD_LAUNCH_STREAM4()                                                                                            \
-    hipLaunchKernelGGL((downdate_f32_mfma<4, 3>), dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, \
+    hipLaunchKernelGGL((downdate_f32_mfma<false, 4, 3>), dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, \
                        n, (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,       \
-                       h->d_status, h->xflags, dcount, joseph, IMGARGS)
+                       h->d_status, h->xflags << 8, (unsigned long long*)nullptr, dcount, joseph, IMGARGS)
 #define DD_LAUNCH_STREAM(NCH)                                                                                          \
-    hipLaunchKernelGGL((downdate_f32_mfma<NCH>), dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, \
+    hipLaunchKernelGGL((downdate_f32_mfma<false, NCH>), dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, \
                        n, (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,       \
-                       h->d_status, h->xflags, dcount, joseph, IMGARGS)
+                       h->d_status, h->xflags << 8, (unsigned long long*)nullptr, dcount, joseph, IMGARGS)
             if (nch >= 3 && !joseph && !(h->xflags & 8)) {         // split-bf16 path (SLAMHIP_X bit 8 switches it off)
                 // HBM-bound: ONE workgroup per tile, handed out by the hardware dispatcher in the band-major order.
                 // Measured against the persistent grid of 2 workgroups per CU walking the super-row lists (one-box
                 // A/B, tools/gpu_r2b.sh): 0.341 against 0.386 ms.  A static split ends with its slowest workgroup (the
                 // CUs do not get equal shares of the memory system; tools/micro_tilewalk.hip shows the same 17 % on a
-                // bare read + rewrite of the tiles); the dispatcher keeps every CU busy to the end.
-                const int2* lst = (const int2*)h->tiles + h->tilesB_off;        // the band-major order
-                const int L = h->tilesB_len;
+                // bare read + rewrite of the tiles); the dispatcher keeps every CU busy to the end.  SLAMHIP_WGS =
+                // workgroups per XCD list (64 = two per CU) and SLAMHIP_ORDER=0 restore the old launch for A/B runs.
+                const bool bandB = slam_exp_env("SLAMHIP_ORDER", 2) != 0;
+                const int2* lst = bandB ? (const int2*)h->tiles + h->tilesB_off : (const int2*)h->tiles;
+                const int L = bandB ? h->tilesB_len : h->tiles_len;
                 // Round 3: a persistent grid (two workgroups per CU) that CLAIMS its tiles from per-XCD counters in list
-                // order: the dispatcher's load balance without a workgroup launch, an exposed first panel chunk and a store
-                // drain per tile.  (Without the pre-split image -- a caller outside the update -- one workgroup per tile.)
-                const bool dyn = img != nullptr;
-                int wgs = dyn ? per_xcd : L;
+                // order (dd_stream_p<DYN>): the dispatcher's load balance without a workgroup launch, an exposed first
+                // panel chunk and a store drain per tile.  SLAMHIP_WGS (experiments build): n > 0 = the static persistent
+                // grid with n workgroups per list, 0 = one workgroup per tile from the dispatcher (round 2's launch).
+                const int wgs_env = slam_exp_env("SLAMHIP_WGS", -1);
+                const bool dyn = wgs_env < 0 && img != nullptr;
+                int wgs = dyn ? per_xcd : (wgs_env > 0 ? wgs_env : L);
                 if (wgs > L) wgs = L;
                 if (wgs < 1) wgs = 1;
-                if (dyn) {                 // (the counters were zeroed by the W1 kernel that wrote the image: ekf_update.hip)
-                    hipLaunchKernelGGL((downdate_f32_mfma<4, 3, true>), dim3(8 * wgs), dim3(NTHREADS), 0, h->stream,
-                                       (float*)h->P, h->ld, n, (const float*)X, (const float*)Y, pitch, kp_total, lst, L,
-                                       h->d_status, h->xflags, dcount, joseph, IMGARGS_CLAIM);
+#ifdef SLAMHIP_EXPERIMENTS
+                if (dyn && slam_exp_env("SLAMHIP_SP", 0)) {        // the software-pipelined one-workgroup-per-CU probe (timing only: P unchanged)
+                    const int per = h->num_cus / 8;
+                    hipLaunchKernelGGL(downdate_f32_sp, dim3(8 * per), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, lst, L, h->d_status,
+                                       dcount, (const char*)img, h->kcap / 16, (float*)h->Pside, h->npad / 2);
                 } else
-                hipLaunchKernelGGL((downdate_f32_mfma<4, 3, true>), dim3(8 * wgs), dim3(NTHREADS), 0, h->stream,
+                if (dyn && slam_exp_env("SLAMHIP_HALF", 0)) {      // the half-tile experiment (off-diagonal tiles only: WRONG results)
+                    // SLAMHIP_HALF: 1 = as written (spills 6 registers), 2 = without stores, 3 = the P tile's second row block late
+                    // (SPLITP), 4 = three workgroups per CU (170 registers)
+                    const int hv = slam_exp_env("SLAMHIP_HALF", 0);
+                    const int per = (hv == 4 ? 3 : 4) * h->num_cus / 8;
+                    auto kern = hv == 2 ? downdate_f32_half<true, false, 4> : hv == 3 ? downdate_f32_half<false, true, 4>
+                              : hv == 4 ? downdate_f32_half<false, false, 3> : downdate_f32_half<false, false, 4>;
+                    hipLaunchKernelGGL(kern, dim3(8 * per), dim3(256), 0, h->stream, (float*)h->P, h->ld,
+                                       (const int2*)h->tiles + h->tilesH_off, h->tilesH_len, h->d_status, dcount, kp_total, (const char*)img,
+                                       h->kcap / 16, h->dd_claim, (float*)h->Pside, h->npad / 2);
+                } else
+#endif
+                if (dyn) {                 // (the counters were zeroed by the W1 kernel that wrote the image: ekf_update.hip)
+                    hipLaunchKernelGGL((downdate_f32_mfma<false, 4, 3, true>), dim3(8 * wgs), dim3(NTHREADS), 0, h->stream,
+                                       (float*)h->P, h->ld, n, (const float*)X, (const float*)Y, pitch, kp_total, lst, L,
+                                       h->d_status, h->xflags << 8,
+#ifdef SLAMHIP_EXPERIMENTS
+                                       (unsigned long long*)h->dd_prof,
+#else
+                                       (unsigned long long*)nullptr,
+#endif
+                                       dcount, joseph, IMGARGS_CLAIM);
+                } else
+                hipLaunchKernelGGL((downdate_f32_mfma<false, 4, 3, true>), dim3(8 * wgs), dim3(NTHREADS), 0, h->stream,
                                    (float*)h->P, h->ld, n, (const float*)X, (const float*)Y, pitch, kp_total, lst, L,
-                                   h->d_status, h->xflags, dcount, joseph, IMGARGS);
+                                   h->d_status, h->xflags << 8, (unsigned long long*)nullptr, dcount, joseph, IMGARGS);
             }
             else if (nch == 4) DD_LAUNCH_STREAM4();
             else if (nch == 3) DD_LAUNCH_STREAM(3);
@@ -1294,12 +1610,13 @@ int launch_downdate(slam_ekf* h, int kp_total, const void* X, const void* Y, int
 #undef DD_LAUNCH_STREAM4
         }
         else
-            hipLaunchKernelGGL(downdate_f32_mfma<>, dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,
+            hipLaunchKernelGGL(downdate_f32_mfma<false>, dim3(8 * per_xcd), dim3(NTHREADS), 0, h->stream, (float*)h->P, h->ld, n,
                                (const float*)X, (const float*)Y, pitch, kp_total, (const int2*)h->tiles, h->tiles_len,
-                               h->d_status, h->xflags, dcount, joseph, IMGARGS);
+                               h->d_status, h->xflags << 8, (unsigned long long*)nullptr, dcount, joseph, IMGARGS);
     } else {
-        const int2* lst = (const int2*)h->tiles;
-        const int L = h->tiles_len;
+        const bool bandB = slam_exp_env("SLAMHIP_ORDER64", 0) == 2;      // experiments build only (speed only)
+        const int2* lst = bandB ? (const int2*)h->tiles + h->tilesB_off : (const int2*)h->tiles;
+        const int L = bandB ? h->tilesB_len : h->tiles_len;
         hipLaunchKernelGGL(downdate_f64_mfma, dim3(8 * L), dim3(256), 0, h->stream, (double*)h->P, h->ld, n,
                            (const double*)X, (const double*)Y, pitch, kp_total, lst, L,
                            h->d_status, dcount, joseph, joseph ? k16 : kp_total, (double*)h->Pside, h->npad / 2);

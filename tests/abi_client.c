@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include "slamhip.h"
+#include "slamhip_diag.h"
 
 static int failures = 0;
 

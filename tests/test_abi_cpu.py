@@ -1,6 +1,7 @@
 """CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol
-that include/slamhip.h declares, carries no torch / oracle dependency, and fails loudly
-(never falls back to a CPU path) when no device is present."""
+that include/slamhip.h (the boundary) and include/slamhip_diag.h (measurement and introspection)
+declare, carries no torch / oracle dependency, and fails loudly (never falls back to a CPU path)
+when no device is present."""
 import ctypes
 import os
 import re
@@ -11,12 +12,21 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "slamhip.h")
+DIAG_HEADER = os.path.join(ROOT, "include", "slamhip_diag.h")
 
 
-def declared_symbols():
-    text = open(HEADER).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(slam_[a-z0-9_]+)\s*\(", text)))
+def declared_symbols(headers=(HEADER, DIAG_HEADER)):
+    syms = set()
+    for path in headers:
+        text = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+        syms |= set(re.findall(r"\b(slam_[a-z0-9_]+)\s*\(", text))
+    return sorted(syms)
+
+
+def test_the_boundary_header_stays_small():
+    """diagnostics live in slamhip_diag.h; the boundary itself is at most 60 entry points."""
+    assert len(declared_symbols((HEADER,))) <= 60
+    assert not set(declared_symbols((HEADER,))) & set(declared_symbols((DIAG_HEADER,)))
 
 
 def test_header_declares_the_hot_path():

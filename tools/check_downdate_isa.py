@@ -2,7 +2,7 @@
 """Build-time check of the down-date's LDS-DMA pipeline (csrc/ekf_syrk.hip: dd_stream_dma): its hand-counted
 s_waitcnt vmcnt(N) are right only if, between two barriers, a step's three chunk requests (buffer_load ... lds) stand IN FRONT
 of the P tile's 32 loads / 32 stores in the wave's queue.  Compiles the file to assembly (hipcc -S, the Makefile's flags) and
-looks at every stretch between two s_barrier of the product kernel downdate_f32_mfma<false, 4, 3, true>:
+looks at every stretch between two s_barrier of the product kernel downdate_f32_mfma<4, 3, true>:
   * a stretch with one chunk request (a step of the pipeline) STARTS with its three pieces: no P load / store (a buffer operation
     without `lds`) in front of them (where the kernel's inlined variants meet, the text behind them may run into another path);
   * both orders the counts rely on exist: [3 chunk pieces][32 P stores] and [3 chunk pieces][32 P loads].
@@ -11,7 +11,7 @@ Exit code 0 and 'ok ...' when the order holds."""
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "downdate_f32_mfmaILb0ELi4ELi3ELb1EE"
+KERNEL = "downdate_f32_mfmaILi4ELi3ELb1EE"
 
 
 def listing():
