@@ -333,7 +333,7 @@ def _fastslam_regimes(ctx, peers, full):
             for b0 in range(k0, k0 + count, KB):       # slam_pf_step_auto_batch: runs of steps that cannot resample as one launch
                 kk = range(b0, min(b0 + KB, k0 + count))
                 batch = pkg.PFShard.prepare_batch([(V, 0.0)] * len(kk), [obs[k] for k in kk], force)
-                pf.step_async_batch(batch, 4.0, Qs, 0.025, Rs)
+                pf.step_async_batch(batch, 4.0, Qs, 0.025, Rs, persistent=True)     # (the bench has the device to itself)
 
         def fresh(k):
             """Every regime starts from a CLEAN filter at the vehicle's pose before step k: every particle there, the map at

@@ -324,11 +324,14 @@ int slam_pf_step_auto(slam_pf_t h, double V, double G, double wheelbase, const d
  * (VG[2k], VG[2k+1]) = (V, G); its m[k] observations are the (range, bearing) pairs at z + 2 zstride k, their landmark
  * ids at ids + zstride k (m[k] <= zstride); force[k] as slam_pf_step_auto's force (force == NULL: the Neff rule at every
  * step).  wheelbase, Q, dt, R, neff_frac, proposal are common to the K steps.
- * Runs of at least four consecutive steps that CANNOT resample (force[k] == 0) go, where the filter allows it -- fp32, the
- * whole filter on this shard, proposal = 0, m[k] <= 32, at most 2048 landmarks and 1024 particles per compute unit of the
- * device -- as persistent launches of up to 16 steps (csrc/pf_batch.hip): poses and weights stay in registers between
- * the steps, every workgroup reduces the step's statistics itself, the statistics tail of a step runs under the next step's
- * sweep.  Every other step is enqueued as slam_pf_step_auto enqueues it, as is everything when flags bit 0 is set.
+ * Runs of at least four consecutive steps that CANNOT resample (force[k] == 0) go -- where the caller allows it (flags bit 1)
+ * and the filter does: fp32, the whole filter on this shard, proposal = 0, m[k] <= 32, at most 2048 landmarks and 1024
+ * particles per compute unit of the device -- as persistent launches of up to 16 steps (csrc/pf_batch.hip): poses and
+ * weights stay in registers between the steps, every workgroup reduces the step's statistics itself, the statistics tail of
+ * a step runs under the next step's sweep.  The persistent grid takes every compute unit whole and its workgroups wait for
+ * each other: the caller sets flags bit 1 only when nothing else (another filter's kernels, another process) keeps the
+ * device's compute units busy meanwhile -- a grid that cannot become co-resident gives up after 2 s and the filter is dead.
+ * Every other step is enqueued as slam_pf_step_auto enqueues it.
  * *enqueued (may be NULL): the steps taken -- less than K only together with SLAM_PF_HALTED (sharded halting flow: resolve
  * the halt, call again with the remaining steps). */
 int slam_pf_step_auto_batch(slam_pf_t h, int K, const double* VG, double wheelbase, const double Q[4], double dt,

@@ -422,11 +422,12 @@ end
 """
 K `step_async!` calls as ONE (slam_pf_step_auto_batch): `controls` is K x 2 (V, G per row), `obs` a vector of K pairs `(z, ids)`
 (z 2 x m_k), `force` a vector of K integers (-1 the Neff rule, 0 never, 1 always).  Runs of at least four consecutive steps that
-cannot resample go as one persistent launch where the filter allows it; the result is the K calls' bit for bit.
+cannot resample go as one persistent launch where the filter allows it and `persistent = true` says that nothing else keeps the
+device busy meanwhile; the result is the K calls' bit for bit.
 """
 function step_async_batch!(s::PFSlamState, controls::AbstractMatrix, wheelbase::Real, Q::AbstractMatrix, dt::Real, obs::AbstractVector,
                            R::AbstractMatrix; neff_frac::Real = 0.75, force::AbstractVector = fill(-1, length(obs)),
-                           proposal::Bool = false, one_by_one::Bool = false)
+                           proposal::Bool = false, persistent::Bool = false)
     K = length(obs)
     ms = Int32[size(o[1], 2) for o in obs]
     stride = max(1, maximum(ms; init = 0))
@@ -442,7 +443,7 @@ function step_async_batch!(s::PFSlamState, controls::AbstractMatrix, wheelbase::
                 (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Ptr{Int32}, Ptr{Int32}, Cint, Ptr{Cdouble},
                  Cdouble, Ptr{Int32}, Cint, Cint, Ref{Cint}),
                 s.handle, K, vg, wheelbase, colmajor4(Q), dt, zz, ii, ms, stride, colmajor4(R), neff_frac,
-                Vector{Int32}(force), proposal ? 1 : 0, one_by_one ? 1 : 0, took))
+                Vector{Int32}(force), proposal ? 1 : 0, persistent ? 2 : 0, took))
     s
 end
 

@@ -730,10 +730,10 @@ __global__ __launch_bounds__(256 * W) void pf_auto_step_way_kernel(PfAutoArgs a)
 // filter: logw0 / logw1 are this rank's two buffers (n_local values each), the other slices come from `peers`.
 template <typename T>
 __global__ __launch_bounds__(SCAN_BLOCK) void pf_auto_scan1_kernel(const T* __restrict__ logw0, const T* __restrict__ logw1,
-                                                                    int64_t n_local, int64_t n_global, const PfCtl* __restrict__ ctl,
+                                                                    int64_t n_local, int64_t n_global, PfCtl* __restrict__ ctl,
                                                                     long long seq, double* __restrict__ cdf,
-                                                                    double* __restrict__ bsum, const PfPeers* __restrict__ peers,
-                                                                    int rank, int world) {
+                                                                    double* __restrict__ bsum, double* __restrict__ boff,
+                                                                    const PfPeers* __restrict__ peers, int rank, int world) {
     if (ctl->resample_seq != seq || ctl->error != 0) return;
     __shared__ double sh16[16];
     const int64_t i = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
@@ -748,7 +748,57 @@ __global__ __launch_bounds__(SCAN_BLOCK) void pf_auto_scan1_kernel(const T* __re
     }
     const double c = block_scan1024(i < n_global ? exp((double)(T)(v - pend) - gmax) : 0.0, sh16);
     if (i < n_global) cdf[i] = c;
-    if (threadIdx.x == SCAN_BLOCK - 1) bsum[blockIdx.x] = c;
+    // Round 5: the block offsets (pf_scan2_kernel's serial order of additions) are formed ONCE, by the workgroup that finishes last,
+    // not by thread 0 of every one of the resampling kernel's workgroups: the block sum goes out write-through, then the arrival
+    // (from PF_BOFF_MIN_NB blocks on: below, thread 0 of a resampling workgroup adds the few sums up faster than this hand-over costs --
+    //  one box, every step resampling: 32768 particles 35.3 against 37.6 us, 65536 42.3 / 44.3, 131072 56.4 / 56.7, 262144 85.6 / 82.8)
+    __shared__ int s_last;
+    if ((int)gridDim.x < PF_BOFF_MIN_NB) {
+        if (threadIdx.x == SCAN_BLOCK - 1) bsum[blockIdx.x] = c;
+        return;
+    }
+    if (threadIdx.x == SCAN_BLOCK - 1) {
+        __hip_atomic_store(bsum + blockIdx.x, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = __hip_atomic_fetch_add(&ctl->arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x < 64) {
+        // 256 dependent additions at most are the cost: lane g holds the sixteen block sums of group g in registers, the groups are
+        // added one after the other (the carry goes from lane to lane); offsets[b + 1] == offsets[b] + bsum[b] exactly
+        const int nb = (int)gridDim.x, lane = threadIdx.x;
+        for (int g0 = 0; g0 < nb; g0 += 1024) {                   // (1024 blocks = 1 M particles per round; the carry goes on)
+            double vv[16], oo[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int b = g0 + 16 * lane + u;
+                vv[u] = b < nb ? __hip_atomic_load(bsum + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            }
+            double carry = g0 == 0 ? 0.0 : sh16[0], endv = 0.0;
+            const int ng = (nb - g0 + 15) / 16 < 64 ? (nb - g0 + 15) / 16 : 64;
+            for (int g = 0; g < ng; ++g) {                        // uniform
+                if (lane == g) {
+                    double run = carry;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        oo[u] = run;
+                        run += vv[u];                             // (+ 0.0 beyond nb: exact)
+                    }
+                    endv = run;
+                }
+                carry = __shfl(endv, g);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int b = g0 + 16 * lane + u;
+                if (lane < ng && b < nb) boff[b] = oo[u];
+            }
+            if (lane == 0) sh16[0] = carry;                       // (the same wave reads it in the next round)
+            if (g0 + 1024 >= nb && lane == 0) boff[nb] = carry;
+        }
+        if (lane == 0) __hip_atomic_store(&ctl->arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed
+    }
 }
 
 // Block offsets (pf_scan2_kernel's serial order, redone by every workgroup out of LDS), ancestors (pf_ancestor_kernel)
@@ -759,31 +809,35 @@ __global__ __launch_bounds__(256) void pf_auto_resample_kernel(T* pose0, T* pose
                                                                 T* logw0, T* logw1, int64_t n, int64_t first, int64_t n_global,
                                                                 const PfCtl* __restrict__ ctl,
                                                                 long long seq, const double* __restrict__ cdf,
-                                                                const double* __restrict__ bsum, int nb,
+                                                                const double* __restrict__ bsum, const double* __restrict__ boff, int nb,
                                                                 int32_t* __restrict__ anc_out, T lw_uniform,
                                                                 const PfPeers* __restrict__ peers, int rank, int world) {
     if (ctl->resample_seq != seq || ctl->error != 0) return;
     __shared__ double s_off[AUTO_NB_MAX + 1];
     __shared__ int s_tl[PF_TAB_MAX];                       // the live tables to compose (once per workgroup, not once per use)
-    for (int i = threadIdx.x; i < nb; i += 256) s_off[i] = bsum[i];
-    if (threadIdx.x < PF_TAB_MAX) s_tl[threadIdx.x] = ctl->tl_idx[threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // the same additions in the same (index) order as pf_scan2_kernel -- s_off[b + 1] == s_off[b] + bsum[b] exactly, which the
-        // two-level search below relies on -- sixteen entries at a time out of registers: written as load / store / add per entry
-        // the loop waited for an LDS round trip per block total
-        double run = 0.0;
-        for (int i0 = 0; i0 < nb; i0 += 16) {
-            double v[16];
+    if (nb >= PF_BOFF_MIN_NB) {
+        for (int i = threadIdx.x; i <= nb; i += 256) s_off[i] = boff[i];      // (formed once, by the cdf kernel's last workgroup)
+        if (threadIdx.x < PF_TAB_MAX) s_tl[threadIdx.x] = ctl->tl_idx[threadIdx.x];
+    } else {
+        for (int i = threadIdx.x; i < nb; i += 256) s_off[i] = bsum[i];
+        if (threadIdx.x < PF_TAB_MAX) s_tl[threadIdx.x] = ctl->tl_idx[threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // the same additions in the same (index) order as pf_scan2_kernel -- s_off[b + 1] == s_off[b] + bsum[b] exactly, which the
+            // search below relies on -- sixteen entries at a time out of registers
+            double run = 0.0;
+            for (int i0 = 0; i0 < nb; i0 += 16) {
+                double v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = i0 + u < nb ? s_off[i0 + u] : 0.0;
+                for (int u = 0; u < 16; ++u) v[u] = i0 + u < nb ? s_off[i0 + u] : 0.0;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                if (i0 + u < nb) s_off[i0 + u] = run;
-                run += v[u];                               // (+ 0.0 beyond nb: exact)
+                for (int u = 0; u < 16; ++u) {
+                    if (i0 + u < nb) s_off[i0 + u] = run;
+                    run += v[u];                               // (+ 0.0 beyond nb: exact)
+                }
             }
+            s_off[nb] = run;
         }
-        s_off[nb] = run;
     }
     __syncthreads();
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -800,10 +854,31 @@ __global__ __launch_bounds__(256) void pf_auto_resample_kernel(T* pose0, T* pose
     }
     int64_t lo = (int64_t)bl * SCAN_BLOCK, hi = lo + SCAN_BLOCK - 1;
     if (hi > n_global - 1) hi = n_global - 1;
-    const double boff = s_off[bl];
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (cdf[mid] + boff >= target) hi = mid; else lo = mid + 1;
+    const double bo = s_off[bl];
+    // first j in [lo, hi] with cdf[j] + bo >= target, else hi -- what ten dependent halvings found, in THREE rounds of independent
+    // probes (strides 128, 16, 1: the values are monotone, so the first probe that reaches the target brackets the answer)
+    {
+        const int64_t last = hi;
+#pragma unroll
+        for (int round = 0; round < 3; ++round) {
+            const int stride = round == 0 ? 128 : (round == 1 ? 16 : 1);
+            constexpr int NP = 15;
+            const int np = round == 2 ? 15 : 7;
+            double c[NP];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int64_t j = lo + (int64_t)stride * (u + 1) - 1;
+                c[u] = (u < np && j <= last) ? cdf[j] : 0.0;
+            }
+            int sel = np;
+#pragma unroll
+            for (int u = NP - 1; u >= 0; --u) {
+                const int64_t j = lo + (int64_t)stride * (u + 1) - 1;
+                if (u < np && (j >= last || c[u] + bo >= target)) sel = u;
+            }
+            lo += (int64_t)stride * sel;
+            if (lo > last) lo = last;
+        }
     }
     const int32_t a = (int32_t)lo;                         // the ancestor's GLOBAL id
     anc_out[p] = a;
@@ -832,7 +907,7 @@ __global__ __launch_bounds__(256) void pf_auto_resample_kernel(T* pose0, T* pose
     T pv[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) pv[r] = ldp(pose_old + (size_t)r * n + q);
-    constexpr int TB = 8;
+    constexpr int TB = 16;
     int32_t tv[TB];
 #pragma unroll
     for (int u = 0; u < TB; ++u) tv[u] = u < count ? ldt(tin + (size_t)s_tl[u] * n + q) : 0;
@@ -1034,20 +1109,20 @@ static int pf_auto_enqueue(slam_pf* h, const PfStepRec& r) {
         if (sh) { const int rcg = pf_launch_peer_gate(h, r.seq); if (rcg) return rcg; }
         PF_DISPATCH(h,
                     hipLaunchKernelGGL(pf_auto_scan1_kernel<T>, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, (const T*)h->logw2[0],
-                                       (const T*)h->logw2[1], h->n, h->n_global, (const PfCtl*)h->d_ctl, r.seq, h->d_cdf, h->d_bsum, pp,
+                                       (const T*)h->logw2[1], h->n, h->n_global, h->d_ctl, r.seq, h->d_cdf, h->d_bsum, h->d_boff, pp,
                                        rank, world),
                     hipLaunchKernelGGL(pf_auto_scan1_kernel<T>, dim3(nb), dim3(SCAN_BLOCK), 0, h->stream, (const T*)h->logw2[0],
-                                       (const T*)h->logw2[1], h->n, h->n_global, (const PfCtl*)h->d_ctl, r.seq, h->d_cdf, h->d_bsum, pp,
+                                       (const T*)h->logw2[1], h->n, h->n_global, h->d_ctl, r.seq, h->d_cdf, h->d_bsum, h->d_boff, pp,
                                        rank, world));
 #define PF_RESAMPLE_LAUNCH(SHV)                                                                                              \
         PF_DISPATCH(h,                                                                                                       \
                     hipLaunchKernelGGL((pf_auto_resample_kernel<T, SHV>), grid, dim3(256), 0, h->stream, (T*)h->pose[0], (T*)h->pose[1], \
                                        h->d_tab[0], h->d_tab[1], (T*)h->logw2[0], (T*)h->logw2[1], h->n, h->first, h->n_global,     \
-                                       (const PfCtl*)h->d_ctl, r.seq, (const double*)h->d_cdf, (const double*)h->d_bsum, nb,      \
+                                       (const PfCtl*)h->d_ctl, r.seq, (const double*)h->d_cdf, (const double*)h->d_bsum, (const double*)h->d_boff, nb,      \
                                        h->d_anc, (T)lw, pp, rank, world),                                                     \
                     hipLaunchKernelGGL((pf_auto_resample_kernel<T, SHV>), grid, dim3(256), 0, h->stream, (T*)h->pose[0], (T*)h->pose[1], \
                                        h->d_tab[0], h->d_tab[1], (T*)h->logw2[0], (T*)h->logw2[1], h->n, h->first, h->n_global,     \
-                                       (const PfCtl*)h->d_ctl, r.seq, (const double*)h->d_cdf, (const double*)h->d_bsum, nb,      \
+                                       (const PfCtl*)h->d_ctl, r.seq, (const double*)h->d_cdf, (const double*)h->d_bsum, (const double*)h->d_boff, nb,      \
                                        h->d_anc, (T)lw, pp, rank, world))
         if (sh) PF_RESAMPLE_LAUNCH(true);
         else PF_RESAMPLE_LAUNCH(false);

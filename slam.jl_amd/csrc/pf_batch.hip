@@ -25,8 +25,12 @@
 // release / acquire hand-overs) and measured it slower than the three conditional kernels it replaces on every size -- DESIGN.md
 // section 7 has the numbers: an L2 write-back per workgroup 76 us, per XCD still on the critical path; 8-byte write-through
 // stores one fabric write each (60 us for the scan); the exchange hops cost what the kernel boundaries cost.
-// The grid must be co-resident (workgroups wait for each other): one workgroup per compute unit, checked by the host against the
-// occupancy query; launches of this kernel on one device are chained by an event so that two filters' grids never interleave.
+// The grid must be co-resident (workgroups wait for each other): one workgroup per compute unit -- each takes the unit's whole
+// register file -- checked by the host against the occupancy query; launches of this kernel on one device are chained by an
+// event so that two filters' grids never interleave.  It is therefore OPT-IN (flags bit 1 of slam_pf_step_auto_batch): the caller
+// vouches that nothing else keeps the device's compute units busy meanwhile.  Measured (tests, round 5): a second filter
+// enqueueing its 256-thread step kernels on another stream can keep a compute unit from ever falling wholly free, the persistent
+// grid then never completes and its workgroups give up after 2 s (PF_ERR_HANDOVER: the filter is dead).
 // Takes: fp32, the whole filter on this shard, FastSLAM-1.0 steps, <= 32 observations per step, maps of <= 2048 landmarks,
 // <= 1024 x (compute units) particles.
 #include <mutex>
@@ -547,8 +551,8 @@ static int pb_pick_ways(slam_pf* h, bool distinct) {
 /* K consecutive slam_pf_step_auto calls as ONE call: step k = control (VG[2k], VG[2k+1]), observations z + 2 zstride k (m[k]
  * (range, bearing) pairs), their landmark ids at ids + zstride k, force[k] (NULL: the Neff rule at every step).  Same filter as
  * the K calls, bit for bit.  Runs of at least four consecutive steps that cannot resample (force[k] == 0) go, where the filter
- * allows it (see the head of pf_batch.hip), as persistent launches of up to 16 steps; every other step is enqueued as
- * slam_pf_step_auto enqueues it.  flags bit 0: no persistent launches.  *enqueued (may be NULL): the steps taken; less than K
+ * allows it (see the head of pf_batch.hip) and the caller ALLOWS it (flags bit 1: nothing else competes for the device's compute
+ * units meanwhile), as persistent launches of up to 16 steps; every other step is enqueued as slam_pf_step_auto enqueues it.  *enqueued (may be NULL): the steps taken; less than K
  * only with SLAM_PF_HALTED (sharded halting flow: resolve, then call again with the rest). */
 extern "C" int slam_pf_step_auto_batch(slam_pf_t h, int K, const double* VG, double wheelbase, const double Q[4], double dt,
                                        const double* z, const int32_t* ids, const int32_t* m, int zstride, const double R[4],
@@ -567,7 +571,7 @@ extern "C" int slam_pf_step_auto_batch(slam_pf_t h, int K, const double* VG, dou
         for (int i = 0; i < m[k]; ++i) ARG_CHECK(ids[(size_t)zstride * k + i] >= 1 && ids[(size_t)zstride * k + i] <= h->nl, "landmark id out of range");
     ARG_CHECK(!h->halted, "a halted step is waiting for slam_pf_resume");
     const double R0[4] = {0, 0, 0, 0};
-    const bool persistent = !(flags & 1) && !proposal && force != nullptr && pb_filter_ok(h);
+    const bool persistent = (flags & 2) && !proposal && force != nullptr && pb_filter_ok(h);
     int k = 0;
     while (k < K) {
         int kc = 0, widx = -1;

@@ -82,7 +82,7 @@ struct PfCtl {                   // device memory; written by the LAST workgroup
     long long seq;               // last completed step
     long long resample_seq;      // the step whose (lazy) resampling the conditional kernels apply
     long long halt_seq;          // != 0: that step wants a resampling the device cannot do; later steps are skipped
-    int32_t arrive;              // (unused: the first form of the hand-over counted arrivals here)
+    int32_t arrive;              // arrival counter of the cdf kernel's workgroups (its last one forms the block offsets; re-armed to 0)
     int32_t error;               // PF_ERR_*: the filter is dead, every later kernel returns at once
     int32_t nresamples;          // resamplings so far
     int32_t pcur, tside;         // live pose buffer / ancestor-table side
@@ -160,6 +160,7 @@ struct slam_pf {
     int has_pending;
     double* d_cdf;       // [n_global]
     double* d_bsum;      // [scan blocks]
+    double* d_boff;      // [scan blocks + 1]: their offsets (auto mode: formed by the cdf kernel's last workgroup)
     int32_t* d_src;      // [n] gather source: >= 0 local index, < 0: -(recv position + 1)
     int32_t* d_anc;      // [n] ancestors of slam_pf_resample_local
     int red_blocks;
@@ -215,6 +216,7 @@ constexpr int32_t LS_TAB = 0xff, LS_BUF = 1 << 8, LS_SEEN = 1 << 9;     // per-l
 static_assert(PF_CTL_TABS == PF_TAB_MAX && PF_CTL_MAXOBS == PF_AUTO_MAXOBS, "control-block sizes");
 
 constexpr int SCAN_BLOCK = 1024;             // particles per block of the cdf (and per record of the statistics exchange)
+constexpr int PF_BOFF_MIN_NB = 192;           // scan blocks from which the cdf kernel's last workgroup forms the block offsets (pf_auto.hip)
 constexpr int AUTO_NB_MAX = 2048;            // scan blocks (of 1024 particles) the fused offsets support
 constexpr int PAR_WAVES = 8;                 // the observation-parallel step kernel: ways per 64-particle workgroup
 constexpr int PF_WAY4_MAX_N = 81920;         // one-box sweep (tools/gpu_r4c.sh, no resampling): 65536: seq 29.7, 2 ways 22.4, 4 ways 20.4 us; 98304: 32.4 / 27.1 / 31.3;

@@ -504,7 +504,7 @@ extern "C" int slam_pf_destroy(slam_pf_t h) {
             if (h->lmtab.c[b][k]) (void)hipFree(h->lmtab.c[b][k]);
     }
     if (h->d_lmtab) (void)hipFree(h->d_lmtab);
-    void* devs[] = {h->logw2[0], h->logw2[1], h->d_part, h->d_out, h->d_cdf, h->d_bsum, h->d_src, h->d_anc, h->d_tab[0], h->d_tab[1],
+    void* devs[] = {h->logw2[0], h->logw2[1], h->d_part, h->d_out, h->d_cdf, h->d_bsum, h->d_boff, h->d_src, h->d_anc, h->d_tab[0], h->d_tab[1],
                     h->d_lmeta, h->d_ctl, h->d_lmstate, h->inbox, h->d_pb_lines};
     if (h->xchg_host) (void)hipHostUnregister(h->xchg_host);
     if (h->h_mir) (void)hipHostFree(h->h_mir);
@@ -569,6 +569,7 @@ static int pf_create_impl(slam_pf* h) {
     if ((rc = pf_alloc(&h->d_cdf, sizeof(double) * (size_t)h->n_global, h->stream))) return rc;
     const size_t nb = ((size_t)h->n_global + SCAN_BLOCK - 1) / SCAN_BLOCK;
     if ((rc = pf_alloc(&h->d_bsum, sizeof(double) * (nb + 1), h->stream))) return rc;
+    if ((rc = pf_alloc(&h->d_boff, sizeof(double) * (nb + 2), h->stream))) return rc;
     if ((rc = pf_alloc(&h->d_src, sizeof(int32_t) * n, h->stream))) return rc;
     if ((rc = pf_alloc(&h->d_anc, sizeof(int32_t) * n, h->stream))) return rc;
     HIP_TRY(hipHostMalloc((void**)&h->h_ids, sizeof(int32_t) * 4 * PF_OCAP, hipHostMallocDefault));
@@ -638,7 +639,7 @@ extern "C" int slam_pf_create(slam_pf_t* out, int dtype, int64_t n_local, int64_
     memset(h->peer_open, 0, sizeof(h->peer_open));
     h->h_ids = nullptr; h->h_obs = nullptr; h->ocap = 0;
     h->stage_ev[0] = h->stage_ev[1] = nullptr; h->stage_used[0] = h->stage_used[1] = 0; h->stage_slot = 0;
-    h->d_part = h->d_out = h->h_out = h->d_cdf = h->d_bsum = nullptr; h->d_src = nullptr; h->d_anc = nullptr;
+    h->d_part = h->d_out = h->h_out = h->d_cdf = h->d_bsum = h->d_boff = nullptr; h->d_src = nullptr; h->d_anc = nullptr;
     h->seen.assign(max_landmarks, 0);
     h->d_ctl = nullptr; h->d_lmstate = nullptr; h->h_mir = h->h_mir_dev = nullptr;
     h->auto_on = 0; h->auto_seq = 0; h->pub_seq = 0; h->nresamples = 0; h->halted = 0; h->halt_gmax = 0.0; h->last_resampled_seq = 0;

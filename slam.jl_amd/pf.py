@@ -243,10 +243,11 @@ class PFShard:
             raise ValueError("force: one value per step")
         return K, vg, zz, ii, ms, stride, ff
 
-    def step_auto_batch(self, batch, wheelbase, Q, dt, R, neff_frac=0.75, proposal=False, one_by_one=False, start=0):
+    def step_auto_batch(self, batch, wheelbase, Q, dt, R, neff_frac=0.75, proposal=False, persistent=False, start=0):
         """K filter steps ENQUEUED by one call (slam_pf_step_auto_batch; ``batch`` from prepare_batch): the same filter as
-        K step_auto calls, bit for bit; where the filter allows it up to 16 steps are one persistent launch.  Returns the
-        number of steps taken from ``start`` on: all of them, or fewer when the library reports SLAM_PF_HALTED (sharded
+        K step_auto calls, bit for bit.  ``persistent=True``: runs of steps that cannot resample may go as persistent launches of
+        up to 16 steps -- the caller vouches that nothing else keeps the device's compute units busy meanwhile (the grid takes them
+        whole and its workgroups wait for each other).  Returns the number of steps taken from ``start`` on: all of them, or fewer when the library reports SLAM_PF_HALTED (sharded
         halting flow: resolve the halt and call again with ``start`` advanced)."""
         K, vg, zz, ii, ms, stride, ff = batch
         pq = Q.ptr if isinstance(Q, _Small) else _ptr(_small(Q))
@@ -254,7 +255,7 @@ class PFShard:
         took = C.c_int(0)
         rc = lib.slam_pf_step_auto_batch(self._h, K - start, _ptr(vg[start:]), wheelbase, pq, dt, _ptr(zz[start:]),
                                          _ptr(ii[start:], C.c_int32), _ptr(ms[start:], C.c_int32), stride, pr, neff_frac,
-                                         _ptr(ff[start:], C.c_int32), 1 if proposal else 0, 1 if one_by_one else 0, C.byref(took))
+                                         _ptr(ff[start:], C.c_int32), 1 if proposal else 0, 2 if persistent else 0, C.byref(took))
         if rc and rc != SLAM_PF_HALTED:
             check(rc)
         return int(took.value)
@@ -672,15 +673,15 @@ class FastSLAM:
                            proposal=proposal, prepared=prepared):
             self._resolve_halt()
 
-    def step_async_batch(self, batch, wheelbase, Q, dt, R, proposal=False, one_by_one=False):
-        """K ``step_async`` calls as one (shard.step_auto_batch, ``batch`` from PFShard.prepare_batch): one persistent launch
-        per up to 16 steps where the filter allows it.  Halts of the sharded halting flow are resolved on the way."""
+    def step_async_batch(self, batch, wheelbase, Q, dt, R, proposal=False, persistent=False):
+        """K ``step_async`` calls as one (shard.step_auto_batch, ``batch`` from PFShard.prepare_batch); ``persistent=True`` allows
+        persistent launches of up to 16 steps (see there).  Halts of the sharded halting flow are resolved on the way."""
         self._gmax_norm = None
         sh = self.shard
         k, K = 0, batch[0]
         while k < K:
             took = sh.step_auto_batch(batch, wheelbase, Q, dt, R, neff_frac=self.neff_frac, proposal=proposal,
-                                      one_by_one=one_by_one, start=k)
+                                      persistent=persistent, start=k)
             k += took
             if k < K:
                 self._resolve_halt()

@@ -53,9 +53,13 @@ def drive(pkg, f, steps, K, checks, what, proposal=False):
     for k0 in range(0, len(steps), K):
         chunk = steps[k0:k0 + K]
         batch = pkg.PFShard.prepare_batch([(s[0], s[1]) for s in chunk], [(s[2], s[3]) for s in chunk], [s[4] for s in chunk])
-        f["batch"].step_async_batch(batch, 4.0, Q, 0.1, R, proposal=proposal)
+        # (persistent launches are opt-in: the caller vouches that nothing else keeps the device busy -- so the other filter's steps
+        #  are enqueued only when this one's are through)
+        f["batch"].step_async_batch(batch, 4.0, Q, 0.1, R, proposal=proposal, persistent=True)
+        f["batch"].shard.sync()
         for V, G, z, ids, force in chunk:
             f["single"].step_async(V, G, 4.0, Q, 0.1, z, ids, R, force_resample=force, proposal=proposal)
+        f["single"].shard.sync()
         if any(k0 <= c < k0 + K for c in checks):
             ra, rb = f["batch"].flush(), f["single"].flush()
             assert ra == rb, f"{what}: Neff / resampled after step {k0 + len(chunk) - 1}: {ra} vs {rb}"
@@ -143,7 +147,7 @@ def test_batch_with_an_exhausted_table_pool_and_legacy_calls_in_between(pkg):
 
 
 def test_batch_falls_back_step_by_step_where_the_persistent_launch_does_not_apply(pkg):
-    """fp64, the FastSLAM-2.0 proposal and the one_by_one flag take slam_pf_step_auto K times: still the same filter."""
+    """fp64, the FastSLAM-2.0 proposal and a call that does not allow persistent launches take slam_pf_step_auto K times: still the same filter."""
     n, nl, seed = 2000 + 3, 12, 7
     lm = scene(nl, 19)
     rng = np.random.default_rng(3)
@@ -160,7 +164,7 @@ def test_batch_falls_back_step_by_step_where_the_persistent_launch_does_not_appl
             g.shard.close()
     f = pair(pkg, n, nl, seed, lm)
     batch = pkg.PFShard.prepare_batch([(s[0], s[1]) for s in steps], [(s[2], s[3]) for s in steps], [s[4] for s in steps])
-    f["batch"].step_async_batch(batch, 4.0, Q, 0.1, R, one_by_one=True)
+    f["batch"].step_async_batch(batch, 4.0, Q, 0.1, R)                  # (persistent launches not allowed: every step on its own)
     for V, G, z, ids, force in steps:
         f["single"].step_async(V, G, 4.0, Q, 0.1, z, ids, R, force_resample=force)
     assert f["batch"].flush() == f["single"].flush()
@@ -186,8 +190,10 @@ def test_two_filters_batching_side_by_side(pkg):
     for k0 in range(0, 32, 16):
         chunk = steps[k0:k0 + 16]
         batch = pkg.PFShard.prepare_batch([(s[0], s[1]) for s in chunk], [(s[2], s[3]) for s in chunk], [s[4] for s in chunk])
-        fa["batch"].step_async_batch(batch, 4.0, Q, 0.1, R)
-        fb["batch"].step_async_batch(batch, 4.0, Q, 0.1, R)
+        fa["batch"].step_async_batch(batch, 4.0, Q, 0.1, R, persistent=True)
+        fb["batch"].step_async_batch(batch, 4.0, Q, 0.1, R, persistent=True)
+    for f in (fa, fb):
+        f["batch"].shard.sync()
     for V, G, z, ids, force in steps:
         fa["single"].step_async(V, G, 4.0, Q, 0.1, z, ids, R, force_resample=force)
         fb["single"].step_async(V, G, 4.0, Q, 0.1, z, ids, R, force_resample=force)

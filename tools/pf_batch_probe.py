@@ -32,7 +32,7 @@ for NP in NPS:
             def run(nsteps):
                 if mode == "batch":
                     for b in range(nsteps // K):
-                        pf.step_async_batch(batches[b % len(batches)], 4.0, Qs, 0.025, Rs)
+                        pf.step_async_batch(batches[b % len(batches)], 4.0, Qs, 0.025, Rs, persistent=True)
                 else:
                     for k in range(nsteps):
                         pf.step_async(0.0, 0.0, 4.0, Qs, 0.025, None, None, Rs, force_resample=force, prepared=prep[k % 64])

@@ -23,11 +23,11 @@ for t in range(64):
 batches = [pkg.PFShard.prepare_batch([(0.0, 0.0)] * K, [obs[(k0 + j) % 64] for j in range(K)], force) for k0 in range(0, 64, K)]
 NWARM, NTIMED = int(os.environ.get('PF_PROBE_WARM', '40')), int(os.environ.get('PF_PROBE_TIMED', '20'))
 for rep in range(NWARM):
-    pf.step_async_batch(batches[rep % len(batches)], 4.0, Qs, 0.025, Rs)
+    pf.step_async_batch(batches[rep % len(batches)], 4.0, Qs, 0.025, Rs, persistent=True)
 pf.flush(); pf.shard.sync()
 t0 = time.perf_counter()
 for rep in range(NTIMED):
-    pf.step_async_batch(batches[rep % len(batches)], 4.0, Qs, 0.025, Rs)
+    pf.step_async_batch(batches[rep % len(batches)], 4.0, Qs, 0.025, Rs, persistent=True)
 pf.flush(); pf.shard.sync()
 print(f"n {NP} K {K} force {force}: {1e6 * (time.perf_counter() - t0) / (NTIMED * K):.1f} us per step over {NTIMED} launches after {NWARM}")
 tr = np.zeros(256 * 16 * 4, dtype=np.uint64)
