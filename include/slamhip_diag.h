@@ -43,8 +43,10 @@ int slam_ekf_timing_stats(slam_ekf_t h, int kid, double out[4]);
 int slam_ekf_timing_reset(slam_ekf_t h);
 
 /* Diagnostics: when enabled the factorisation kernel records 100 MHz wall-clock stamps at its
- * phase boundaries; out8 (may be NULL) receives the stamps of the last update. */
-int slam_ekf_debug_stamps(slam_ekf_t h, int enable, uint64_t* out8);
+ * phase boundaries; out16 (may be NULL) receives the stamps of the last update: [0..7] the workgroup
+ * that factors S, [8..15] the first of the workgroups that form W1 in the same launch (zero when
+ * the update took the two-launch form). */
+int slam_ekf_debug_stamps(slam_ekf_t h, int enable, uint64_t* out16);
 
 /* Measurement hook (bench.py: roofline.copy_floor_ms): the bare memory side of the covariance down-date (src/ekf.jl:75) on
  * THIS handle's matrix -- every stored tile the down-date touches read once and written back unchanged (bit-exact), in

@@ -71,7 +71,7 @@ static inline int slam_exp_env(const char* name, int dflt) {
 constexpr int SLAM_XFLAGS_MASK = ~0;
 #else
 static inline int slam_exp_env(const char*, int dflt) { return dflt; }
-constexpr int SLAM_XFLAGS_MASK = 8 | 32 | 64 | 512;
+constexpr int SLAM_XFLAGS_MASK = 8 | 32 | 64 | 128 | 512;
 #endif
 
 struct TimingPair {
@@ -153,7 +153,7 @@ struct slam_ekf {
     int gate_blocks_cap;
 
     // small device scratch + pinned mirror for scalar outputs
-    double* d_small;     // 64 doubles
+    double* d_small;     // 64 doubles: [0..11] small results, [40..55] debug stamps, [56] the ready word factor_w1_kernel's workgroups meet on
     double* h_small;     // pinned, 64 doubles
     int32_t* d_status;   // [4]  [0] = not-PD flag of the last update
     int32_t* h_status;   // pinned
@@ -162,7 +162,7 @@ struct slam_ekf {
     int debug_flags;     // SLAMHIP_DEBUG env bits: 1 = no P stores, 2 = no MFMAs, 4 = no P loads (timing experiments, WRONG results)
     void* dd_prof;       // SLAMHIP_DEBUG & 8: per-wave phase clocks of the fp32 down-date (printed at destroy)
     int factor_blocked;  // K4: blocked MFMA elimination (default) or the scalar one (SLAMHIP_FACTOR=scalar)
-    int debug_stamps;    // factor kernel writes 100 MHz wall-clock stamps into d_small[40..47]
+    int debug_stamps;    // factor kernel writes 100 MHz wall-clock stamps into d_small[40..55]
     int async_updates;
     int deferred;        // first deferred error
     int pending_status;  // an update's status word has not been read back yet

@@ -829,6 +829,27 @@ extern "C" int slam_exp_observe_enqueue(slam_ekf_t h, const double* z, int nz, c
     if ((rc = launch_gate(h, nz, R, gate1, gate2, z, true))) return rc;
     return launch_update(h, nz, R, SLAM_FORM_CHOLESKY, true);
 }
+
+/* Experiments build only (tools/dbg_fw1.py): the update's workspace as it stands -- what: 0 = W1 ([npad][2 kcap], handle dtype),
+ * 1 = the pre-split bf16 image of W1 (fp32 handles), 2 = C ([kcap][kcap] doubles), 3 = g ([kcap] doubles).  Copies
+ * min(bytes, size) bytes; *size receives the buffer's size. */
+extern "C" int slam_exp_workspace(slam_ekf_t h, int what, void* out, size_t bytes, size_t* size) {
+    ARG_CHECK(h != nullptr && h->kcap > 0, "no workspace yet");
+    HIP_TRY(hipSetDevice(h->device));
+    const void* src = nullptr;
+    size_t sz = 0;
+    if (what == 0) { src = h->W1; sz = h->esz * (size_t)h->npad * 2 * h->kcap; }
+    else if (what == 1) { src = h->Wimg; sz = h->Wimg ? (size_t)(h->npad / 128) * (h->kcap / 16) * 3 * 4096 : 0; }
+    else if (what == 2) { src = h->Cmat; sz = sizeof(double) * (size_t)h->kcap * h->kcap; }
+    else if (what == 3) { src = h->gvec; sz = sizeof(double) * (size_t)h->kcap; }
+    ARG_CHECK(src != nullptr, "no such buffer");
+    if (size) *size = sz;
+    if (out && bytes) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipMemcpy(out, src, bytes < sz ? bytes : sz, hipMemcpyDeviceToHost));
+    }
+    return SLAM_OK;
+}
 #endif
 
 extern "C" int slam_ekf_set_async(slam_ekf_t h, int async_updates) {
@@ -846,14 +867,14 @@ extern "C" int slam_ekf_sync(slam_ekf_t h) {
     return SLAM_OK;
 }
 
-extern "C" int slam_ekf_debug_stamps(slam_ekf_t h, int enable, uint64_t* out8) {
+extern "C" int slam_ekf_debug_stamps(slam_ekf_t h, int enable, uint64_t* out16) {
     ARG_CHECK(h != nullptr, "null handle");
     h->debug_stamps = enable ? 1 : 0;
-    if (out8) {
+    if (out16) {      // [0..7]: the factorisation's workgroup; [8..15]: the first panel workgroup of factor_w1_kernel
         HIP_TRY(hipSetDevice(h->device));
-        HIP_TRY(hipMemcpyAsync(h->h_small, h->d_small + 40, sizeof(uint64_t) * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->h_small, h->d_small + 40, sizeof(uint64_t) * 16, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
-        memcpy(out8, h->h_small, sizeof(uint64_t) * 8);
+        memcpy(out16, h->h_small, sizeof(uint64_t) * 16);
     }
     return SLAM_OK;
 }

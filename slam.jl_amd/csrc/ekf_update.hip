@@ -38,13 +38,23 @@ namespace {
 // grid.x: 256-row blocks, grid.y: chunks of PHT_OBS observations
 // ---------------------------------------------------------------------------
 constexpr int PHT_OBS = 16;
+// One entry of P H': h . (P[r, 0], P[r, 1], P[r, 2], P[r, f], P[r, f + 1]) with the roundings SPELLED OUT (one product, four
+// fused multiply-adds, left to right): the four kernels that form entries of P H' must produce the same number for the same
+// entry whatever the compiler would have contracted in each of them (round 5: the streamed front half keeps its operands in
+// registers and is compared bit for bit with the two-launch form, which reads them back from memory).
+__device__ __forceinline__ double pht_entry(double h0, double h1, double h2, double h3, double h4, double p0, double p1, double p2,
+                                            double q0, double q1) {
+    return __builtin_fma(h4, q1, __builtin_fma(h3, q0, __builtin_fma(h2, p2, __builtin_fma(h1, p1, h0 * p0))));
+}
+constexpr int HB_STRIDE = 10, HB_MAXOBS = 64;      // Jacobian blocks of the kp <= 128 path: [HB_MAXOBS][10] doubles, then HB_MAXOBS state indices
 
 // (a device function: it runs as the workgroups 1.. of the fused factor kernel, next to the one-workgroup
 //  factorisation; row0 = first row of this workgroup, by = its chunk of PHT_OBS observations)
 template <typename T>
 __device__ __forceinline__ void pht_body(const T* __restrict__ x, const T* __restrict__ P, int ld, int n,
                                          const int32_t* __restrict__ idf, int m, int k, int kp, double* __restrict__ PHt,
-                                         int pitch, int tile_log2, const int32_t* __restrict__ dcount, int row0, int by) {
+                                         int pitch, int tile_log2, const int32_t* __restrict__ dcount, int row0, int by,
+                                         const double* __restrict__ hblk = nullptr) {
     __shared__ double sh[PHT_OBS][10];
     __shared__ int sf[PHT_OBS];
     SLAM_DEVICE_COUNT(dcount, m, k, kp)
@@ -52,7 +62,11 @@ __device__ __forceinline__ void pht_body(const T* __restrict__ x, const T* __res
     const int i0 = by * PHT_OBS;
     if (2 * i0 >= kp) return;                                   // (device count: a chunk beyond the padded width)
     const int mc = (m - i0 < PHT_OBS) ? m - i0 : PHT_OBS;       // observations in this chunk (may be <= 0 for pure padding)
-    if (tid < mc) {
+    if (tid < mc && hblk) {                                     // (kp <= 128: the blocks s_build_kernel left -- the same numbers the streamed form uses)
+#pragma unroll
+        for (int q = 0; q < 10; ++q) sh[tid][q] = hblk[HB_STRIDE * (i0 + tid) + q];
+        sf[tid] = reinterpret_cast<const int*>(hblk + HB_STRIDE * HB_MAXOBS)[i0 + tid];
+    } else if (tid < mc) {
         const double xv = (double)x[0], yv = (double)x[1], phi = (double)x[2];
         const int f = 3 + 2 * (idf[i0 + tid] - 1);
         const ObsModel om = obs_model(xv, yv, phi, (double)x[f], (double)x[f + 1]);
@@ -82,8 +96,8 @@ __device__ __forceinline__ void pht_body(const T* __restrict__ x, const T* __res
         for (int i = 0; i < PHT_OBS; ++i) {
             if (i < mc) {
                 const double* hb = sh[i];
-                out[2 * i] = hb[0] * p0 + hb[1] * p1 + hb[2] * p2 + hb[6] * (double)q0[i] + hb[7] * (double)q1[i];
-                out[2 * i + 1] = hb[3] * p0 + hb[4] * p1 + hb[5] * p2 + hb[8] * (double)q0[i] + hb[9] * (double)q1[i];
+                out[2 * i] = pht_entry(hb[0], hb[1], hb[2], hb[6], hb[7], p0, p1, p2, (double)q0[i], (double)q1[i]);
+                out[2 * i + 1] = pht_entry(hb[3], hb[4], hb[5], hb[8], hb[9], p0, p1, p2, (double)q0[i], (double)q1[i]);
             }
         }
     }
@@ -117,8 +131,8 @@ __global__ __launch_bounds__(128) void pht_compact_kernel(const T* __restrict__ 
         const int f = 3 + 2 * (idf[i] - 1);
         const double q0 = (double)sym_at(P, ld, tile_log2, r, f), q1 = (double)sym_at(P, ld, tile_log2, r, f + 1);
         const ObsModel om = obs_model(xv, yv, phi, (double)x[f], (double)x[f + 1]);
-        out[2 * i] = om.Hv[0] * p0 + om.Hv[1] * p1 + om.Hv[2] * p2 + om.Hf[0] * q0 + om.Hf[1] * q1;
-        out[2 * i + 1] = om.Hv[3] * p0 + om.Hv[4] * p1 + om.Hv[5] * p2 + om.Hf[2] * q0 + om.Hf[3] * q1;
+        out[2 * i] = pht_entry(om.Hv[0], om.Hv[1], om.Hv[2], om.Hf[0], om.Hf[1], p0, p1, p2, q0, q1);
+        out[2 * i + 1] = pht_entry(om.Hv[3], om.Hv[4], om.Hv[5], om.Hf[2], om.Hf[3], p0, p1, p2, q0, q1);
     }
     for (int c = k + threadIdx.x; c < kp; c += blockDim.x) out[c] = 0.0;
 }
@@ -135,7 +149,10 @@ template <typename T>
 __global__ __launch_bounds__(128) void s_build_kernel(const T* __restrict__ x, const T* __restrict__ P, int ld,
                                                        const int32_t* __restrict__ idf, int m, int k, int kp,
                                                        double* __restrict__ Sg, int pitch, int tile_log2,
-                                                       const int32_t* __restrict__ dcount, double R0, double R1, double R2, double R3) {
+                                                       const int32_t* __restrict__ dcount, double R0, double R1, double R2, double R3,
+                                                       double* __restrict__ hblk, unsigned* __restrict__ ready) {
+    // (the word factor_w1_kernel's workgroups meet on starts every update at zero, whatever the last update left)
+    if (ready && blockIdx.x == 0 && threadIdx.x == 0) ready[0] = 0u;
     SLAM_DEVICE_COUNT(dcount, m, k, kp)
     const int i = blockIdx.x;
     if (2 * i >= kp) return;
@@ -151,6 +168,15 @@ __global__ __launch_bounds__(128) void s_build_kernel(const T* __restrict__ x, c
     const double xv = (double)x[0], yv = (double)x[1], phi = (double)x[2];
     const int fi = 3 + 2 * (idf[i] - 1);
     const ObsModel oi = obs_model(xv, yv, phi, (double)x[fi], (double)x[fi + 1]);
+    if (hblk && threadIdx.x == 0) {
+        // the observation's Jacobian blocks and state index, for the workgroups of factor_w1_kernel that form P H' (they must not
+        // evaluate the model themselves: x is updated inside that launch)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) hblk[HB_STRIDE * i + q] = oi.Hv[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hblk[HB_STRIDE * i + 6 + q] = oi.Hf[q];
+        reinterpret_cast<int*>(hblk + HB_STRIDE * HB_MAXOBS)[i] = fi;
+    }
     const int rows[5] = {0, 1, 2, fi, fi + 1};
     for (int b = threadIdx.x; b < kp; b += blockDim.x) {
         if (b >= k) {                                                  // padding columns
@@ -173,8 +199,8 @@ __global__ __launch_bounds__(128) void s_build_kernel(const T* __restrict__ x, c
         double ph[5];                                                  // PHt[rows[t]][b]   (pht_compact_kernel's expression)
 #pragma unroll
         for (int t = 0; t < 5; ++t)
-            ph[t] = bb == 0 ? oj.Hv[0] * pr[t][0] + oj.Hv[1] * pr[t][1] + oj.Hv[2] * pr[t][2] + oj.Hf[0] * pr[t][3] + oj.Hf[1] * pr[t][4]
-                            : oj.Hv[3] * pr[t][0] + oj.Hv[4] * pr[t][1] + oj.Hv[5] * pr[t][2] + oj.Hf[2] * pr[t][3] + oj.Hf[3] * pr[t][4];
+            ph[t] = bb == 0 ? pht_entry(oj.Hv[0], oj.Hv[1], oj.Hv[2], oj.Hf[0], oj.Hf[1], pr[t][0], pr[t][1], pr[t][2], pr[t][3], pr[t][4])
+                            : pht_entry(oj.Hv[3], oj.Hv[4], oj.Hv[5], oj.Hf[2], oj.Hf[3], pr[t][0], pr[t][1], pr[t][2], pr[t][3], pr[t][4]);
 #pragma unroll
         for (int ra = 0; ra < 2; ++ra) {                               // (factor_body's build_S expression)
             double sv = oi.Hv[3 * ra + 0] * ph[0] + oi.Hv[3 * ra + 1] * ph[1] + oi.Hv[3 * ra + 2] * ph[2] + oi.Hf[2 * ra + 0] * ph[3] +
@@ -416,8 +442,69 @@ __device__ __forceinline__ bool factor_diag_block(double* M, int mp, int J, doub
     return !bad;
 }
 
+// Round 5: the inverse factor leaves the factorisation BLOCK COLUMN BY BLOCK COLUMN (factor_w1_kernel): after step J of the blocked
+// elimination the block row J of inv(L) is final -- its off-diagonal blocks X_JC sit transposed in the blocks (C, J) above the
+// diagonal, i.e. where C = inv(L)' / sqrt(D) has them, its diagonal block inv(L)_JJ in block (J, J) -- so C's columns 16 J .. 16 J +
+// 15 can go out while the elimination works on step J + 1.  They are stored write-through (16 bytes per lane: two adjacent
+// columns) and the ready word is raised once they have drained: the workgroups that form W1 = P H' C take block column after
+// block column.
+struct ProgC {
+    double* C;               // [kp][pitch] row-major, as factor_body's emit_C leaves it
+    int pitch, k;
+    unsigned* ready;         // block columns out so far; PC_DONE: all of them and g; PC_FAIL: the factorisation failed
+    int mode;                // (experiments build, SLAMHIP_FW1: 1 = no drain and no ready word inside the elimination, 2 = no block column leaves before its end)
+};
+constexpr unsigned PC_DONE = 15u, PC_FAIL = 31u;
+typedef unsigned pc_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_pc __attribute__((ext_vector_type(2)));
+// Block column Jc of C from the elimination's working matrix (see above), one 16 x 16 block per WAVE (waves 1 .. Jc: the blocks
+// above the diagonal, wave Jc + 1 -- wave 0 when there is no such wave -- the diagonal block): the same expressions as emit_C,
+// C[a][b] = inv(L)[b][a] / sqrt(D_b) for a < b, 1 / sqrt(D_b) on the diagonal, 0 below it and in the padding.  Two 16-byte
+// write-through stores per lane and NO wait for them: a store drained inside the elimination's step would lengthen the step
+// (measured: 1.5 us per step with one wave emitting and draining); the caller drains one step later, when it costs nothing.
+__device__ __forceinline__ void emit_c_part(const double* M, int mp, int Jc, const double* dvec, const ProgC& pc, int wave, int lane,
+                                            int nwaves) {
+    const int blk = wave - 1;                                    // this wave's row block of the column
+    const bool diag = blk == Jc || (wave == 0 && Jc + 1 >= nwaves);
+    if (!diag && !(blk >= 0 && blk < Jc)) return;
+    const auto rsc = __builtin_amdgcn_make_buffer_rsrc(pc.C, (short)0, 0x7fffffff, 0x00020000);
+    const int b0 = 16 * Jc + 2 * (lane & 7);                     // this lane's two columns
+    const double m0 = b0 < pc.k ? 1.0 / sqrt(dvec[b0]) : 0.0, m1 = b0 + 1 < pc.k ? 1.0 / sqrt(dvec[b0 + 1]) : 0.0;
+    const int rblk = diag ? Jc : blk;
+    double v[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                                // (both rows' LDS reads before the first use)
+        const int a = 16 * rblk + (lane >> 3) + 8 * u;
+        if (!diag) {                                             // X_JcC, transposed in block (C, Jc)
+            v[u][0] = M[a * mp + b0];
+            v[u][1] = M[a * mp + b0 + 1];
+        } else {                                                 // inv(L)_JcJc, unit lower
+            v[u][0] = a < b0 ? M[b0 * mp + a] : (a == b0 ? 1.0 : 0.0);
+            v[u][1] = a < b0 + 1 ? M[(b0 + 1) * mp + a] : (a == b0 + 1 ? 1.0 : 0.0);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int a = 16 * rblk + (lane >> 3) + 8 * u;
+        double c0, c1;
+        if (!diag) {
+            c0 = v[u][0] * m0;
+            c1 = v[u][1] * m1;
+        } else {
+            c0 = a == b0 ? m0 : v[u][0] * m0;
+            c1 = a == b0 + 1 ? m1 : v[u][1] * m1;
+        }
+        if (a >= pc.k || b0 >= pc.k) c0 = 0.0;
+        if (a >= pc.k || b0 + 1 >= pc.k) c1 = 0.0;
+        pc_u32x4 w4;
+        const unsigned long long u0 = (unsigned long long)__double_as_longlong(c0), u1 = (unsigned long long)__double_as_longlong(c1);
+        w4.x = (unsigned)u0; w4.y = (unsigned)(u0 >> 32); w4.z = (unsigned)u1; w4.w = (unsigned)(u1 >> 32);
+        __builtin_amdgcn_raw_buffer_store_b128(w4, rsc, (unsigned)(((size_t)a * pc.pitch + b0) * 8), 0u, 16);      // (aux 16 = sc1: write-through)
+    }
+}
+
 __device__ __forceinline__ bool eliminate_blocked(double* M, int mp, int k, int kp, double* dvec, double* dinv, double* flag,
-                                                  bool four = true) {
+                                                  bool four = true, const ProgC pc = ProgC{nullptr, 0, 0, nullptr, 0}) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
     const int li = lane & 15, kk = lane >> 4;
@@ -485,6 +572,11 @@ __device__ __forceinline__ bool eliminate_blocked(double* M, int mp, int k, int 
         }
     };
     for (int J = 0; J < nbk; ++J) {
+        if (pc.ready && J > 0 && !(pc.mode & 2)) {
+            // the block column the previous step completed goes out (the stores of the one before have had a step to drain)
+            if (!(pc.mode & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (wave > 0) emit_c_part(M, mp, J - 1, dvec, pc, wave, lane, nwaves);
+        }
         // ---- [A] wave 0: the trailing update of block (J, J) from step J-1, then its factorisation.
         //      waves 1..: the rest of step J-1's trailing update, then T_JC = sum_{K=C}^{J-1} L_JK X_KC.
         f64x4 T = {0.0, 0.0, 0.0, 0.0};
@@ -510,6 +602,8 @@ __device__ __forceinline__ bool eliminate_blocked(double* M, int mp, int k, int 
             }
         }
         __syncthreads();
+        // (every wave has drained its stores of block column J - 2 before the barrier: the columns 0 .. J - 2 are out)
+        if (pc.ready && !(pc.mode & 3) && J >= 2 && tid == nt - 1 && flag[0] == 0.0) __hip_atomic_store(pc.ready, (unsigned)(J - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- [B] (waves 1..nbk-1: at most 7 tasks, nbk <= 8)
         if (wave >= 1 && C < J) {                     // X_JC = -Linv_JJ * T_JC, stored transposed in block (C, J)
             f64x4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -532,6 +626,16 @@ __device__ __forceinline__ bool eliminate_blocked(double* M, int mp, int k, int 
             for (int r = 0; r < 4; ++r) M[(16 * I + 4 * r + kk) * mp + 16 * J + li] = acc[r] * di;
         }
         __syncthreads();
+    }
+    if (pc.ready && flag[0] == 0.0) {
+        // the last block column that holds real columns (the padding's are zero: the readers do not wait for them); this drain is
+        // the one that is paid for
+        if (pc.mode & 2)
+            for (int Jc = 0; Jc < nbk - 1; ++Jc) emit_c_part(M, mp, Jc, dvec, pc, wave, lane, nwaves);
+        emit_c_part(M, mp, nbk - 1, dvec, pc, wave, lane, nwaves);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(pc.ready, (unsigned)nbk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // the inverse's off-diagonal blocks move below the diagonal (over L, no longer needed); D goes on the diagonal
     for (int b = tr; b < kp; b += trs) {
@@ -583,7 +687,7 @@ __device__ __forceinline__ void factor_body(
     const int32_t* __restrict__ idf, int m, int k, int kp, double R0, double R1, double R2, double R3,
     double* __restrict__ Cout, int c_pitch, double* __restrict__ gvec, double* __restrict__ Sout, int want_sinv,
     double* __restrict__ Mglobal, int32_t* __restrict__ status, unsigned long long* __restrict__ stamps,
-    const int32_t* __restrict__ dcount, int blocked) {
+    const int32_t* __restrict__ dcount, int blocked, unsigned* __restrict__ ready = nullptr, int mode = 0) {
 #define STAMP(i)                                                  \
     do {                                                          \
         if (stamps && threadIdx.x == 0) stamps[i] = wall_clock64(); \
@@ -695,13 +799,19 @@ __device__ __forceinline__ void factor_body(
     STAMP(3);
     bool ok;
     if constexpr (!INLDS) ok = eliminate_in_memory(M, mp, k, mvec);
-    else if (blocked) ok = eliminate_blocked(M, mp, k, kp, rowbuf, rowbuf + kp, colbuf, blocked != 2);      // (2: one pivot per MFMA, experiments build)
+    else if (blocked) {
+        const ProgC pcs{Cout, c_pitch, k, ready, mode};      // (ready: C leaves block column by block column, factor_w1_kernel)
+        ok = eliminate_blocked(M, mp, k, kp, rowbuf, rowbuf + kp, colbuf, blocked != 2, pcs);      // (2: one pivot per MFMA, experiments build)
+    }
     else if (kp == 32) ok = eliminate_in_registers<2>(M, mp, k, kp, rowbuf, colbuf);
     else if (kp == 64) ok = eliminate_in_registers<4>(M, mp, k, kp, rowbuf, colbuf);
     else if (kp == 96) ok = eliminate_in_registers<6>(M, mp, k, kp, rowbuf, colbuf);
     else ok = eliminate_in_registers<8>(M, mp, k, kp, rowbuf, colbuf);
     if (!ok) {
-        if (tid == 0) { status[0] = 1; status[1] = 1; }    // [1] is sticky until slam_ekf_sync reads it
+        if (tid == 0) {
+            status[0] = 1; status[1] = 1;                   // [1] is sticky until slam_ekf_sync reads it
+            if (ready) __hip_atomic_store(ready, PC_FAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return;
     }
     STAMP(4);
@@ -729,10 +839,18 @@ __device__ __forceinline__ void factor_body(
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
         s += __shfl_xor(s, 4);
-        if (part == 0 && a < kp) gvec[a] = (a < k) ? s + yvec[a] * mvec[a] : 0.0;
+        if (part == 0 && a < kp) {
+            const double gv = (a < k) ? s + yvec[a] * mvec[a] : 0.0;
+            if (ready) __hip_atomic_store(gvec + a, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (write-through: read by other XCDs inside this launch)
+            else gvec[a] = gv;
+        }
     }
     STAMP(5);
-    if (!want_sinv) {
+    if (ready) {                                           // C went out during the elimination; g is out now
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(ready, PC_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (!want_sinv) {
         // C[a][b] = Linv[b][a]/sqrt(D_b) (a<b), 1/sqrt(D_b) (a==b), 0 below and in the padding.  Consecutive threads:
         // consecutive b (coalesced store, conflict-free LDS column walk thanks to the odd pitch); four rows' worth of
         // LDS reads are requested before the first is used (the loop used to wait for every element's read in turn)
@@ -803,13 +921,13 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_kernel(
     double* __restrict__ Cout, int c_pitch, double* __restrict__ gvec, double* __restrict__ Sout, int want_sinv,
     double* __restrict__ Mglobal, int32_t* __restrict__ status, unsigned long long* __restrict__ stamps,
     const int32_t* __restrict__ dcount, int blocked, const T* __restrict__ P, int ld, int n, double* __restrict__ PHt,
-    int tile_log2, int nbx) {
+    int tile_log2, int nbx, const double* __restrict__ hblk) {
     if (blockIdx.x == 0) {
         factor_body<T, INLDS>(x, PHtS, pht_pitch, z, idf, m, k, kp, R0, R1, R2, R3, Cout, c_pitch, gvec, Sout, want_sinv, Mglobal,
                               status, stamps, dcount, blocked);
     } else {
         const int b = blockIdx.x - 1;
-        pht_body<T>(x, P, ld, n, idf, m, k, kp, PHt, pht_pitch, tile_log2, dcount, (b % nbx) * FACTOR_THREADS, b / nbx);
+        pht_body<T>(x, P, ld, n, idf, m, k, kp, PHt, pht_pitch, tile_log2, dcount, (b % nbx) * FACTOR_THREADS, b / nbx, hblk);
     }
 }
 
@@ -928,6 +1046,10 @@ constexpr int W1_THREADS = 512;
 // three-way bf16 split of an fp32 value (exact: v = h + m + l), round to nearest even at every level
 __device__ __forceinline__ void split_bf16(float v, unsigned short& h, unsigned short& m, unsigned short& l) {
     typedef __bf16 bf1;
+    // (the split is OF THE FLOAT -- of the number W1 holds, as the down-date's own split2 would make it.  Handed an
+    //  fp64 -> fp32 conversion, the compiler folded it into the bf16 conversion in one kernel and not in another: where the float
+    //  is a tie between two bf16 values the two rounded differently -- both splits exact, the down-dates one ulp apart.  Round 5.)
+    asm volatile("" : "+v"(v));
     const bf1 bh = (bf1)v;
     const float r1 = v - (float)bh;
     const bf1 bm = (bf1)r1;
@@ -1076,6 +1198,223 @@ __global__ __launch_bounds__(W1_THREADS) void w1_mfma_kernel(const double* __res
     else w1_mfma_body<TO, 8>(PHt, pitchA, Cmat, pitchC, sC, W1, pitchW, x, n, g, img, img_nch, drift, dbg);
 }
 
+
+// ---------------------------------------------------------------------------
+// Round 5 -- K4 + K2/K3 + K5 in ONE launch with C STREAMED (kp <= 128, reference form, blocked factorisation).
+//
+// Before: factor_kernel (workgroup 0 factors S, the others form the panel P H' and write it to memory) and then
+// w1_mfma_kernel (reads the panel and C back, W1 = P H' C, x += P H' g): the second launch could not start before the
+// first had ended, and all it did between its launch and its first MFMA was to wait for the panel it had just written.
+// Here every WAVE of the workgroups 1.. keeps its 16 rows of P H' in REGISTERS (the MFMA A operands, formed exactly as
+// pht_body forms them) and takes C block column by block column as the elimination of workgroup 0 completes them (ProgC
+// above): column block cb of W1 needs the rows 0 .. 16 cb + 15 of C's column block cb and nothing else.  The full panel is
+// never written.  What remains after the factorisation's last step is one block column's worth of work, not a launch.
+// `wpw` waves of a workgroup work (the launch spreads the 16-row groups over all CUs; every workgroup carries the
+// factorisation's LDS, so there is one per CU).
+//
+// Workgroup 0 never waits for the others, and is dispatched first (workgroups are placed in the order of their index), so the
+// grid may be larger than the chip.  The ready word: block columns out (PC_DONE: g too, PC_FAIL: not positive definite);
+// s_build_kernel, the launch before, zeroes it.
+// The panel workgroups must not evaluate the observation model: x is updated by THIS launch (a workgroup placed late would
+// see moved means).  They read the Jacobian blocks s_build_kernel left (hblk).
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T ld_agent(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <typename TO, int NCB>      // NCB = kp / 16
+__device__ __forceinline__ void w1_stream_body(const TO* __restrict__ P, int ld, int tile_log2, int n, int npad, int m, int k,
+                                               const double* __restrict__ hblk, const double* __restrict__ Cmat, int pitchC,
+                                               double* lds, TO* __restrict__ W1, int pitchW, TO* __restrict__ x,
+                                               const double* __restrict__ g, char* __restrict__ img, int img_nch,
+                                               unsigned long long* __restrict__ drift, const unsigned* __restrict__ ready,
+                                               unsigned long long* __restrict__ stamps, int wpw, int mode) {
+#define CSTAMP(i)                                                                        \
+    do {                                                                                 \
+        if (stamps && blockIdx.x == 1 && threadIdx.x == 0) stamps[8 + (i)] = wall_clock64(); \
+    } while (0)
+    CSTAMP(0);
+    double* sh = lds;                                           // [HB_MAXOBS][10], then the state indices
+    const int* sfs = reinterpret_cast<const int*>(sh + HB_STRIDE * HB_MAXOBS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kk = lane >> 4;
+    const int rb = blockIdx.x - 1;
+    const int r0 = (rb * wpw + wave) * 16;                      // this wave's 16 rows
+    const bool act = wave < wpw && r0 < npad;                   // (wave-uniform; the other waves only keep the two barriers)
+    for (int t = tid; t < HB_STRIDE * HB_MAXOBS + HB_MAXOBS / 2; t += FACTOR_THREADS) sh[t] = hblk[t];
+    __syncthreads();
+    double moved = 0.0;
+    if (act) {
+        // the wave's 16 x kp block of P H': lane (i, kk) holds row r0 + i, the two columns of the observations 4 s + kk
+        // (pht_body's expressions, so the operands are the numbers the two-launch form read back from memory)
+        f64x2 a[NCB * 2];
+        {
+            const int r = r0 + i;
+            const bool live = r < n;
+            const int rr = live ? r : 0;
+            const double p0 = (double)P[p_off(ld, tile_log2, rr, 0)];
+            const double p1 = (double)P[p_off(ld, tile_log2, rr, 1)];
+            const double p2 = (double)P[p_off(ld, tile_log2, rr, 2)];
+            TO q0[NCB * 2], q1[NCB * 2];
+#pragma unroll
+            for (int s = 0; s < NCB * 2; ++s) {                 // all gathers before the first use
+                const int ob = 4 * s + kk;
+                const int f = sfs[ob < m ? ob : 0];
+                q0[s] = sym_at(P, ld, tile_log2, rr, f);
+                q1[s] = sym_at(P, ld, tile_log2, rr, f + 1);
+            }
+#pragma unroll
+            for (int s = 0; s < NCB * 2; ++s) {
+                const int ob = 4 * s + kk;
+                const double* hb = sh + HB_STRIDE * (ob < m ? ob : 0);
+                const double v0 = pht_entry(hb[0], hb[1], hb[2], hb[6], hb[7], p0, p1, p2, (double)q0[s], (double)q1[s]);
+                const double v1 = pht_entry(hb[3], hb[4], hb[5], hb[8], hb[9], p0, p1, p2, (double)q0[s], (double)q1[s]);
+                double a0 = (live && ob < m) ? v0 : 0.0, a1 = (live && ob < m) ? v1 : 0.0;
+                // (evaluated HERE: left alone, the compiler sinks the second column's arithmetic to its first use, the MFMAs, and keeps
+                //  its seven inputs per observation alive until then -- 200 registers, spilled)
+                asm volatile("" : "+v"(a0), "+v"(a1));
+                a[s][0] = a0;
+                a[s][1] = a1;
+            }
+        }
+        CSTAMP(1);
+        const int nbk = (k + 15) >> 4;                          // block columns with real columns; the others of W1 are zero
+        const auto rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Cmat), (short)0, 0x7fffffff, 0x00020000);
+        // the ready word, read by ONE lane at agent scope (sc1) until it covers `need`
+        auto wait_for = [&](unsigned need) __attribute__((always_inline)) {
+            unsigned v = 0;
+            if (lane == 0)
+                while ((v = ld_agent(ready)) < need) __builtin_amdgcn_s_sleep(16);
+            return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+        };
+        // column block cb of W1 and of its bf16 image (layout: see w1_mfma_body)
+        auto put = [&](int cb, const f64x4& v) __attribute__((always_inline)) {
+            if (mode & 4) return;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W1[(size_t)(r0 + 4 * r + kk) * pitchW + 16 * cb + i] = (TO)v[r];
+            if (img) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = (r0 & 127) + 4 * r + kk;
+                    unsigned short hh, mm, ll;
+                    split_bf16((float)v[r], hh, mm, ll);
+                    char* d = img + ((size_t)((r0 >> 7) * img_nch + cb) * 3) * 4096 + rr * 32 + ((((i >> 3) ^ (rr >> 3)) & 1) * 16) + (i & 7) * 2;
+                    *reinterpret_cast<unsigned short*>(d) = hh;
+                    *reinterpret_cast<unsigned short*>(d + 4096) = mm;
+                    *reinterpret_cast<unsigned short*>(d + 8192) = ll;
+                }
+            }
+        };
+        unsigned rdy = 0;
+        bool failed = false;
+        f64x4 acc[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            acc[cb] = f64x4{0.0, 0.0, 0.0, 0.0};
+            if (cb < nbk && !failed) {                          // (wave-uniform)
+                if (rdy < (unsigned)(cb + 1)) rdy = wait_for((unsigned)(cb + 1));
+                failed = rdy == PC_FAIL;
+                if (cb == 0) CSTAMP(2);
+                if (cb == nbk - 1) CSTAMP(3);
+                if (!failed) {
+                    // the B operands straight from C (rows 0 .. 16 cb + 15 of block column cb: one 128-byte line per quarter-wave and
+                    // load).  PLAIN loads: a line of C is written once per launch, write-through, and read only after the ready
+                    // word covers it, so no cache on the way can hold an older copy -- and the CU's L1 and the XCD's L2 serve
+                    // the other waves.  No LDS, no workgroup barrier: a wave whose gathers came back early does not wait for
+                    // its neighbours'.
+                    double bv[2 * NCB][2];
+#pragma unroll
+                    for (int s = 0; s < 2 * cb + 2; ++s)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const u32x2_pc w2 = __builtin_amdgcn_raw_buffer_load_b64(rsc, (unsigned)(((size_t)(8 * s + 2 * kk + t) * pitchC + 16 * cb + i) * 8), 0u, 0);
+                            bv[s][t] = __longlong_as_double((long long)((unsigned long long)w2.x | ((unsigned long long)w2.y << 32)));
+                        }
+                    if (!(mode & 8)) {
+#pragma unroll
+                        for (int s = 0; s < 2 * cb + 2; ++s)    // (the order of w1_mfma_body: s, then t, ascending)
+#pragma unroll
+                            for (int t = 0; t < 2; ++t) acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][t], bv[s][t], acc[cb], 0, 0, 0);
+                    }
+                }
+            }
+            // the stores lag one column block behind (vmcnt counts stores too: the wait for the next block column's loads then
+            // covers stores that have had a step of the elimination to drain)
+            if (cb > 0 && !failed) put(cb - 1, acc[cb - 1]);
+        }
+        if (!failed) put(NCB - 1, acc[NCB - 1]);
+        CSTAMP(4);
+        // g = inv(S) v follows the last block column
+        if (!failed && rdy != PC_DONE) {
+            rdy = wait_for(PC_DONE);
+            failed = rdy == PC_FAIL;
+        }
+        CSTAMP(5);
+        if (!failed) {
+            // x += PHt*g  (ekf.jl:74 with W*v = PHt*(C*C'*v)): lane (i, kk) holds a quarter of row i
+            const auto rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(g), (short)0, 0x7fffffff, 0x00020000);
+            double sx = 0.0;
+            pc_u32x4 gw[NCB * 2];
+#pragma unroll
+            for (int s = 0; s < NCB * 2; ++s) gw[s] = __builtin_amdgcn_raw_buffer_load_b128(rsg, (unsigned)((8 * s + 2 * kk) * 8), 0u, 0);      // (plain loads, as for C)
+#pragma unroll
+            for (int s = 0; s < NCB * 2; ++s) {
+                const double g0 = __longlong_as_double((long long)((unsigned long long)gw[s].x | ((unsigned long long)gw[s].y << 32)));
+                const double g1 = __longlong_as_double((long long)((unsigned long long)gw[s].z | ((unsigned long long)gw[s].w << 32)));
+                sx = __builtin_fma(a[s][0], g0, sx);
+                sx = __builtin_fma(a[s][1], g1, sx);
+            }
+            sx += __shfl_xor(sx, 16);
+            sx += __shfl_xor(sx, 32);
+            if (kk == 0 && r0 + i < n) {
+                const double xo = (double)x[r0 + i];
+                const TO xn = (TO)(xo + sx);
+                x[r0 + i] = xn;
+                if (r0 + i >= 3) moved = fabs((double)xn - xo);
+            }
+        }
+    }
+    if (drift) {                // (see w1_mfma_body)
+        __shared__ double s_moved[FACTOR_THREADS / 64];
+        moved = fmax_nan(moved, __shfl_xor(moved, 1));
+        moved = fmax_nan(moved, __shfl_xor(moved, 2));
+        moved = fmax_nan(moved, __shfl_xor(moved, 4));
+        moved = fmax_nan(moved, __shfl_xor(moved, 8));
+        if (lane == 0) s_moved[wave] = moved;
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int w = 1; w < FACTOR_THREADS / 64; ++w) moved = fmax_nan(moved, s_moved[w]);
+            if (!(moved == 0.0)) atomicMax(drift + (rb & 15) * SLAM_GRID_SLOTS, (unsigned long long)__double_as_longlong(moved));
+        }
+    }
+    CSTAMP(6);
+#undef CSTAMP
+}
+
+template <typename T>
+__global__ __launch_bounds__(FACTOR_THREADS) void factor_w1_kernel(
+    T* __restrict__ x, const double* __restrict__ Sg, int s_pitch, const double* __restrict__ z,
+    const int32_t* __restrict__ idf, int m, int k, int kp, double R0, double R1, double R2, double R3,
+    double* __restrict__ Cout, int c_pitch, double* __restrict__ gvec, int32_t* __restrict__ status,
+    unsigned long long* __restrict__ stamps, const int32_t* __restrict__ dcount, int blocked, const T* __restrict__ P, int ld,
+    int n, int npad, int tile_log2, const double* __restrict__ hblk, T* __restrict__ W1, int pitchW, char* __restrict__ img, int img_nch,
+    unsigned* __restrict__ dd_claim, unsigned long long* __restrict__ drift, unsigned* __restrict__ sync, int wpw, int mode) {
+    if (blockIdx.x == 0) {
+        factor_body<T, true>(x, Sg, s_pitch, z, idf, m, k, kp, R0, R1, R2, R3, Cout, c_pitch, gvec, (double*)nullptr, 0, (double*)nullptr,
+                             status, stamps, dcount, blocked, sync, mode);
+        return;
+    }
+    // (the tile counters of the down-date that follows: see w1_mfma_kernel)
+    if (dd_claim && blockIdx.x == 1 && threadIdx.x < 128) dd_claim[threadIdx.x] = 0u;
+    SLAM_DEVICE_COUNT(dcount, m, k, kp)
+    if (m == 0) return;                                          // (workgroup 0 returns the same way: nobody waits)
+    extern __shared__ double lds[];
+    if (kp == 32) w1_stream_body<T, 2>(P, ld, tile_log2, n, npad, m, k, hblk, Cout, c_pitch, lds, W1, pitchW, x, gvec, img, img_nch, drift, sync, stamps, wpw, mode);
+    else if (kp == 64) w1_stream_body<T, 4>(P, ld, tile_log2, n, npad, m, k, hblk, Cout, c_pitch, lds, W1, pitchW, x, gvec, img, img_nch, drift, sync, stamps, wpw, mode);
+    else if (kp == 96) w1_stream_body<T, 6>(P, ld, tile_log2, n, npad, m, k, hblk, Cout, c_pitch, lds, W1, pitchW, x, gvec, img, img_nch, drift, sync, stamps, wpw, mode);
+    else w1_stream_body<T, 8>(P, ld, tile_log2, n, npad, m, k, hblk, Cout, c_pitch, lds, W1, pitchW, x, gvec, img, img_nch, drift, sync, stamps, wpw, mode);
+}
+
 // x += PHt * g      (ekf.jl:74 with W*v = PHt*(C*C'*v)); 8 lanes per row
 template <typename T>
 __global__ __launch_bounds__(256) void x_update_kernel(T* __restrict__ x, const double* __restrict__ PHt, int pitch, int n,
@@ -1133,11 +1472,16 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form, const int32_t*
     // K2c: the 3 + 2m rows of P*H' the factorisation needs (compact panel PHtS); the full panel is formed by the
     // fused kernel below, next to the factorisation
     const int tlog = h->dtype == SLAM_F32 ? 7 : 6;
+    // round 5: factorisation, panel and W1 in one launch, C streamed (factor_w1_kernel; SLAMHIP_X bit 128: the two launches of round 4)
+    const bool fused = !joseph && kp <= 128 && h->factor_blocked == 1 && !(h->xflags & 128);
+    double* hblk = h->Smat;      // (free in the reference form: the observations' Jacobian blocks, HB_MAXOBS * (HB_STRIDE + 1/2) doubles <= 32 * 32,
+                                 //  written by s_build_kernel for kp <= 128)
     {
         KTimer t(h, SLAM_K_PHT);
         if (kp <= 128)      // S itself, kp/2 workgroups (the factor kernel copies it into LDS)
             hipLaunchKernelGGL(s_build_kernel<T>, dim3(kp / 2), dim3(128), 0, h->stream, x, P, h->ld, h->idfbuf, m, k, kp, h->PHtS,
-                               pitchA, tlog, dcount, R[0], R[1], R[2], R[3]);
+                               pitchA, tlog, dcount, R[0], R[1], R[2], R[3], joseph ? (double*)nullptr : hblk,
+                               fused ? reinterpret_cast<unsigned*>(h->d_small + 56) : (unsigned*)nullptr);
         else                // the compact panel; the factor kernel forms S from it
             hipLaunchKernelGGL(pht_compact_kernel<T>, dim3(3 + 2 * m), dim3(128), 0, h->stream, x, P, h->ld, n, h->idfbuf, m, k, kp,
                                h->PHtS, pitchA, tlog, dcount);
@@ -1151,24 +1495,42 @@ int update_typed(slam_ekf* h, int m, const double R[4], int form, const int32_t*
         const size_t aux = (size_t)7 * kp * sizeof(double) + (size_t)m * (10 * sizeof(double) + sizeof(int));
         const size_t shm = aux + (in_lds ? (size_t)kp * (kp + 1) * sizeof(double) : 0);
         unsigned long long* stamps = h->debug_stamps ? (unsigned long long*)(h->d_small + 40) : (unsigned long long*)nullptr;
-        if (in_lds)
+        if (fused) {
+            const bool img = h->dtype == SLAM_F32 && h->Wimg && !(h->xflags & 16);
+            const size_t need = (size_t)(HB_STRIDE * HB_MAXOBS + HB_MAXOBS / 2) * sizeof(double);
+            // the 16-row groups spread over the CUs: `wpw` working waves per workgroup.  Over 7/8 of the chip, not all of it:
+            // at C3 (1256 groups) 6 waves on 210 CUs end at 40.1 us, 5 waves on 252 CUs at 44.1 us and slow the factorisation's own
+            // workgroup by 3 us, 8 waves on 157 CUs at 44.0 us (profiles/r05_front_half_timeline.txt)
+            const int groups = h->npad / 16, room = h->num_cus >= 16 ? h->num_cus * 7 / 8 : 1;
+            int wpw = (groups + room - 1) / room;
+            wpw = wpw < 1 ? 1 : (wpw > FACTOR_THREADS / 64 ? FACTOR_THREADS / 64 : wpw);
+            wpw = slam_exp_env("SLAMHIP_FW1_WPW", wpw);
+            hipLaunchKernelGGL(factor_w1_kernel<T>, dim3(1 + (groups + wpw - 1) / wpw), dim3(FACTOR_THREADS), shm > need ? shm : need, h->stream, x,
+                               (const double*)h->PHtS, pitchA, (const double*)h->obsbuf, (const int32_t*)h->idfbuf, m, k, kp, R[0], R[1],
+                               R[2], R[3], h->Cmat, pitchA, h->gvec, h->d_status, stamps, dcount, h->factor_blocked, (const T*)P, h->ld, n,
+                               h->npad, tlog, (const double*)hblk, W1, pitchW, img ? (char*)h->Wimg : (char*)nullptr, h->kcap / 16,
+                               img ? h->dd_claim : (unsigned*)nullptr, drift, reinterpret_cast<unsigned*>(h->d_small + 56), wpw,
+                               slam_exp_env("SLAMHIP_FW1", 0));
+        } else if (in_lds)
             hipLaunchKernelGGL((factor_kernel<T, true>), fgrid, dim3(FACTOR_THREADS), shm, h->stream, x, h->PHtS, pitchA,
                                h->obsbuf, h->idfbuf, m, k, kp, R[0], R[1], R[2], R[3], h->Cmat, pitchA, h->gvec,
                                joseph ? h->Smat : (double*)nullptr, joseph ? 1 : 0, (double*)nullptr, h->d_status, stamps, dcount, h->factor_blocked,
-                               (const T*)P, h->ld, n, h->PHt, tlog, nbx);
+                               (const T*)P, h->ld, n, h->PHt, tlog, nbx, joseph ? (const double*)nullptr : (const double*)hblk);
         else
             hipLaunchKernelGGL((factor_kernel<T, false>), fgrid, dim3(FACTOR_THREADS), shm, h->stream, x, h->PHtS, pitchA,
                                h->obsbuf, h->idfbuf, m, k, kp, R[0], R[1], R[2], R[3], h->Cmat, pitchA, h->gvec,
                                joseph ? h->Smat : (double*)nullptr, joseph ? 1 : 0, h->Mwork, h->d_status, stamps, dcount, 0,
-                               (const T*)P, h->ld, n, h->PHt, tlog, nbx);
+                               (const T*)P, h->ld, n, h->PHt, tlog, nbx, (const double*)nullptr);
     }
     HIP_TRY(hipGetLastError());
     const dim3 pg_grid(h->npad / PG_ROWS, (kp + PG_COLS - 1) / PG_COLS);
     int kp_total;
     bool use_img = false;      // the W1 kernel also leaves the panel pre-split for the split-bf16 down-date (SLAMHIP_X bit 16: off)
-    {   // K5
+    use_img = !joseph && kp <= 128 && h->dtype == SLAM_F32 && h->Wimg && !(h->xflags & 16);
+    if (fused) {
+        kp_total = round_up(k, 16);
+    } else {   // K5
         KTimer t(h, SLAM_K_W1);
-        use_img = !joseph && kp <= 128 && h->dtype == SLAM_F32 && h->Wimg && !(h->xflags & 16);
         if (!joseph && kp <= 128) {
             // W1 = PHt*C and x += PHt*g on the fp64 matrix cores
             hipLaunchKernelGGL(w1_mfma_kernel<T>, dim3(h->npad / 128), dim3(W1_THREADS), (size_t)kp * kp * sizeof(double),
@@ -1226,5 +1588,7 @@ int update_kernels_init() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, fbig));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_kernel<double, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, fbig));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_w1_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, fbig));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_w1_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, fbig));
     return SLAM_OK;
 }

@@ -397,8 +397,9 @@ class EKFSlamState(SlamState):
         return float(out[0]), ("one workgroup per tile", "persistent grid")[int(out[1])]
 
     def debug_stamps(self, enable=True):
-        """Diagnostics: 100 MHz wall-clock stamps of the factorisation kernel's phases (last update)."""
-        out = (C.c_uint64 * 8)()
+        """Diagnostics: 100 MHz wall-clock stamps of the factorisation kernel's phases (last update): [0..7] the workgroup that
+        factors S, [8..15] the first of the workgroups that form W1 in the same launch."""
+        out = (C.c_uint64 * 16)()
         check(lib.slam_ekf_debug_stamps(self._h, 1 if enable else 0, out))
         return [int(v) for v in out]
 

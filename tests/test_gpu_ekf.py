@@ -952,6 +952,43 @@ def test_lds_dma_chunk_pipeline_against_the_register_staged_one(pkg, monkeypatch
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m,N", [(1, 40), (7, 300), (16, 1000), (33, 1500), (50, 1500), (64, 1500), (57, 6000)])
+def test_streamed_front_half_against_the_two_launches(pkg, monkeypatch, dtype, m, N):
+    """Round 5: for k <= 128 in the reference form the factorisation, the panel P H' and W1 = P H' C are ONE launch
+    (csrc/ekf_update.hip: factor_w1_kernel): C leaves the elimination block column by block column and the panel waves keep their
+    operands in registers.  SLAMHIP_X=128 keeps round 4's two launches (panel written to memory, W1 formed by a second kernel).
+    Same expressions in the same order: mean and covariance must agree bit for bit over several steps, at one to eight block
+    columns, with landmark rows above and below the observed columns' tiles -- and a failed factorisation must leave the state
+    untouched and the ready words reset (the next update works)."""
+    rng = np.random.default_rng(900 + m)
+    x, P = random_state(rng, N, spread=600.0 if N < 3000 else 2500.0)
+    got = {}
+    for name, flag in (("fused", None), ("two", "128")):
+        if flag is None:
+            monkeypatch.delenv("SLAMHIP_X", raising=False)
+        else:
+            monkeypatch.setenv("SLAMHIP_X", flag)
+        st = pkg.EKFSlamState(x, P, dtype=dtype, max_landmarks=N)
+        r2 = np.random.default_rng(13)
+        for step in range(3):
+            xo = st.download("x").astype(np.float64)
+            ids = r2.permutation(N)[:m] + 1
+            st.update(noisy_obs(r2, xo, ids), R, ids)
+            if step == 1:
+                before = st.download()
+                with pytest.raises(pkg.NotPositiveDefinite):
+                    st.update(noisy_obs(r2, xo, ids), np.diag([-1e9, -1e9]), ids)
+                after = st.download()
+                assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1]), name
+        got[name] = st.download()
+        st.close()
+    monkeypatch.delenv("SLAMHIP_X", raising=False)
+    assert np.array_equal(got["fused"][0], got["two"][0])
+    assert np.array_equal(got["fused"][1], got["two"][1])
+    assert np.array_equal(got["fused"][1], got["fused"][1].T)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_telemetry_ellipses_and_monitor_schema(pkg, dtype):
     """Row N3: feature / vehicle ellipses computed on the device from the 2 x 2 blocks (no download of P) against
     the oracle's restatement of feature_ellipses (sim/browser/wsserver.jl:72-85); the eigenvector sign is
