@@ -988,6 +988,32 @@ def test_streamed_front_half_against_the_two_launches(pkg, monkeypatch, dtype, m
     assert np.array_equal(got["fused"][1], got["fused"][1].T)
 
 
+def test_streamed_front_half_with_more_workgroups_than_compute_units(pkg, monkeypatch):
+    """factor_w1_kernel's panel workgroups wait for the ONE workgroup that factors S; that is safe for any grid only because
+    workgroup 0 is placed first and never waits for the others.  N = 24000 (n = 48003, fp32): 3008 sixteen-row groups = 376
+    workgroups of eight working waves, more than the chip has CUs -- the late ones start after the early ones have left.  Compared
+    with the two-launch form (SLAMHIP_X=128) bit for bit: mean, diagonal, and blocks from the head, the middle and the tail."""
+    import bench as B
+    N, nz = 24000, 64
+    got = {}
+    for name, flag in (("fused", None), ("two", "128")):
+        if flag is None:
+            monkeypatch.delenv("SLAMHIP_X", raising=False)
+        else:
+            monkeypatch.setenv("SLAMHIP_X", flag)
+        st, zs = B.make_workload_on_device(pkg, N, nz, 3, 4242, "f32", 0)
+        ms = [B.gpu_step(st, z) for z in zs]
+        assert min(ms) >= 40, ms                                  # (k >= 80: the split-bf16 down-date, five block columns or more)
+        n = st.n
+        got[name] = (st.download("x"), st.diag(), st.get_block(0, 0, 200, 200), st.get_block(n // 2 - 100, 0, 300, 300),
+                     st.get_block(n - 300, n // 2, 300, 300), st.get_block(n - 260, n - 260, 260, 260))
+        st.close()
+    monkeypatch.delenv("SLAMHIP_X", raising=False)
+    for a, b in zip(got["fused"], got["two"]):
+        assert np.array_equal(a, b)
+    assert np.all(np.isfinite(got["fused"][1])) and np.all(got["fused"][1] > 0)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_telemetry_ellipses_and_monitor_schema(pkg, dtype):
     """Row N3: feature / vehicle ellipses computed on the device from the 2 x 2 blocks (no download of P) against
