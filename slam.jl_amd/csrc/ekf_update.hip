@@ -1212,8 +1212,11 @@ __global__ __launch_bounds__(W1_THREADS) void w1_mfma_kernel(const double* __res
 // `wpw` waves of a workgroup work (the launch spreads the 16-row groups over all CUs; every workgroup carries the
 // factorisation's LDS, so there is one per CU).
 //
-// Workgroup 0 never waits for the others, and is dispatched first (workgroups are placed in the order of their index), so the
-// grid may be larger than the chip.  The ready word: block columns out (PC_DONE: g too, PC_FAIL: not positive definite);
+// Why waiting inside the launch is safe for ANY grid size: the only wait is for workgroup 0, and workgroup 0 waits for nobody.
+// Workgroups go to the XCDs round-robin and every XCD places its share in index order, so workgroup 0 is the first of this
+// launch that XCD 0 places: no workgroup of this launch can hold a CU of XCD 0 before it, and the panel workgroups spinning on
+// the other XCDs do not keep it from a CU.  (Another stream's kernel on XCD 0 delays it, and with it everyone; it does not
+// depend on this launch, so it ends.)  The ready word: block columns out (PC_DONE: g too, PC_FAIL: not positive definite);
 // s_build_kernel, the launch before, zeroes it.
 // The panel workgroups must not evaluate the observation model: x is updated by THIS launch (a workgroup placed late would
 // see moved means).  They read the Jacobian blocks s_build_kernel left (hblk).

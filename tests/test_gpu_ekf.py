@@ -990,7 +990,7 @@ def test_streamed_front_half_against_the_two_launches(pkg, monkeypatch, dtype, m
 
 def test_streamed_front_half_with_more_workgroups_than_compute_units(pkg, monkeypatch):
     """factor_w1_kernel's panel workgroups wait for the ONE workgroup that factors S; that is safe for any grid only because
-    workgroup 0 is placed first and never waits for the others.  N = 24000 (n = 48003, fp32): 3008 sixteen-row groups = 376
+    workgroup 0 never waits for the others and is the first of the launch its XCD places.  N = 24000 (n = 48003, fp32): 3008 sixteen-row groups = 376
     workgroups of eight working waves, more than the chip has CUs -- the late ones start after the early ones have left.  Compared
     with the two-launch form (SLAMHIP_X=128) bit for bit: mean, diagonal, and blocks from the head, the middle and the tail."""
     import bench as B
