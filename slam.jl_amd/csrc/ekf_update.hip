@@ -452,7 +452,9 @@ struct ProgC {
     double* C;               // [kp][pitch] row-major, as factor_body's emit_C leaves it
     int pitch, k;
     unsigned* ready;         // block columns out so far; PC_DONE: all of them and g; PC_FAIL: the factorisation failed
-    int mode;                // (experiments build, SLAMHIP_FW1: 1 = no drain and no ready word inside the elimination, 2 = no block column leaves before its end)
+    int mode;                // (experiments build, SLAMHIP_FW1: 1 = no drain and no ready word inside the elimination, 2 = no block column leaves before its end,
+                             //  16 = wave 0 stamps step 3 of the elimination into stamps[8..13] instead of the panel workgroup's stamps)
+    unsigned long long* stamps;
 };
 constexpr unsigned PC_DONE = 15u, PC_FAIL = 31u;
 typedef unsigned pc_u32x4 __attribute__((ext_vector_type(4)));
@@ -504,7 +506,7 @@ __device__ __forceinline__ void emit_c_part(const double* M, int mp, int Jc, con
 }
 
 __device__ __forceinline__ bool eliminate_blocked(double* M, int mp, int k, int kp, double* dvec, double* dinv, double* flag,
-                                                  bool four = true, const ProgC pc = ProgC{nullptr, 0, 0, nullptr, 0}) {
+                                                  bool four = true, const ProgC pc = ProgC{nullptr, 0, 0, nullptr, 0, nullptr}) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
     const int li = lane & 15, kk = lane >> 4;
@@ -571,7 +573,12 @@ __device__ __forceinline__ bool eliminate_blocked(double* M, int mp, int k, int 
             }
         }
     };
+#define ESTAMP(i)                                                                                             \
+    do {                                                                                                      \
+        if ((pc.mode & 16) && pc.stamps && J == 3 && tid == 0) pc.stamps[8 + (i)] = wall_clock64();           \
+    } while (0)
     for (int J = 0; J < nbk; ++J) {
+        ESTAMP(0);
         if (pc.ready && J > 0 && !(pc.mode & 2)) {
             // the block column the previous step completed goes out (the stores of the one before have had a step to drain)
             if (!(pc.mode & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -584,8 +591,10 @@ __device__ __forceinline__ bool eliminate_blocked(double* M, int mp, int k, int 
         const int tp = nbk - J;                       // trailing block rows of step J-1
         if (wave == 0) {
             if (J > 0) trailing(J - 1, 0, 1, 1);
+            ESTAMP(1);
             const bool okb = four ? factor_diag_block4(M, mp, J, dvec, dinv) : factor_diag_block(M, mp, J, dvec, dinv);
             if (!okb && lane == 0) flag[0] = 1.0;
+            ESTAMP(2);
         } else {
             if (J > 0) trailing(J - 1, wave, nwaves - 1, tp * (tp + 1) / 2);
             if (C < J) {
@@ -602,6 +611,7 @@ __device__ __forceinline__ bool eliminate_blocked(double* M, int mp, int k, int 
             }
         }
         __syncthreads();
+        ESTAMP(3);
         // (every wave has drained its stores of block column J - 2 before the barrier: the columns 0 .. J - 2 are out)
         if (pc.ready && !(pc.mode & 3) && J >= 2 && tid == nt - 1 && flag[0] == 0.0) __hip_atomic_store(pc.ready, (unsigned)(J - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- [B] (waves 1..nbk-1: at most 7 tasks, nbk <= 8)
@@ -625,8 +635,11 @@ __device__ __forceinline__ bool eliminate_blocked(double* M, int mp, int k, int 
 #pragma unroll
             for (int r = 0; r < 4; ++r) M[(16 * I + 4 * r + kk) * mp + 16 * J + li] = acc[r] * di;
         }
+        ESTAMP(4);
         __syncthreads();
+        ESTAMP(5);
     }
+#undef ESTAMP
     if (pc.ready && flag[0] == 0.0) {
         // the last block column that holds real columns (the padding's are zero: the readers do not wait for them); this drain is
         // the one that is paid for
@@ -800,7 +813,7 @@ __device__ __forceinline__ void factor_body(
     bool ok;
     if constexpr (!INLDS) ok = eliminate_in_memory(M, mp, k, mvec);
     else if (blocked) {
-        const ProgC pcs{Cout, c_pitch, k, ready, mode};      // (ready: C leaves block column by block column, factor_w1_kernel)
+        const ProgC pcs{Cout, c_pitch, k, ready, mode, stamps};      // (ready: C leaves block column by block column, factor_w1_kernel)
         ok = eliminate_blocked(M, mp, k, kp, rowbuf, rowbuf + kp, colbuf, blocked != 2, pcs);      // (2: one pivot per MFMA, experiments build)
     }
     else if (kp == 32) ok = eliminate_in_registers<2>(M, mp, k, kp, rowbuf, colbuf);
@@ -1233,7 +1246,7 @@ __device__ __forceinline__ void w1_stream_body(const TO* __restrict__ P, int ld,
                                                unsigned long long* __restrict__ stamps, int wpw, int mode) {
 #define CSTAMP(i)                                                                        \
     do {                                                                                 \
-        if (stamps && blockIdx.x == 1 && threadIdx.x == 0) stamps[8 + (i)] = wall_clock64(); \
+        if (stamps && !(mode & 16) && blockIdx.x == 1 && threadIdx.x == 0) stamps[8 + (i)] = wall_clock64(); \
     } while (0)
     CSTAMP(0);
     double* sh = lds;                                           // [HB_MAXOBS][10], then the state indices

@@ -20,8 +20,13 @@ for z in zs:
     rows.append((s - s[0]) / 100.0)
 rows = np.array(rows[8:])
 med = np.median(rows, axis=0)
-names = ["F start", "F jacobians", "F S in LDS", "F (S out)", "F eliminated", "F g", "F end", "-",
-         "P start", "P operands", "P block col 0 in", "P last block col in", "P last W1 out", "P g in", "P end", "-"]
+if int(os.environ.get("SLAMHIP_FW1", "0")) & 16:
+    names = ["F start", "F jacobians", "F S in LDS", "F (S out)", "F eliminated", "F g", "F end", "-",
+             "E step 3 starts", "E wave 0: trailing done", "E wave 0: diagonal block done", "E after barrier A", "E wave 0 at barrier B", "E after barrier B", "-", "-"]
+    print("(experiments build, SLAMHIP_FW1 bit 16: step 3 of the elimination, wave 0)")
+else:
+  names = ["F start", "F jacobians", "F S in LDS", "F (S out)", "F eliminated", "F g", "F end", "-",
+           "P start", "P operands", "P block col 0 in", "P last block col in", "P last W1 out", "P g in", "P end", "-"]
 print(f"N={N} nz={nz} SLAMHIP_X={os.environ.get('SLAMHIP_X', '0')}: median over {len(rows)} steps, us from the factorising workgroup's start")
 for n, v in zip(names, med):
     if n != "-":
