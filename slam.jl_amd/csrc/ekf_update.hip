@@ -201,12 +201,24 @@ __global__ __launch_bounds__(128) void s_build_kernel(const T* __restrict__ x, c
         for (int t = 0; t < 5; ++t)
             ph[t] = bb == 0 ? pht_entry(oj.Hv[0], oj.Hv[1], oj.Hv[2], oj.Hf[0], oj.Hf[1], pr[t][0], pr[t][1], pr[t][2], pr[t][3], pr[t][4])
                             : pht_entry(oj.Hv[3], oj.Hv[4], oj.Hv[5], oj.Hf[2], oj.Hf[3], pr[t][0], pr[t][1], pr[t][2], pr[t][3], pr[t][4]);
+        // Round 5: S leaves this kernel SYMMETRISED, S = (S + S') * 0.5 (ekf.jl:69) -- it used to be a pass of the factorising
+        // workgroup over its LDS copy, 2.8 us at the head of the serial chain.  The mirrored entry S[b][2i + ra] is formed HERE as
+        // workgroup j's thread 2i + ra forms it: from the transposed 5 x 5 block of P (the same 25 values: the stored matrix is
+        // symmetric entry for entry, sym_at(r, c) == sym_at(c, r)), with the same expressions in the same order.
 #pragma unroll
-        for (int ra = 0; ra < 2; ++ra) {                               // (factor_body's build_S expression)
-            double sv = oi.Hv[3 * ra + 0] * ph[0] + oi.Hv[3 * ra + 1] * ph[1] + oi.Hv[3 * ra + 2] * ph[2] + oi.Hf[2 * ra + 0] * ph[3] +
-                        oi.Hf[2 * ra + 1] * ph[4];
+        for (int ra = 0; ra < 2; ++ra) {
+            double sv = pht_entry(oi.Hv[3 * ra + 0], oi.Hv[3 * ra + 1], oi.Hv[3 * ra + 2], oi.Hf[2 * ra + 0], oi.Hf[2 * ra + 1], ph[0], ph[1], ph[2],
+                                  ph[3], ph[4]);                        // S[2i + ra][b]
             if (j == i) sv += ra ? (bb ? R3 : R1) : (bb ? R2 : R0);     // RR block = R (column-major args)
-            (ra ? row1 : row0)[b] = sv;
+            double pt[5];                                               // PHt[rows of observation j][2i + ra]
+#pragma unroll
+            for (int t = 0; t < 5; ++t)
+                pt[t] = pht_entry(oi.Hv[3 * ra + 0], oi.Hv[3 * ra + 1], oi.Hv[3 * ra + 2], oi.Hf[2 * ra + 0], oi.Hf[2 * ra + 1], pr[0][t], pr[1][t],
+                                  pr[2][t], pr[3][t], pr[4][t]);
+            double st = pht_entry(oj.Hv[3 * bb + 0], oj.Hv[3 * bb + 1], oj.Hv[3 * bb + 2], oj.Hf[2 * bb + 0], oj.Hf[2 * bb + 1], pt[0], pt[1], pt[2],
+                                  pt[3], pt[4]);                        // S[b][2i + ra]
+            if (j == i) st += bb ? (ra ? R3 : R1) : (ra ? R2 : R0);
+            (ra ? row1 : row0)[b] = (b == 2 * i + ra) ? sv : (sv + st) * 0.5;
         }
     }
 }
@@ -511,29 +523,8 @@ __device__ __forceinline__ bool eliminate_blocked(double* M, int mp, int k, int 
     const int lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
     const int li = lane & 15, kk = lane >> 4;
     const int nbk = (k + 15) >> 4;                    // blocks that hold real rows; the rest is identity padding
-    // S = (S + S')/2 (ekf.jl:69), in place; D = 1 on the padding
-    // thread (tr, tc) of a (nt/32) x 32 grid walks rows tr + (nt/32) i and columns tc + 32 u: no integer division,
-    // and the (at most four) column visits of a row are requested together
+    // (S arrives symmetrised: s_build_kernel forms S = (S + S')/2, ekf.jl:69, entry by entry.)  D = 1 on the padding
     const int tc = tid & 31, tr = tid >> 5, trs = nt >> 5;
-    for (int r = tr; r < kp; r += trs) {
-        double v1[4], v2[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c = tc + 32 * u;
-            const bool on = c < r;                    // (c < r < kp)
-            v1[u] = on ? M[r * mp + c] : 0.0;
-            v2[u] = on ? M[c * mp + r] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c = tc + 32 * u;
-            if (c < r) {
-                const double v = (v1[u] + v2[u]) * 0.5;
-                M[r * mp + c] = v;
-                M[c * mp + r] = v;
-            }
-        }
-    }
     for (int j = tid; j < kp; j += nt) { dvec[j] = 1.0; dinv[j] = 1.0; }
     if (tid == 0) flag[0] = 0.0;
     __syncthreads();
@@ -577,6 +568,7 @@ __device__ __forceinline__ bool eliminate_blocked(double* M, int mp, int k, int 
     do {                                                                                                      \
         if ((pc.mode & 16) && pc.stamps && J == 3 && tid == 0) pc.stamps[8 + (i)] = wall_clock64();           \
     } while (0)
+    if ((pc.mode & 16) && pc.stamps && tid == 0) pc.stamps[14] = wall_clock64();      // (the loop starts)
     for (int J = 0; J < nbk; ++J) {
         ESTAMP(0);
         if (pc.ready && J > 0 && !(pc.mode & 2)) {
@@ -640,15 +632,23 @@ __device__ __forceinline__ bool eliminate_blocked(double* M, int mp, int k, int 
         ESTAMP(5);
     }
 #undef ESTAMP
-    if (pc.ready && flag[0] == 0.0) {
-        // the last block column that holds real columns (the padding's are zero: the readers do not wait for them); this drain is
-        // the one that is paid for
-        if (pc.mode & 2)
-            for (int Jc = 0; Jc < nbk - 1; ++Jc) emit_c_part(M, mp, Jc, dvec, pc, wave, lane, nwaves);
-        emit_c_part(M, mp, nbk - 1, dvec, pc, wave, lane, nwaves);
+    if ((pc.mode & 16) && pc.stamps && tid == 0) pc.stamps[15] = wall_clock64();      // (the loop has ended)
+    if (pc.ready) {
+        // Streamed form: the last block column that holds real columns goes out (the padding's are zero: the readers do not wait for
+        // them) and its drain is the one that is paid for.  The inverse's off-diagonal blocks STAY above the diagonal, transposed
+        // (the caller's y / g products read them there: no pass over the matrix between the last pivot and the ready word); D goes
+        // on the diagonal -- the emission reads only strictly lower entries of the diagonal blocks.
+        if (flag[0] == 0.0) {
+            if (pc.mode & 2)
+                for (int Jc = 0; Jc < nbk - 1; ++Jc) emit_c_part(M, mp, Jc, dvec, pc, wave, lane, nwaves);
+            emit_c_part(M, mp, nbk - 1, dvec, pc, wave, lane, nwaves);
+        }
+        for (int j = tid; j < kp; j += nt) M[(size_t)j * mp + j] = dvec[j];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(pc.ready, (unsigned)nbk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool good = flag[0] == 0.0;
+        if (good && tid == 0) __hip_atomic_store(pc.ready, (unsigned)nbk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return good;
     }
     // the inverse's off-diagonal blocks move below the diagonal (over L, no longer needed); D goes on the diagonal
     for (int b = tr; b < kp; b += trs) {
@@ -831,12 +831,14 @@ __device__ __forceinline__ void factor_body(
     // mvec <- 1/sqrt(D)
     for (int b = tid; b < kp; b += nt) mvec[b] = (b < k) ? 1.0 / sqrt(M[(size_t)b * mp + b]) : 0.0;
     __syncthreads();
+    // (streamed form: inv(L)[b][a] of an earlier block column a sits transposed above the diagonal -- the same numbers in the same order)
+    const bool up = ready != nullptr;
     // y = C'*v :  y[b] = (v[b] + sum_{a<b} Linv[b][a] v[a]) / sqrt(D_b);  8 lanes per row
     for (int b0 = 0; b0 < kp; b0 += nt / 8) {
         const int b = b0 + (tid >> 3), part = tid & 7;
         double s = 0.0;
         if (b < k)       // (all 16 reads of a lane's share requested together, masked ones included: 4.8 against 3.4 us -- dropped)
-            for (int a = part; a < b; a += 8) s += M[(size_t)b * mp + a] * vvec[a];
+            for (int a = part; a < b; a += 8) s += ((up && (a >> 4) < (b >> 4)) ? M[(size_t)a * mp + b] : M[(size_t)b * mp + a]) * vvec[a];
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
         s += __shfl_xor(s, 4);
@@ -848,7 +850,7 @@ __device__ __forceinline__ void factor_body(
         const int a = a0 + (tid >> 3), part = tid & 7;
         double s = 0.0;
         if (a < k)
-            for (int b = a + 1 + part; b < k; b += 8) s += M[(size_t)b * mp + a] * mvec[b] * yvec[b];
+            for (int b = a + 1 + part; b < k; b += 8) s += ((up && (a >> 4) < (b >> 4)) ? M[(size_t)a * mp + b] : M[(size_t)b * mp + a]) * mvec[b] * yvec[b];
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
         s += __shfl_xor(s, 4);

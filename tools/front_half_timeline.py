@@ -22,7 +22,7 @@ rows = np.array(rows[8:])
 med = np.median(rows, axis=0)
 if int(os.environ.get("SLAMHIP_FW1", "0")) & 16:
     names = ["F start", "F jacobians", "F S in LDS", "F (S out)", "F eliminated", "F g", "F end", "-",
-             "E step 3 starts", "E wave 0: trailing done", "E wave 0: diagonal block done", "E after barrier A", "E wave 0 at barrier B", "E after barrier B", "-", "-"]
+             "E step 3 starts", "E wave 0: trailing done", "E wave 0: diagonal block done", "E after barrier A", "E wave 0 at barrier B", "E after barrier B", "E loop starts", "E loop ends"]
     print("(experiments build, SLAMHIP_FW1 bit 16: step 3 of the elimination, wave 0)")
 else:
   names = ["F start", "F jacobians", "F S in LDS", "F (S out)", "F eliminated", "F g", "F end", "-",
