@@ -215,8 +215,9 @@ __global__ __launch_bounds__(128) void s_build_kernel(const T* __restrict__ x, c
             for (int t = 0; t < 5; ++t)
                 pt[t] = pht_entry(oi.Hv[3 * ra + 0], oi.Hv[3 * ra + 1], oi.Hv[3 * ra + 2], oi.Hf[2 * ra + 0], oi.Hf[2 * ra + 1], pr[0][t], pr[1][t],
                                   pr[2][t], pr[3][t], pr[4][t]);
-            double st = pht_entry(oj.Hv[3 * bb + 0], oj.Hv[3 * bb + 1], oj.Hv[3 * bb + 2], oj.Hf[2 * bb + 0], oj.Hf[2 * bb + 1], pt[0], pt[1], pt[2],
-                                  pt[3], pt[4]);                        // S[b][2i + ra]
+            // (row bb of observation j's Jacobian picked by selects: indexed with bb the whole model went to scratch)
+            double st = pht_entry(bb ? oj.Hv[3] : oj.Hv[0], bb ? oj.Hv[4] : oj.Hv[1], bb ? oj.Hv[5] : oj.Hv[2], bb ? oj.Hf[2] : oj.Hf[0],
+                                  bb ? oj.Hf[3] : oj.Hf[1], pt[0], pt[1], pt[2], pt[3], pt[4]);      // S[b][2i + ra]
             if (j == i) st += bb ? (ra ? R3 : R1) : (ra ? R2 : R0);
             (ra ? row1 : row0)[b] = (b == 2 * i + ra) ? sv : (sv + st) * 0.5;
         }

@@ -45,6 +45,19 @@ def test_library_exports_every_declared_symbol(pkg):
     assert sorted(pkg._lib.SIGNATURES) == declared_symbols()
 
 
+def test_product_library_is_not_the_laboratory(pkg):
+    """The product library exports exactly what the two headers declare (no slam_exp_* entry, no debug trace) and contains none of
+    the experiments build's environment switches: those live in libslamhip_exp.so (make exp), which no test and no bench loads."""
+    out = subprocess.run(["nm", "-D", "--defined-only", pkg._lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if " T " in line and line.split()[-1].startswith("slam_"))
+    assert exported == declared_symbols(), sorted(set(exported) ^ set(declared_symbols()))
+    blob = open(pkg._lib.LIB_PATH, "rb").read()
+    for name in (b"SLAMHIP_DEBUG", b"SLAMHIP_FW1", b"SLAMHIP_STAMPS", b"SLAMHIP_WGS", b"SLAMHIP_PB_W", b"SLAMHIP_W1DBG", b"SLAMHIP_SP"):
+        assert name not in blob, name
+    for name in (b"SLAMHIP_X", b"SLAMHIP_ROCTX"):                  # (the product's own switches are there)
+        assert name in blob, name
+
+
 def test_library_has_no_torch_or_python_dependency(pkg):
     out = subprocess.run(["ldd", pkg._lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "libamdhip64" in out
