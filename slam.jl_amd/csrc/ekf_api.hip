@@ -692,6 +692,10 @@ static int read_status(slam_ekf* h, int sticky) {
     const int bad = sticky ? h->h_status[1] : h->h_status[0];
     if (h->h_status[1]) HIP_TRY(hipMemsetAsync(h->d_status + 1, 0, sizeof(int32_t), h->stream));
     h->pending_status = 0;
+    if (bad == 2) {      // (factor_w1_kernel: a panel wave gave up waiting for the factorising workgroup -- a defect, not a property of the data)
+        slam_set_error("update: the factorisation did not publish within 2 s; covariance unchanged, the mean may be partly updated");
+        return SLAM_E_HIP;
+    }
     if (bad) {
         slam_set_error("innovation covariance S is not positive definite (state left unchanged)");
         return SLAM_E_NOTPD;

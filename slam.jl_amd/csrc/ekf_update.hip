@@ -470,6 +470,7 @@ struct ProgC {
     unsigned long long* stamps;
 };
 constexpr unsigned PC_DONE = 15u, PC_FAIL = 31u;
+constexpr unsigned long long FW1_TIMEOUT = 200000000ull;      // ticks of wall_clock64 (100 MHz): 2 s
 typedef unsigned pc_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2_pc __attribute__((ext_vector_type(2)));
 // Block column Jc of C from the elimination's working matrix (see above), one 16 x 16 block per WAVE (waves 1 .. Jc: the blocks
@@ -1246,7 +1247,7 @@ __device__ __forceinline__ void w1_stream_body(const TO* __restrict__ P, int ld,
                                                double* lds, TO* __restrict__ W1, int pitchW, TO* __restrict__ x,
                                                const double* __restrict__ g, char* __restrict__ img, int img_nch,
                                                unsigned long long* __restrict__ drift, const unsigned* __restrict__ ready,
-                                               unsigned long long* __restrict__ stamps, int wpw, int mode) {
+                                               unsigned long long* __restrict__ stamps, int wpw, int mode, int32_t* __restrict__ status) {
 #define CSTAMP(i)                                                                        \
     do {                                                                                 \
         if (stamps && !(mode & 16) && blockIdx.x == 1 && threadIdx.x == 0) stamps[8 + (i)] = wall_clock64(); \
@@ -1298,11 +1299,22 @@ __device__ __forceinline__ void w1_stream_body(const TO* __restrict__ P, int ld,
         CSTAMP(1);
         const int nbk = (k + 15) >> 4;                          // block columns with real columns; the others of W1 are zero
         const auto rsc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Cmat), (short)0, 0x7fffffff, 0x00020000);
-        // the ready word, read by ONE lane at agent scope (sc1) until it covers `need`
+        // the ready word, read by ONE lane at agent scope (sc1) until it covers `need`.  Bounded: a factorising workgroup that has not
+        // published after FW1_TIMEOUT (2 s of the 100 MHz clock; the whole kernel takes 50 us) is a defect, and the wave then gives up
+        // LOUDLY -- status 2, the down-date behind this launch does not run, slam_ekf_sync reports it -- instead of hanging the device.
         auto wait_for = [&](unsigned need) __attribute__((always_inline)) {
             unsigned v = 0;
-            if (lane == 0)
-                while ((v = ld_agent(ready)) < need) __builtin_amdgcn_s_sleep(16);
+            if (lane == 0) {
+                const unsigned long long t0 = wall_clock64();
+                while ((v = ld_agent(ready)) < need) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (wall_clock64() - t0 > FW1_TIMEOUT) {
+                        status[0] = 2; status[1] = 2;
+                        v = PC_FAIL;
+                        break;
+                    }
+                }
+            }
             return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
         };
         // column block cb of W1 and of its bf16 image (layout: see w1_mfma_body)
@@ -1419,6 +1431,7 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_w1_kernel(
     int n, int npad, int tile_log2, const double* __restrict__ hblk, T* __restrict__ W1, int pitchW, char* __restrict__ img, int img_nch,
     unsigned* __restrict__ dd_claim, unsigned long long* __restrict__ drift, unsigned* __restrict__ sync, int wpw, int mode) {
     if (blockIdx.x == 0) {
+        if (mode & 32) return;      // (experiments build, SLAMHIP_FW1 bit 32: the factorising workgroup publishes NOTHING -- what the panel waves' timeout is for)
         factor_body<T, true>(x, Sg, s_pitch, z, idf, m, k, kp, R0, R1, R2, R3, Cout, c_pitch, gvec, (double*)nullptr, 0, (double*)nullptr,
                              status, stamps, dcount, blocked, sync, mode);
         return;
@@ -1428,10 +1441,10 @@ __global__ __launch_bounds__(FACTOR_THREADS) void factor_w1_kernel(
     SLAM_DEVICE_COUNT(dcount, m, k, kp)
     if (m == 0) return;                                          // (workgroup 0 returns the same way: nobody waits)
     extern __shared__ double lds[];
-    if (kp == 32) w1_stream_body<T, 2>(P, ld, tile_log2, n, npad, m, k, hblk, Cout, c_pitch, lds, W1, pitchW, x, gvec, img, img_nch, drift, sync, stamps, wpw, mode);
-    else if (kp == 64) w1_stream_body<T, 4>(P, ld, tile_log2, n, npad, m, k, hblk, Cout, c_pitch, lds, W1, pitchW, x, gvec, img, img_nch, drift, sync, stamps, wpw, mode);
-    else if (kp == 96) w1_stream_body<T, 6>(P, ld, tile_log2, n, npad, m, k, hblk, Cout, c_pitch, lds, W1, pitchW, x, gvec, img, img_nch, drift, sync, stamps, wpw, mode);
-    else w1_stream_body<T, 8>(P, ld, tile_log2, n, npad, m, k, hblk, Cout, c_pitch, lds, W1, pitchW, x, gvec, img, img_nch, drift, sync, stamps, wpw, mode);
+    if (kp == 32) w1_stream_body<T, 2>(P, ld, tile_log2, n, npad, m, k, hblk, Cout, c_pitch, lds, W1, pitchW, x, gvec, img, img_nch, drift, sync, stamps, wpw, mode, status);
+    else if (kp == 64) w1_stream_body<T, 4>(P, ld, tile_log2, n, npad, m, k, hblk, Cout, c_pitch, lds, W1, pitchW, x, gvec, img, img_nch, drift, sync, stamps, wpw, mode, status);
+    else if (kp == 96) w1_stream_body<T, 6>(P, ld, tile_log2, n, npad, m, k, hblk, Cout, c_pitch, lds, W1, pitchW, x, gvec, img, img_nch, drift, sync, stamps, wpw, mode, status);
+    else w1_stream_body<T, 8>(P, ld, tile_log2, n, npad, m, k, hblk, Cout, c_pitch, lds, W1, pitchW, x, gvec, img, img_nch, drift, sync, stamps, wpw, mode, status);
 }
 
 // x += PHt * g      (ekf.jl:74 with W*v = PHt*(C*C'*v)); 8 lanes per row
