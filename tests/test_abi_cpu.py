@@ -126,6 +126,26 @@ def test_host_helpers(pkg):
     assert ekf._obs(np.zeros((2, 0))).shape == (0, 2)
 
 
+def test_batch_packing_for_the_k_step_call(pkg):
+    """Host logic of FastSLAM.step_async_batch / slam_pf_step_auto_batch (no GPU): K steps packed once in the layout the entry point
+    takes -- controls K x (V, G) contiguous, observations as (range, bearing) pairs padded to the widest step, ids padded with
+    zeros, the force words -1 (Neff rule) / 0 / 1."""
+    z1 = np.array([[10.0, 20.0, 30.0], [0.1, 0.2, 0.3]])
+    z2 = np.array([[5.0], [-0.5]])
+    K, vg, zz, ii, ms, stride, ff = pkg.PFShard.prepare_batch([(1.0, 0.1), (2.0, -0.2), (3.0, 0.0)], [(z1, [4, 2, 9]), (z2, [7]), (np.zeros((2, 0)), [])],
+                                                              [None, False, True])
+    assert K == 3 and stride == 3 and ms.tolist() == [3, 1, 0] and ms.dtype == np.int32
+    assert vg.flags["C_CONTIGUOUS"] and vg.tolist() == [[1.0, 0.1], [2.0, -0.2], [3.0, 0.0]]
+    assert zz.shape == (3, 3, 2) and zz[0].tolist() == [[10.0, 0.1], [20.0, 0.2], [30.0, 0.3]] and zz[1, 0].tolist() == [5.0, -0.5]
+    assert not zz[1, 1:].any() and not zz[2].any()
+    assert ii.dtype == np.int32 and ii.tolist() == [[4, 2, 9], [7, 0, 0], [0, 0, 0]]
+    assert ff.tolist() == [-1, 0, 1] and ff.dtype == np.int32
+    assert pkg.PFShard.prepare_batch([(1.0, 0.0)] * 2, [(z2, [1])] * 2)[6].tolist() == [-1, -1]          # the Neff rule at every step
+    assert pkg.PFShard.prepare_batch([(1.0, 0.0)] * 2, [(z2, [1])] * 2, False)[6].tolist() == [0, 0]     # one word for all
+    with pytest.raises(ValueError):
+        pkg.PFShard.prepare_batch([(1.0, 0.0)] * 2, [(z2, [1])] * 2, [True])
+
+
 def test_sim_driver_pieces(pkg, golden_dir):
     import math
     S = pkg.sim
